@@ -1,0 +1,53 @@
+"""Ahead-of-time build of libhelio.so (hipcc, gfx950 only).
+
+The library is built IN-TREE (doodle_amd/libhelio.so) so that it travels with the
+repository snapshot to the GPU box; nothing is JIT-compiled at import time.
+hipcc cross-compiles for gfx950 without a GPU present.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libhelio.so")
+SOURCES = ["abi.hip", "geometry.hip", "splat_fwd.hip", "splat_bwd.hip"]
+HEADERS = [os.path.join(CSRC, "helio_math.h"), os.path.join(ROOT, "include", "helio.h")]
+# -ffp-contract=off: the geometry stage is bit-faithful to the reference's fp32 CPU
+# arithmetic; FMAs appear only where written (helio_math.h).  Division and sqrt stay
+# correctly rounded (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt).
+FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-std=c++17", "-ffp-contract=off",
+         "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wno-pass-failed"]
+
+
+def hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    return "hipcc"
+
+
+def is_stale() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + HEADERS
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    if not force and not is_stale():
+        return LIB
+    cmd = [hipcc(), *FLAGS, "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-o", LIB,
+           *[os.path.join(CSRC, s) for s in SOURCES]]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,120 @@
+// extern "C" entry points of libhelio.so (declared in include/helio.h).
+// Validates sizes and pointers on the host BEFORE any launch (a faulting kernel can
+// reset the whole node), enqueues on the caller's stream, never synchronises, never
+// allocates.  No exception crosses the boundary: errors are negative return codes plus
+// a thread-local message.
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include "helio.h"
+
+namespace helio {
+void launch_geometry_fwd(int, int, const float*, const float*, const float*, const float*, long,
+                         const helio_plane*, float*, float*, float*, hipStream_t);
+void launch_geometry_bwd(int, int, int, const float*, const float*, const float*, const float*, long,
+                         const helio_plane*, const float*, const float*, const float*, float*, hipStream_t);
+void launch_ideal_normals(int, int, const float*, const float*, const float*, float*, hipStream_t);
+int launch_splat_fwd(int, int, int, const float*, const float*, const float*, float*, int, hipStream_t);
+void launch_splat_bwd(int, int, int, const float*, const float*, const float*, const float*, float*, hipStream_t);
+int splat_bwd_blocks(int);
+}  // namespace helio
+
+namespace {
+thread_local char g_err[256] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int after_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(HELIO_E_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+    return HELIO_OK;
+}
+
+bool sizes_ok(int B, int N) { return B >= 1 && N >= 1 && B <= 65535 && (long)B * N <= (1l << 31) / 4; }
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+}  // namespace
+
+extern "C" {
+
+int helio_abi_version(void) { return HELIO_ABI_VERSION; }
+const char* helio_last_error_string(void) { return g_err; }
+
+int helio_device_arch(int device, char* buf, int buflen) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(HELIO_E_NODEVICE, "no HIP device %d", device);
+    }
+    if (buf && buflen > 0) { strncpy(buf, prop.gcnArchName, buflen - 1); buf[buflen - 1] = 0; }
+    return HELIO_OK;
+}
+
+int helio_geometry_fwd(int B, int N, const float* helios_d, const float* sun_d, const float* action_d,
+                       const float* trig_d, long trig_b_stride, const helio_plane* plane,
+                       float* actual_d, float* refl_d, float* rays_d, void* stream) {
+    if (!sizes_ok(B, N)) return fail(HELIO_E_INVALID, "geometry_fwd: bad sizes B=%d N=%d", B, N);
+    if (!helios_d || !sun_d || !action_d || !trig_d || !plane || !actual_d)
+        return fail(HELIO_E_INVALID, "geometry_fwd: null pointer");
+    if (trig_b_stride != 0 && trig_b_stride != 4l * N)
+        return fail(HELIO_E_INVALID, "geometry_fwd: trig_b_stride must be 0 or 4*N");
+    if (!aligned16(trig_d) || (rays_d && !aligned16(rays_d)))
+        return fail(HELIO_E_INVALID, "geometry_fwd: trig/rays must be 16-byte aligned");
+    helio::launch_geometry_fwd(B, N, helios_d, sun_d, action_d, trig_d, trig_b_stride, plane, actual_d,
+                               refl_d, rays_d, static_cast<hipStream_t>(stream));
+    return after_launch("geometry_fwd");
+}
+
+int helio_splat_fwd(int B, int N, int R, const float* rays_d, const float* xs_d, const float* ys_d,
+                    float* image_d, int variant, void* stream) {
+    if (!sizes_ok(B, N) || R < 1 || R > 16384) return fail(HELIO_E_INVALID, "splat_fwd: bad sizes B=%d N=%d R=%d", B, N, R);
+    if (!rays_d || !xs_d || !ys_d || !image_d) return fail(HELIO_E_INVALID, "splat_fwd: null pointer");
+    if (!aligned16(rays_d) || !aligned16(image_d)) return fail(HELIO_E_INVALID, "splat_fwd: rays/image must be 16-byte aligned");
+    if (helio::launch_splat_fwd(B, N, R, rays_d, xs_d, ys_d, image_d, variant, static_cast<hipStream_t>(stream)) != HELIO_OK)
+        return fail(HELIO_E_INVALID, "splat_fwd: unknown variant %d", variant);
+    return after_launch("splat_fwd");
+}
+
+int helio_splat_bwd_blocks(int R) { return R >= 1 ? helio::splat_bwd_blocks(R) : 0; }
+
+int helio_splat_bwd(int B, int N, int R, const float* rays_d, const float* xs_d, const float* ys_d,
+                    const float* grad_image_d, float* moments_d, void* stream) {
+    if (!sizes_ok(B, N) || R < 1 || R > 16384) return fail(HELIO_E_INVALID, "splat_bwd: bad sizes B=%d N=%d R=%d", B, N, R);
+    if (!rays_d || !xs_d || !ys_d || !grad_image_d || !moments_d) return fail(HELIO_E_INVALID, "splat_bwd: null pointer");
+    if (!aligned16(rays_d) || !aligned16(grad_image_d)) return fail(HELIO_E_INVALID, "splat_bwd: rays/grad_image must be 16-byte aligned");
+    helio::launch_splat_bwd(B, N, R, rays_d, xs_d, ys_d, grad_image_d, moments_d, static_cast<hipStream_t>(stream));
+    return after_launch("splat_bwd");
+}
+
+int helio_geometry_bwd(int B, int N, int n_blocks, const float* helios_d, const float* sun_d,
+                       const float* action_d, const float* trig_d, long trig_b_stride,
+                       const helio_plane* plane, const float* moments_d, const float* grad_actual_d,
+                       const float* grad_refl_d, float* grad_action_d, void* stream) {
+    if (!sizes_ok(B, N)) return fail(HELIO_E_INVALID, "geometry_bwd: bad sizes B=%d N=%d", B, N);
+    if (!helios_d || !sun_d || !action_d || !trig_d || !plane || !grad_action_d)
+        return fail(HELIO_E_INVALID, "geometry_bwd: null pointer");
+    if (moments_d && n_blocks < 1) return fail(HELIO_E_INVALID, "geometry_bwd: n_blocks must be >= 1 with moments");
+    if (trig_b_stride != 0 && trig_b_stride != 4l * N)
+        return fail(HELIO_E_INVALID, "geometry_bwd: trig_b_stride must be 0 or 4*N");
+    if (!aligned16(trig_d)) return fail(HELIO_E_INVALID, "geometry_bwd: trig must be 16-byte aligned");
+    helio::launch_geometry_bwd(B, N, n_blocks, helios_d, sun_d, action_d, trig_d, trig_b_stride, plane,
+                               moments_d, grad_actual_d, grad_refl_d, grad_action_d,
+                               static_cast<hipStream_t>(stream));
+    return after_launch("geometry_bwd");
+}
+
+int helio_ideal_normals(int B, int N, const float* helios_d, const float* sun_d,
+                        const float target_position[3], float* out_d, void* stream) {
+    if (!sizes_ok(B, N)) return fail(HELIO_E_INVALID, "ideal_normals: bad sizes B=%d N=%d", B, N);
+    if (!helios_d || !sun_d || !target_position || !out_d) return fail(HELIO_E_INVALID, "ideal_normals: null pointer");
+    helio::launch_ideal_normals(B, N, helios_d, sun_d, target_position, out_d, static_cast<hipStream_t>(stream));
+    return after_launch("ideal_normals");
+}
+
+}  // extern "C"

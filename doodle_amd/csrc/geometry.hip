@@ -1,0 +1,230 @@
+// Per-ray geometry kernels (forward, backward, ideal normals) for gfx950.
+//
+// One thread per ray (b,n); a ray reads 12 B of action, 16 B of trig, 12 B of
+// heliostat position (L2-resident) and writes 12+12+16 B: the stage is pure HBM
+// streaming and a rounding error of the chip's time (the splat dominates).  What
+// matters here is bit-fidelity with the reference (helio_math.h).
+//
+// Reference: newenv_rl_test_multi_error.py :78-104 (rotation), :369-373 (leaky
+// ReLU + renormalise), :376-383 (incident, reflection), :52-75 (intersection),
+// :126-127,:146 (sigma), :256-278 (ideal normals).
+#include <hip/hip_runtime.h>
+#include "helio.h"
+#include "helio_math.h"
+
+namespace helio {
+
+struct PlaneK {  // helio_plane by value in kernel-argument space
+    vec3 o, nrm, u, v, w;
+    float sigma_scale;
+};
+
+// Everything the forward computes for one ray; the backward recomputes it.
+struct Ray {
+    float ze_pre;          // rotated Z before the leaky ReLU
+    vec3 vrot;             // rotated + leaky-clamped, un-normalised
+    float nv;              // max(|vrot|,1e-9)
+    vec3 act;              // `actual` (output #2)
+    vec3 inc;              // unit incident direction (heliostat → sun)
+    float na;              // max(|act|,1e-9)
+    vec3 nh;               // act re-normalised inside reflect_vectors
+    float dots;
+    vec3 r0;  float nr0;   // un-normalised reflection and its clamped norm
+    vec3 r;                // `refl` (output #3)
+    vec3 phat;
+    float denom, t;  bool valid;
+    vec3 x;                // intersection (0 if invalid)
+    vec3 dh;  float dist, sraw, sigma, two_raw, two_s2;
+    vec3 d0;  float a, b, c, c2, k2;
+};
+
+__device__ __forceinline__ Ray trace(vec3 nin, float ce, float se, float cu, float su,
+                                     vec3 h, vec3 s, const PlaneK& P) {
+    Ray q;
+    // :96-102  rotate about Up (Z) then East (X); every op individually rounded
+    float xu = __fsub_rn(__fmul_rn(cu, nin.x), __fmul_rn(su, nin.y));
+    float yu = __fadd_rn(__fmul_rn(su, nin.x), __fmul_rn(cu, nin.y));
+    float ye = __fsub_rn(__fmul_rn(ce, yu), __fmul_rn(se, nin.z));
+    float ze = __fadd_rn(__fmul_rn(se, yu), __fmul_rn(ce, nin.z));
+    q.ze_pre = ze;
+    ze = ze > 0.0f ? ze : __fmul_rn(ze, 0.01f);                  // :369 leaky_relu(0.01)
+    q.vrot = {xu, ye, ze};
+    q.act = unit3(q.vrot, q.nv);                                  // :372
+    q.inc = unit3(sub3(s, h));                                    // :377-380
+    q.nh = unit3(q.act, q.na);                                    // :48
+    q.dots = -dot3(q.inc, q.nh);                                  // :49
+    float two = __fmul_rn(2.0f, q.dots);
+    q.r0 = {__fsub_rn(-q.inc.x, __fmul_rn(two, q.nh.x)),          // :50
+            __fsub_rn(-q.inc.y, __fmul_rn(two, q.nh.y)),
+            __fsub_rn(-q.inc.z, __fmul_rn(two, q.nh.z))};
+    q.r = unit3(q.r0, q.nr0);                                     // :383
+    q.phat = unit3(P.nrm);                                        // :60
+    q.denom = dot3(q.r, q.phat);                                  // :62
+    q.valid = fabsf(q.denom) > 1e-9f;                             // :63
+    float safe = q.valid ? q.denom : 1e-9f;                       // :65
+    q.t = __fdiv_rn(dot3(sub3(P.o, h), q.phat), safe);            // :67
+    float st = q.valid ? q.t : 0.0f;                              // :69
+    q.x = add3(h, scale3(st, q.r));                               // :71
+    if (!q.valid) q.x = {0.0f, 0.0f, 0.0f};                       // :73
+    // per-ray constants of the footprint, :126-127 and :146
+    q.dh = sub3(q.x, h);
+    q.dist = norm3(q.dh);
+    q.sraw = __fmul_rn(P.sigma_scale, q.dist);
+    q.sigma = fmaxf(q.sraw, 1e-9f);
+    q.two_raw = __fmul_rn(2.0f, __fmul_rn(q.sigma, q.sigma));
+    q.two_s2 = fmaxf(q.two_raw, 1e-12f);
+    // separable restatement of :134-148: with d0 = o - x and the
+    // orthonormal frame (u, v, w = u×v),  |P_ij - x|² = (xs_i+a)² + (ys_j+b)² + c²
+    q.d0 = sub3(P.o, q.x);
+    q.a = dot3(q.d0, P.u);
+    q.b = dot3(q.d0, P.v);
+    q.c = dot3(q.d0, P.w);
+    q.c2 = __fmul_rn(q.c, q.c);
+    q.k2 = q.valid ? __fdiv_rn(1.44269504088896340736f, q.two_s2) : 0.0f;
+    return q;
+}
+
+__global__ void __launch_bounds__(256)
+geometry_fwd_kernel(int B, int N, const float* __restrict__ helios, const float* __restrict__ sun,
+                    const float* __restrict__ action, const float* __restrict__ trig, long trig_b_stride,
+                    PlaneK P, float* __restrict__ actual, float* __restrict__ refl,
+                    float* __restrict__ rays) {
+    const long M = (long)B * N;
+    for (long m = (long)blockIdx.x * blockDim.x + threadIdx.x; m < M; m += (long)gridDim.x * blockDim.x) {
+        const int b = (int)(m / N), n = (int)(m - (long)b * N);
+        const float4 tg = *reinterpret_cast<const float4*>(trig + (long)b * trig_b_stride + 4l * n);
+        Ray q = trace(ld3(action + 3 * m), tg.x, tg.y, tg.z, tg.w, ld3(helios + 3l * n), ld3(sun + 3l * b), P);
+        st3(actual + 3 * m, q.act);
+        if (refl) st3(refl + 3 * m, q.r);
+        if (rays) *reinterpret_cast<float4*>(rays + 4 * m) = make_float4(q.a, q.b, q.k2, q.c2);
+    }
+}
+
+// Adjoint of y = v / max(|v|, 1e-9) given n = the clamped norm and y.
+__device__ __forceinline__ vec3 unit_bwd(vec3 gy, vec3 y, float n, bool clamped) {
+    if (clamped) return {gy.x / n, gy.y / n, gy.z / n};          // norm path has zero gradient
+    float p = gy.x * y.x + gy.y * y.y + gy.z * y.z;
+    return {(gy.x - y.x * p) / n, (gy.y - y.y * p) / n, (gy.z - y.z * p) / n};
+}
+
+__global__ void __launch_bounds__(256)
+geometry_bwd_kernel(int B, int N, int n_blocks,
+                    const float* __restrict__ helios, const float* __restrict__ sun,
+                    const float* __restrict__ action, const float* __restrict__ trig, long trig_b_stride,
+                    PlaneK P, const float* __restrict__ moments,
+                    const float* __restrict__ g_actual, const float* __restrict__ g_refl,
+                    float* __restrict__ g_action) {
+    const float LN2 = 0.69314718055994530942f;
+    const long M = (long)B * N;
+    for (long m = (long)blockIdx.x * blockDim.x + threadIdx.x; m < M; m += (long)gridDim.x * blockDim.x) {
+        const int b = (int)(m / N), n = (int)(m - (long)b * N);
+        const float4 tg = *reinterpret_cast<const float4*>(trig + (long)b * trig_b_stride + 4l * n);
+        const float ce = tg.x, se = tg.y, cu = tg.z, su = tg.w;
+        const vec3 h = ld3(helios + 3l * n);
+        Ray q = trace(ld3(action + 3 * m), ce, se, cu, su, h, ld3(sun + 3l * b), P);
+
+        vec3 gr = g_refl ? ld3(g_refl + 3 * m) : vec3{0.f, 0.f, 0.f};
+        if (moments && q.valid) {
+            // fixed-order sum of the column-block partials → deterministic
+            float M0 = 0.f, Mx = 0.f, My = 0.f, Mxx = 0.f, Myy = 0.f;
+            for (int jb = 0; jb < n_blocks; ++jb) {
+                const float* p = moments + (((long)b * n_blocks + jb) * N + n) * HELIO_MOMENT_STRIDE;
+                M0 += p[0]; Mx += p[1]; My += p[2]; Mxx += p[3]; Myy += p[4];
+            }
+            // gauss = exp2(-q k2), q = t² + s² + c2  →  cotangents of (a, b, k2, c2)
+            const float ga = -2.0f * LN2 * q.k2 * Mx;
+            const float gb = -2.0f * LN2 * q.k2 * My;
+            const float gk2 = -LN2 * (Mxx + Myy + q.c2 * M0);
+            const float gc2 = -LN2 * q.k2 * M0;
+            // a = d0·u, b = d0·v, c2 = (d0·w)², d0 = o - x
+            const float gc = 2.0f * q.c * gc2;
+            vec3 gx = {-(ga * P.u.x + gb * P.v.x + gc * P.w.x),
+                       -(ga * P.u.y + gb * P.v.y + gc * P.w.y),
+                       -(ga * P.u.z + gb * P.v.z + gc * P.w.z)};
+            // k2 = log2e / max(2σ²,1e-12); σ = max(σs |x-h|, 1e-9)
+            if (q.two_raw >= 1e-12f && q.sraw >= 1e-9f && q.dist > 0.0f) {
+                const float g_two = -gk2 * q.k2 / q.two_s2;
+                const float g_dist = g_two * 4.0f * q.sigma * P.sigma_scale;
+                gx.x += g_dist * q.dh.x / q.dist;
+                gx.y += g_dist * q.dh.y / q.dist;
+                gx.z += g_dist * q.dh.z / q.dist;
+            }
+            // x = h + t r,  t = num / denom,  denom = r·p̂
+            const float gt = gx.x * q.r.x + gx.y * q.r.y + gx.z * q.r.z;
+            const float gden = -gt * q.t / q.denom;
+            gr.x += q.t * gx.x + gden * q.phat.x;
+            gr.y += q.t * gx.y + gden * q.phat.y;
+            gr.z += q.t * gx.z + gden * q.phat.z;
+        }
+        // r = r0 / max(|r0|,1e-9)
+        vec3 gr0 = unit_bwd(gr, q.r, q.nr0, norm3(q.r0) < 1e-9f);
+        // r0 = -inc - (2 dots) n̂ ;  dots = -(inc·n̂)   (inc does not depend on the action)
+        const float gdots = -2.0f * (gr0.x * q.nh.x + gr0.y * q.nh.y + gr0.z * q.nh.z);
+        const float two = 2.0f * q.dots;
+        vec3 gnh = {-two * gr0.x - gdots * q.inc.x, -two * gr0.y - gdots * q.inc.y, -two * gr0.z - gdots * q.inc.z};
+        // n̂ = act / max(|act|,1e-9) ; act also is an output
+        vec3 gact = unit_bwd(gnh, q.nh, q.na, norm3(q.act) < 1e-9f);
+        if (g_actual) { vec3 e = ld3(g_actual + 3 * m); gact.x += e.x; gact.y += e.y; gact.z += e.z; }
+        // act = vrot / max(|vrot|,1e-9)
+        vec3 gv = unit_bwd(gact, q.act, q.nv, norm3(q.vrot) < 1e-9f);
+        // leaky ReLU on Z, then the two rotations transposed
+        const float gze = q.ze_pre > 0.0f ? gv.z : gv.z * 0.01f;
+        const float gyu = ce * gv.y + se * gze;
+        const float gz = -se * gv.y + ce * gze;
+        const float gxin = cu * gv.x + su * gyu;
+        const float gyin = -su * gv.x + cu * gyu;
+        st3(g_action + 3 * m, {gxin, gyin, gz});
+    }
+}
+
+__global__ void __launch_bounds__(256)
+ideal_normals_kernel(int B, int N, const float* __restrict__ helios, const float* __restrict__ sun,
+                     vec3 target, float* __restrict__ out) {
+    const long M = (long)B * N;
+    for (long m = (long)blockIdx.x * blockDim.x + threadIdx.x; m < M; m += (long)gridDim.x * blockDim.x) {
+        const int b = (int)(m / N), n = (int)(m - (long)b * N);
+        const vec3 h = ld3(helios + 3l * n);
+        vec3 s = add3(unit3(sub3(ld3(sun + 3l * b), h)), unit3(sub3(target, h)));   // :264-266 / :275-277
+        st3(out + 3 * m, unit3(s));                                                  // :267 / :278
+    }
+}
+
+static inline PlaneK to_k(const helio_plane* p) {
+    PlaneK k;
+    k.o = {p->origin[0], p->origin[1], p->origin[2]};
+    k.nrm = {p->normal[0], p->normal[1], p->normal[2]};
+    k.u = {p->u[0], p->u[1], p->u[2]};
+    k.v = {p->v[0], p->v[1], p->v[2]};
+    k.w = {p->w[0], p->w[1], p->w[2]};
+    k.sigma_scale = p->sigma_scale;
+    return k;
+}
+
+static inline int ray_grid(long M) {
+    long g = (M + 255) / 256;
+    return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
+}
+
+void launch_geometry_fwd(int B, int N, const float* helios, const float* sun, const float* action,
+                         const float* trig, long trig_b_stride, const helio_plane* plane,
+                         float* actual, float* refl, float* rays, hipStream_t st) {
+    hipLaunchKernelGGL(geometry_fwd_kernel, dim3(ray_grid((long)B * N)), dim3(256), 0, st,
+                       B, N, helios, sun, action, trig, trig_b_stride, to_k(plane), actual, refl, rays);
+}
+
+void launch_geometry_bwd(int B, int N, int n_blocks, const float* helios, const float* sun,
+                         const float* action, const float* trig, long trig_b_stride,
+                         const helio_plane* plane, const float* moments, const float* g_actual,
+                         const float* g_refl, float* g_action, hipStream_t st) {
+    hipLaunchKernelGGL(geometry_bwd_kernel, dim3(ray_grid((long)B * N)), dim3(256), 0, st,
+                       B, N, n_blocks, helios, sun, action, trig, trig_b_stride, to_k(plane), moments,
+                       g_actual, g_refl, g_action);
+}
+
+void launch_ideal_normals(int B, int N, const float* helios, const float* sun, const float* target,
+                          float* out, hipStream_t st) {
+    hipLaunchKernelGGL(ideal_normals_kernel, dim3(ray_grid((long)B * N)), dim3(256), 0, st,
+                       B, N, helios, sun, vec3{target[0], target[1], target[2]}, out);
+}
+
+}  // namespace helio

@@ -1,0 +1,38 @@
+// Device-side arithmetic helpers shared by the geometry kernels.
+//
+// The geometry stage must be BIT-IDENTICAL with the reference's fp32 CPU results
+// (an algebraically equal geometry with different rounding
+// already breaks the 1e-5 image tolerance at sigma_scale=0.01).  So every
+// primitive below restates exactly what the ATen CPU kernel does, and the
+// library is compiled with -ffp-contract=off so that nothing else fuses:
+//   norm over 3 elements  = sqrt(fma(z,z,fma(y,y,x*x)))      (correctly rounded)
+//   dot over 3 elements   = (p0+p1)+p2, products rounded separately
+//   x / max(norm,1e-9)    = IEEE division per component
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace helio {
+
+struct vec3 { float x, y, z; };
+
+__device__ __forceinline__ vec3 ld3(const float* __restrict__ p) { return {p[0], p[1], p[2]}; }
+__device__ __forceinline__ void st3(float* __restrict__ p, vec3 v) { p[0] = v.x; p[1] = v.y; p[2] = v.z; }
+
+__device__ __forceinline__ float norm3(vec3 v) {
+    return __fsqrt_rn(__fmaf_rn(v.z, v.z, __fmaf_rn(v.y, v.y, __fmul_rn(v.x, v.x))));
+}
+__device__ __forceinline__ float dot3(vec3 a, vec3 b) {
+    return __fadd_rn(__fadd_rn(__fmul_rn(a.x, b.x), __fmul_rn(a.y, b.y)), __fmul_rn(a.z, b.z));
+}
+__device__ __forceinline__ vec3 sub3(vec3 a, vec3 b) { return {__fsub_rn(a.x, b.x), __fsub_rn(a.y, b.y), __fsub_rn(a.z, b.z)}; }
+__device__ __forceinline__ vec3 add3(vec3 a, vec3 b) { return {__fadd_rn(a.x, b.x), __fadd_rn(a.y, b.y), __fadd_rn(a.z, b.z)}; }
+__device__ __forceinline__ vec3 scale3(float s, vec3 a) { return {__fmul_rn(s, a.x), __fmul_rn(s, a.y), __fmul_rn(s, a.z)}; }
+// x / max(|x|, 1e-9); also hands back the clamped norm
+__device__ __forceinline__ vec3 unit3(vec3 v, float& nclamped) {
+    float n = fmaxf(norm3(v), 1e-9f);
+    nclamped = n;
+    return {__fdiv_rn(v.x, n), __fdiv_rn(v.y, n), __fdiv_rn(v.z, n)};
+}
+__device__ __forceinline__ vec3 unit3(vec3 v) { float n; return unit3(v, n); }
+
+}  // namespace helio

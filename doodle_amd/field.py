@@ -1,0 +1,202 @@
+"""HelioField — the reference's optics surface on top of the HIP kernels.
+
+Mirrors ``HelioField`` of DOODLE's ``newenv_rl_test_multi_error.py`` (:154-415): same
+constructor signature, methods, public attributes, error-selection rule and return
+conventions, so that ``HelioEnv`` and the training scripts run on it unchanged.  All
+arithmetic of ``render`` / ``calculate_ideal_normals`` runs in libhelio.so (hand-written
+HIP for gfx950); this module only shapes arguments, keeps the pre-sampled error tensors
+and wires autograd.  There is no CPU path: on a CPU device (or without the library) the
+compute methods raise ``RuntimeError``.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import native
+
+_TINY = 1e-9
+
+
+def _get_ops():
+    # indirection so the host-logic tests can substitute a checker backend
+    return native.get_ops()
+
+
+class _Render(torch.autograd.Function):
+    """image, actual, refl = render(normals); differentiable w.r.t. ``normals`` only."""
+
+    @staticmethod
+    def forward(ctx, normals, field, sun, trig, trig_stride):
+        ops = _get_ops()
+        actual, refl, rays = ops.geometry_fwd(field.heliostat_positions, sun, normals, trig, trig_stride,
+                                              field._plane)
+        image = ops.splat_fwd(rays, field._xs, field._ys)
+        ctx.field, ctx.trig_stride = field, trig_stride
+        ctx.save_for_backward(normals, sun, trig, rays)
+        return image, actual, refl
+
+    @staticmethod
+    def backward(ctx, g_image, g_actual, g_refl):
+        normals, sun, trig, rays = ctx.saved_tensors
+        field, ops = ctx.field, _get_ops()
+        moments = None
+        if g_image is not None:
+            moments = ops.splat_bwd(rays, field._xs, field._ys, g_image.contiguous())
+        g = ops.geometry_bwd(field.heliostat_positions, sun, normals, trig, ctx.trig_stride, field._plane,
+                             moments,
+                             g_actual.contiguous() if g_actual is not None else None,
+                             g_refl.contiguous() if g_refl is not None else None)
+        return g, None, None, None, None
+
+
+class HelioField:
+    """Heliostat field with per-sun-position pre-sampled orientation errors
+    (reference: newenv_rl_test_multi_error.py:154)."""
+
+    def __init__(
+        self,
+        heliostat_positions,
+        target_position,
+        target_area: tuple,
+        target_normal,
+        error_scale_mrad: float = 1.0,
+        sigma_scale: float = 0.01,
+        initial_action_noise: float = 0.01,
+        resolution: int = 100,
+        device="cpu",
+        max_batch_size: int = 25,
+    ) -> None:
+        self.device = torch.device(device)
+        self.max_batch_size = int(max_batch_size)
+
+        self.heliostat_positions = torch.as_tensor(
+            heliostat_positions, dtype=torch.float32, device=self.device).contiguous()
+        self.num_heliostats = self.heliostat_positions.shape[0]
+        self.target_position = torch.as_tensor(target_position, dtype=torch.float32, device=self.device)
+        self.target_width, self.target_height = target_area
+
+        # The few constructor constants are computed with CPU torch ops — the same
+        # ATen kernels the reference runs on CPU (:189-213) — and uploaded, so that they
+        # carry the reference's bits whatever the device.
+        tn = torch.as_tensor(target_normal, dtype=torch.float32).detach().cpu()
+        tn = tn / tn.norm().clamp_min(_TINY)
+        u = torch.tensor([1.0, 0.0, 0.0])
+        if torch.allclose(tn, torch.tensor([0.0, 1.0, 0.0])):
+            v = torch.tensor([0.0, 0.0, 1.0])
+        else:
+            v = torch.linalg.cross(tn, u)
+            v = v / v.norm().clamp_min(_TINY)
+        self.target_normal = tn.to(self.device)
+        self.plane_u, self.plane_v = u.to(self.device), v.to(self.device)
+
+        self.error_scale_mrad = float(error_scale_mrad)
+        self.initial_action_noise = float(initial_action_noise)
+        self.sigma_scale = float(sigma_scale)
+        self.resolution = int(resolution)
+
+        # native-side constants: receiver frame (w = u × v closes the orthonormal
+        # frame of the separable footprint) and the pixel coordinates of :129-130
+        w = torch.linalg.cross(u.double(), v.double()).float()
+        tp = self.target_position.detach().cpu()
+        self._plane = native.Plane(tuple(tp.tolist()), tuple(tn.tolist()), tuple(u.tolist()),
+                                   tuple(v.tolist()), tuple(w.tolist()), self.sigma_scale)
+        self._target_xyz = tuple(tp.tolist())
+        self._xs = torch.linspace(-self.target_width / 2, self.target_width / 2, self.resolution).to(self.device)
+        self._ys = torch.linspace(-self.target_height / 2, self.target_height / 2, self.resolution).to(self.device)
+
+        self._trig_cache = {}
+        self.reset_errors()
+        self.initial_action = None
+
+    # ------------------------------------------------------------------ errors
+    def reset_errors(self) -> None:
+        """Re-draw both error tensors (:220-239); same RNG call order as the reference."""
+        self.error_angles_mrad = (
+            torch.randn(self.num_heliostats, 2, device=self.device) * self.error_scale_mrad)
+        if self.max_batch_size >= 1:
+            self.batch_error_angles_mrad = self._sample_error_angles(self.max_batch_size)
+        else:
+            self.batch_error_angles_mrad = None
+
+    def _sample_error_angles(self, batch_size: int) -> torch.Tensor:
+        """[batch_size, N, 2] fresh error angles in mrad (:243-252)."""
+        return torch.randn(batch_size, self.num_heliostats, 2, device=self.device) * self.error_scale_mrad
+
+    def _trig_of(self, errs: torch.Tensor) -> torch.Tensor:
+        """(cos_e, sin_e, cos_u, sin_u) of errs·1e-3 (:87-91), computed by torch ON THE
+        DEVICE WHERE ``errs`` LIVES (CPU tensors assigned by a script keep torch's CPU
+        trig, i.e. the reference's bits) and moved to the field's device."""
+        ang = errs.detach().to(torch.float32) * 1e-3
+        e, u = ang[..., 0], ang[..., 1]
+        t = torch.stack([e.cos(), e.sin(), u.cos(), u.sin()], dim=-1)
+        return t.to(self.device).contiguous()
+
+    def _cached_trig(self, slot: str, errs: torch.Tensor) -> torch.Tensor:
+        key = (errs.data_ptr(), errs._version, tuple(errs.shape), errs.device)
+        hit = self._trig_cache.get(slot)
+        if hit is None or hit[0] != key:
+            hit = (key, self._trig_of(errs), errs)     # keep errs alive: its data_ptr is the key
+            self._trig_cache[slot] = hit
+        return hit[1]
+
+    def _select_trig(self, B: int):
+        """Error-selection rule of render() (:340-353) → (trig table, batch stride)."""
+        N = self.num_heliostats
+        if B == 1:
+            return self._cached_trig("single", self.error_angles_mrad), 0
+        batch = self.batch_error_angles_mrad
+        if batch is not None and B <= batch.shape[0]:
+            return self._cached_trig("batch", batch), 4 * N     # rows [:B] are a prefix
+        return self._trig_of(self._sample_error_angles(B)), 4 * N
+
+    # ------------------------------------------------------------------ optics
+    def calculate_ideal_normals(self, sun_position) -> torch.Tensor:
+        """Normals that send every heliostat's reflection to the target centre (:256-278)."""
+        sun = torch.as_tensor(sun_position, dtype=torch.float32, device=self.device)
+        if sun.dim() == 1:
+            return _get_ops().ideal_normals(self.heliostat_positions, sun.view(1, 3).contiguous(),
+                                            self._target_xyz)[0]
+        return _get_ops().ideal_normals(self.heliostat_positions, sun.contiguous(), self._target_xyz)
+
+    def init_actions(self, sun_position) -> None:
+        """Noisy initial mirror orientations (:291-304); always consumes one randn_like."""
+        ideal = self.calculate_ideal_normals(sun_position)
+        noisy = ideal + torch.randn_like(ideal) * self.initial_action_noise
+        if ideal.dim() == 2:
+            noisy = noisy / noisy.norm(dim=1, keepdim=True).clamp_min(_TINY)
+            self.initial_action = noisy.flatten()
+        else:
+            noisy = noisy / noisy.norm(dim=2, keepdim=True).clamp_min(_TINY)
+            self.initial_action = noisy.view(ideal.shape[0], -1)
+
+    def render(self, sun_position, action, ideal_normals=None, show_spillage: bool = False,
+               monitor: bool = False):
+        """Flux image(s) on the receiver (:308-415).
+
+        Returns ``(image, actual)`` or, with ``monitor``, ``(image, actual, refl)``;
+        ``image`` is ``[R,R]`` for a 1-D sun and ``[B,R,R]`` otherwise, ``actual`` is
+        ``[B,N,3]`` (``[1,N,3]`` for a 1-D sun), ``refl`` is ``[B·N,3]``.
+        ``ideal_normals`` and ``show_spillage`` are accepted and unused, as in the reference.
+        """
+        sun = torch.as_tensor(sun_position, dtype=torch.float32, device=self.device)
+        batched = sun.dim() > 1
+        if not batched:
+            sun = sun.unsqueeze(0)
+        sun = sun.contiguous()
+        B, N = sun.shape[0], self.num_heliostats
+
+        act = torch.as_tensor(action, dtype=torch.float32, device=self.device)
+        normals = act.reshape(B, N, 3).contiguous()
+        trig, stride = self._select_trig(B)
+
+        if torch.is_grad_enabled() and normals.requires_grad:
+            images, actual, refl = _Render.apply(normals, self, sun, trig, stride)
+        else:
+            ops = _get_ops()
+            actual, refl, rays = ops.geometry_fwd(self.heliostat_positions, sun, normals, trig, stride,
+                                                  self._plane, want_refl=monitor)
+            images = ops.splat_fwd(rays, self._xs, self._ys)
+        img = images if batched else images[0]
+        if not monitor:
+            return img, actual
+        return img, actual, refl.view(-1, 3)

@@ -1,0 +1,158 @@
+"""ctypes binding of libhelio.so (include/helio.h) for torch tensors.
+
+This is the only place the package touches the C ABI.  It hands the library raw device
+pointers of caller-owned torch tensors plus torch's current HIP stream; it never
+falls back to a CPU implementation: if the library or a HIP device is missing, every
+op raises ``RuntimeError``.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhelio.so")
+
+RAY_STRIDE = 4
+MOMENT_STRIDE = 5
+
+EXPORTS = (
+    "helio_abi_version", "helio_last_error_string", "helio_device_arch", "helio_geometry_fwd",
+    "helio_splat_fwd", "helio_splat_bwd_blocks", "helio_splat_bwd", "helio_geometry_bwd",
+    "helio_ideal_normals",
+)
+
+
+class Plane(ctypes.Structure):
+    """``struct helio_plane`` (host memory)."""
+    _fields_ = [("origin", ctypes.c_float * 3), ("normal", ctypes.c_float * 3),
+                ("u", ctypes.c_float * 3), ("v", ctypes.c_float * 3), ("w", ctypes.c_float * 3),
+                ("sigma_scale", ctypes.c_float)]
+
+
+_vp, _i, _l = ctypes.c_void_p, ctypes.c_int, ctypes.c_long
+_lib = None
+
+
+def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
+    """dlopen libhelio.so and declare the prototypes of include/helio.h."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"{path} is missing: build it with `python -m doodle_amd.build` "
+            "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    lib = ctypes.CDLL(path)
+    pp = ctypes.POINTER(Plane)
+    protos = {
+        "helio_abi_version": (_i, []),
+        "helio_last_error_string": (ctypes.c_char_p, []),
+        "helio_device_arch": (_i, [_i, ctypes.c_char_p, _i]),
+        "helio_geometry_fwd": (_i, [_i, _i, _vp, _vp, _vp, _vp, _l, pp, _vp, _vp, _vp, _vp]),
+        "helio_splat_fwd": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp]),
+        "helio_splat_bwd_blocks": (_i, [_i]),
+        "helio_splat_bwd": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+        "helio_geometry_bwd": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _l, pp, _vp, _vp, _vp, _vp, _vp]),
+        "helio_ideal_normals": (_i, [_i, _i, _vp, _vp, ctypes.c_float * 3, _vp, _vp]),
+    }
+    for name, (res, args) in protos.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype, fn.argtypes = res, args
+    if lib.helio_abi_version() != 1:
+        raise RuntimeError("libhelio.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def _check(lib, rc: int) -> None:
+    if rc != 0:
+        raise RuntimeError(f"libhelio: {lib.helio_last_error_string().decode()} (code {rc})")
+
+
+def _dev(t: torch.Tensor) -> int:
+    if not t.is_cuda:
+        raise RuntimeError("doodle_amd renders only on a HIP device (MI355X); got a CPU tensor — "
+                           "there is no CPU fallback")
+    return t.data_ptr()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+class HipOps:
+    """Tensor-level front end of the C ABI.  All tensors fp32, contiguous, on one HIP device."""
+
+    def __init__(self):
+        self.lib = load_library()
+        if not torch.cuda.is_available():
+            raise RuntimeError("no HIP device visible: doodle_amd has no CPU fallback")
+        buf = ctypes.create_string_buffer(64)
+        _check(self.lib, self.lib.helio_device_arch(torch.cuda.current_device(), buf, 64))
+        self.arch = buf.value.decode()
+        if not self.arch.startswith("gfx950"):
+            raise RuntimeError(f"libhelio.so is built for gfx950 (MI355X); device is {self.arch}")
+        self.splat_variant = int(os.environ.get("HELIO_SPLAT_VARIANT", "0"))
+
+    # -- forward ---------------------------------------------------------------------------
+    def geometry_fwd(self, helios, sun, normals, trig, trig_b_stride, plane, want_refl=True, want_rays=True):
+        B, N = normals.shape[0], normals.shape[1]
+        actual = torch.empty_like(normals)
+        refl = torch.empty_like(normals) if want_refl else None
+        rays = torch.empty((B, N, RAY_STRIDE), dtype=torch.float32, device=normals.device) if want_rays else None
+        _check(self.lib, self.lib.helio_geometry_fwd(
+            B, N, _dev(helios), _dev(sun), _dev(normals), _dev(trig), trig_b_stride, plane,
+            actual.data_ptr(), refl.data_ptr() if want_refl else None,
+            rays.data_ptr() if want_rays else None, _stream()))
+        return actual, refl, rays
+
+    def splat_fwd(self, rays, xs, ys, variant=None):
+        B, N, R = rays.shape[0], rays.shape[1], xs.shape[0]
+        image = torch.empty((B, R, R), dtype=torch.float32, device=rays.device)
+        _check(self.lib, self.lib.helio_splat_fwd(
+            B, N, R, _dev(rays), _dev(xs), _dev(ys), image.data_ptr(),
+            self.splat_variant if variant is None else variant, _stream()))
+        return image
+
+    # -- backward --------------------------------------------------------------------------
+    def splat_bwd(self, rays, xs, ys, grad_image):
+        B, N, R = rays.shape[0], rays.shape[1], xs.shape[0]
+        jb = self.lib.helio_splat_bwd_blocks(R)
+        moments = torch.empty((B, jb, N, MOMENT_STRIDE), dtype=torch.float32, device=rays.device)
+        _check(self.lib, self.lib.helio_splat_bwd(
+            B, N, R, _dev(rays), _dev(xs), _dev(ys), _dev(grad_image), moments.data_ptr(), _stream()))
+        return moments
+
+    def geometry_bwd(self, helios, sun, normals, trig, trig_b_stride, plane, moments, grad_actual, grad_refl):
+        B, N = normals.shape[0], normals.shape[1]
+        grad = torch.empty_like(normals)
+        _check(self.lib, self.lib.helio_geometry_bwd(
+            B, N, moments.shape[1] if moments is not None else 0,
+            _dev(helios), _dev(sun), _dev(normals), _dev(trig), trig_b_stride, plane,
+            _dev(moments) if moments is not None else None,
+            _dev(grad_actual) if grad_actual is not None else None,
+            _dev(grad_refl) if grad_refl is not None else None,
+            grad.data_ptr(), _stream()))
+        return grad
+
+    # -- ideal normals ---------------------------------------------------------------------
+    def ideal_normals(self, helios, sun, target_xyz):
+        B, N = sun.shape[0], helios.shape[0]
+        out = torch.empty((B, N, 3), dtype=torch.float32, device=helios.device)
+        _check(self.lib, self.lib.helio_ideal_normals(
+            B, N, _dev(helios), _dev(sun), (ctypes.c_float * 3)(*target_xyz), out.data_ptr(), _stream()))
+        return out
+
+
+_ops = None
+
+
+def get_ops() -> HipOps:
+    """The process-wide HipOps (raises if the library or the device is missing)."""
+    global _ops
+    if _ops is None:
+        _ops = HipOps()
+    return _ops

@@ -1,0 +1,140 @@
+/*
+ * helio.h — C ABI of libhelio.so: the MI355X (gfx950) implementation of DOODLE's
+ * differentiable heliostat render hot path.
+ *
+ * The reference (github.com/l3th4l/DOODLE) is pure Python/PyTorch and has NO
+ * FFI/plugin interface of its own; its boundary for this path is the Python
+ * class surface HelioField.render / calculate_ideal_normals / init_actions
+ * (newenv_rl_test_multi_error.py:256-415).  The entry points below are what a
+ * binding for that surface calls; doodle_amd/native.py binds them with ctypes
+ * (see INTEGRATION.md for the stub a reference maintainer would add).
+ * "Replaces" comments cite reference file:line in newenv_rl_test_multi_error.py.
+ *
+ * Conventions
+ *   - every pointer named *_d is DEVICE memory owned by the caller (a torch
+ *     tensor); fp32, dense row-major with the stated shape.  The library never
+ *     allocates, frees or keeps a pointer after returning.
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, no
+ *     call synchronises.
+ *   - return value: 0 on success, a negative HELIO_E_* code otherwise;
+ *     helio_last_error_string() describes the last failure on this thread.
+ *   - B = sun positions, N = heliostats, R = receiver resolution (image R x R).
+ */
+#ifndef HELIO_H
+#define HELIO_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HELIO_ABI_VERSION 1
+
+#define HELIO_OK            0
+#define HELIO_E_INVALID    -1   /* bad size / null pointer                       */
+#define HELIO_E_LAUNCH     -2   /* hipGetLastError() after a launch was not ok   */
+#define HELIO_E_NODEVICE   -3   /* no HIP device / wrong architecture            */
+
+/* Receiver plane, HOST memory (passed by value to the kernels).
+ * origin = target_position, normal = unit target normal (ctor :184-192),
+ * u/v = plane_u/plane_v (:206-213), w = u x v (unit; the image plane's normal),
+ * sigma_scale (:197). */
+typedef struct helio_plane {
+    float origin[3];
+    float normal[3];
+    float u[3];
+    float v[3];
+    float w[3];
+    float sigma_scale;
+} helio_plane;
+
+/* Number of floats per ray in the `rays` work buffer written by
+ * helio_geometry_fwd and read by the splat kernels:
+ *   rays[b,n,:] = (a, b, k2, c2)  with
+ *   gauss_bn[i,j] = exp2( -((xs[i]+a)^2 + (ys[j]+b)^2 + c2) * k2 ),
+ *   k2 = log2(e)/max(2 sigma^2,1e-12) for a valid ray and 0 for a plane-parallel
+ *   one (which then contributes exactly 1.0 to every pixel, as :141-148 does). */
+#define HELIO_RAY_STRIDE 4
+/* Floats per ray and per column block in the moment buffer (splat backward). */
+#define HELIO_MOMENT_STRIDE 5
+
+int         helio_abi_version(void);
+const char *helio_last_error_string(void);
+/* gfx arch name of device `device` into buf; HELIO_E_NODEVICE if there is none. */
+int         helio_device_arch(int device, char *buf, int buflen);
+
+/*
+ * Replaces the per-ray part of HelioField.render, :356-389 plus the per-ray
+ * constants of gaussian_blur_batch :126-127,146: orientation-error rotation
+ * (:78-104), leaky-ReLU Z clamp and renormalisation (:369-373), incident
+ * direction (:376-380), reflection (:46-50, :383), ray/plane intersection
+ * (:52-75).  Bit-identical with the reference's CPU fp32 results for `actual`
+ * and `refl`.
+ *
+ *   helios_d [N,3]   sun_d [B,3]   action_d [B,N,3]
+ *   trig_d   [B,N,4] = (cos_e, sin_e, cos_u, sin_u) of (error_mrad * 1e-3);
+ *            trig_b_stride = N*4 normally, 0 to broadcast one [N,4] table
+ *   actual_d [B,N,3] out            refl_d [B,N,3] out, may be NULL
+ *   rays_d   [B,N,HELIO_RAY_STRIDE] out, may be NULL
+ */
+int helio_geometry_fwd(int B, int N,
+                       const float *helios_d, const float *sun_d, const float *action_d,
+                       const float *trig_d, long trig_b_stride,
+                       const helio_plane *plane,
+                       float *actual_d, float *refl_d, float *rays_d,
+                       void *stream);
+
+/*
+ * Replaces gaussian_blur_batch + the sum over heliostats, :107-149, :404-406.
+ *   image_d[b,i,j] = sum_n exp2(-((xs[i]+a)^2 + (ys[j]+b)^2 + c2) * k2)
+ * xs_d/ys_d [R] are the reference's torch.linspace pixel coordinates (:129-130);
+ * image dim0 runs along plane_u, dim1 along plane_v.
+ * variant: 0 = default for this build, 1 = VALU LDS-tiled, 2 = f32 MFMA.
+ */
+int helio_splat_fwd(int B, int N, int R,
+                    const float *rays_d, const float *xs_d, const float *ys_d,
+                    float *image_d, int variant, void *stream);
+
+/* Column blocks the backward splat splits an R-wide image into (the size of the
+ * second dimension of moments_d). */
+int helio_splat_bwd_blocks(int R);
+
+/*
+ * Backward of helio_splat_fwd (autograd of :107-149,:404-406 w.r.t. the ray
+ * parameters): per ray and per column block jb, the five centred moments of
+ * Gg = grad_image[b] * gauss_bn,
+ *   moments_d[b,jb,n,:] = sum_{i, j in block} Gg * (1, t, s, t^2, s^2),
+ *   t = xs[i]+a, s = ys[j]+b.
+ * moments_d has shape [B, helio_splat_bwd_blocks(R), N, HELIO_MOMENT_STRIDE].
+ */
+int helio_splat_bwd(int B, int N, int R,
+                    const float *rays_d, const float *xs_d, const float *ys_d,
+                    const float *grad_image_d, float *moments_d, void *stream);
+
+/*
+ * Backward of helio_geometry_fwd: chains d(image)/d(ray parameters) (from the
+ * moments; moments_d may be NULL when the image has no gradient) and the direct
+ * cotangents of `actual` and `refl` (either may be NULL) back to the mirror
+ * normals.  Same branch semantics as torch autograd of :356-389 (leaky-ReLU
+ * slope, clamp_min and where() masks).
+ *   grad_action_d [B,N,3] out
+ */
+int helio_geometry_bwd(int B, int N, int n_blocks,
+                       const float *helios_d, const float *sun_d, const float *action_d,
+                       const float *trig_d, long trig_b_stride,
+                       const helio_plane *plane,
+                       const float *moments_d,
+                       const float *grad_actual_d, const float *grad_refl_d,
+                       float *grad_action_d, void *stream);
+
+/*
+ * Replaces calculate_ideal_normals, :256-278:
+ *   out[b,n,:] = unit( unit(sun_b - h_n) + unit(target - h_n) ), bit-identical
+ *   with the reference's CPU fp32 result.
+ */
+int helio_ideal_normals(int B, int N, const float *helios_d, const float *sun_d,
+                        const float target_position[3], float *out_d, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HELIO_H */
