@@ -8,6 +8,9 @@
 //   norm over 3 elements  = sqrt(fma(z,z,fma(y,y,x*x)))      (correctly rounded)
 //   dot over 3 elements   = (p0+p1)+p2, products rounded separately
 //   x / max(norm,1e-9)    = IEEE division per component
+// NB: HIP's __fsqrt_rn() is the APPROXIMATE v_sqrt_f32 (see __clang_hip_math.h); the
+// correctly rounded square root is plain sqrtf under hipcc's default
+// -fhip-fp32-correctly-rounded-divide-sqrt, which build.py passes explicitly.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -19,7 +22,7 @@ __device__ __forceinline__ vec3 ld3(const float* __restrict__ p) { return {p[0],
 __device__ __forceinline__ void st3(float* __restrict__ p, vec3 v) { p[0] = v.x; p[1] = v.y; p[2] = v.z; }
 
 __device__ __forceinline__ float norm3(vec3 v) {
-    return __fsqrt_rn(__fmaf_rn(v.z, v.z, __fmaf_rn(v.y, v.y, __fmul_rn(v.x, v.x))));
+    return __builtin_sqrtf(__builtin_fmaf(v.z, v.z, __builtin_fmaf(v.y, v.y, v.x * v.x)));
 }
 __device__ __forceinline__ float dot3(vec3 a, vec3 b) {
     return __fadd_rn(__fadd_rn(__fmul_rn(a.x, b.x), __fmul_rn(a.y, b.y)), __fmul_rn(a.z, b.z));
