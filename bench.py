@@ -1,0 +1,237 @@
+#!/usr/bin/env python3
+"""bench.py — HelioField.render frames/s on MI355X (driver contract, see README).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg4] [--no-cpu]
+
+A "step" is one ``HelioField.render`` forward over one batch of B synthetic sun
+positions (B frames), inputs resident in HBM.  With N>1 (launched by
+``torch.distributed.run``, one rank per GPU) every rank renders its own B-row shard of
+a global batch of N·B suns and the ranks all-gather the images over RCCL (weak scaling);
+there is no other collective on the path.  Rank 0 prints ONE JSON line.
+
+Extra objects in the line:
+  roofline        the dominant kernel (splat forward) at the bench workload, timed live
+                  with HIP events on the launch stream
+  roofline_large  the same kernel at BASELINE config 4 (N=2000, B=512, R=512)
+  cpu_baseline    the oracle (oracle/torch_oracle.py, a CPU PyTorch restatement of the
+                  reference that is bit-identical with it) timed on this host's cores
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from doodle_amd import HelioField  # noqa: E402
+from doodle_amd import native, synthetic  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+F32_MFMA_PEAK_TF = 157.3     # dense f32 MFMA = f32 vector peak (spec)
+
+
+def build_field(w, helios, errs, device, max_batch=None):
+    f = HelioField(helios, synthetic.TARGET_POSITION, synthetic.TARGET_AREA, synthetic.TARGET_NORMAL,
+                   error_scale_mrad=w.error_scale_mrad, sigma_scale=w.sigma_scale,
+                   initial_action_noise=0.01, resolution=w.R, device=device,
+                   max_batch_size=max_batch or errs.shape[0])
+    f.batch_error_angles_mrad = errs.to(device)
+    f.error_angles_mrad = errs[0].to(device)
+    return f
+
+
+def make_action(field, suns, noise):
+    ideal = field.calculate_ideal_normals(suns)
+    a = ideal + noise.to(ideal.device)
+    a = a / a.norm(dim=2, keepdim=True)
+    return a.reshape(a.shape[0], -1).contiguous()
+
+
+def time_kernel(fn, iters, warm=3):
+    """Average duration (s) of ``fn`` — one kernel launch — over ``iters`` back-to-back
+    launches, bracketed by HIP events on the current (launch) stream."""
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / iters
+
+
+def splat_roofline(field, suns, action, iters, variant=None):
+    """Roofline entry for the splat-forward kernel on (field, suns)."""
+    ops = native.get_ops()
+    B, N, R = suns.shape[0], field.num_heliostats, field.resolution
+    trig, stride = field._select_trig(B)
+    normals = action.reshape(B, N, 3).contiguous()
+    _, _, rays = ops.geometry_fwd(field.heliostat_positions, suns, normals, trig, stride, field._plane)
+    image = torch.empty((B, R, R), dtype=torch.float32, device=suns.device)
+    lib, st = ops.lib, torch.cuda.current_stream().cuda_stream
+    var = ops.splat_variant if variant is None else variant
+    args = (B, N, R, rays.data_ptr(), field._xs.data_ptr(), field._ys.data_ptr(), image.data_ptr(), var, st)
+    t = time_kernel(lambda: lib.helio_splat_fwd(*args), iters)
+    flops = 2.0 * B * N * R * R                       # one FMA per (ray, pixel)
+    bytes_alg = 4.0 * B * R * R + 16.0 * B * N + 8.0 * R   # image store + ray parameters + xs/ys
+    return {
+        "bound": "mfma", "kernel": "splat_fwd", "achieved": round(flops / t / 1e12, 3),
+        "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": round(flops / t / 1e12 / F32_MFMA_PEAK_TF, 4),
+        "traffic": None, "kernel_us": round(t * 1e6, 2),
+        "hbm_achieved_GBs": round(bytes_alg / t / 1e9, 1), "hbm_frac": round(bytes_alg / t / 1e9 / HBM_PEAK_GBS, 4),
+        "algorithmic_bytes": bytes_alg, "algorithmic_flops": flops,
+    }
+
+
+def cpu_baseline(w, seed, budget_s=12.0):
+    """The oracle timed on this host: forward render of the bench workload."""
+    from oracle import torch_oracle as to
+    helios, suns, errs, noise = synthetic.make_inputs(w, seed)
+    sc = to.Scene.build(helios, synthetic.TARGET_POSITION, synthetic.TARGET_AREA, synthetic.TARGET_NORMAL,
+                        w.R, w.sigma_scale)
+    ideal = to.ideal_normals(helios, sc.target_position, suns)
+    a = ideal + noise
+    a = (a / a.norm(dim=2, keepdim=True)).reshape(w.B, -1)
+    with torch.no_grad():
+        to.render(sc, suns, a, errs)                     # warm-up
+        n, t0 = 0, time.perf_counter()
+        while True:
+            to.render(sc, suns, a, errs)
+            n += 1
+            el = time.perf_counter() - t0
+            if el > budget_s or n >= 40:
+                break
+    return {"value": round(w.B * n / el, 2), "unit": "frames/s", "cores": torch.get_num_threads(),
+            "kind": "port", "host_cpus": os.cpu_count(),
+            "sample": f"{n} forward renders of {w.name} (all {w.B} suns, whole workload), {el:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--workload", default="cfg2", choices=sorted(synthetic.CONFIGS))
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-large", action="store_true", help="skip the config-4 roofline leg")
+    ap.add_argument("--mode", default="fwd", choices=["fwd", "fwdbwd"])
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    w = synthetic.CONFIGS[args.workload]
+    helios, suns, errs, noise = synthetic.make_inputs(w, args.seed, b_offset=rank * w.B, b_count=w.B)
+    field = build_field(w, helios, errs, dev)
+    suns_d = suns.to(dev)
+    action = make_action(field, suns_d, noise)
+    gathered = torch.empty((world * w.B, w.R, w.R), dtype=torch.float32, device=dev) if world > 1 else None
+    if args.mode == "fwdbwd":
+        action.requires_grad_(True)
+        G = torch.ones((w.B, w.R, w.R), device=dev)
+
+    def step():
+        if args.mode == "fwd":
+            with torch.no_grad():
+                img, _ = field.render(suns_d, action, None)
+        else:
+            img, actual = field.render(suns_d, action, None)
+            torch.autograd.grad((img * G).sum() + actual.sum(), action)
+        if gathered is not None:
+            dist.all_gather_into_tensor(gathered, img.detach())
+
+    for _ in range(args.warmup):
+        step()
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    el = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([el], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+
+    if rank == 0:
+        frames = world * w.B * args.steps
+        out = {
+            "metric": "HelioField.render frames/sec", "value": round(frames / el, 1), "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(el / args.steps * 1e3, 5), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{w.name} {'forward' if args.mode == 'fwd' else 'forward+backward'} "
+                                   f"HelioField.render, sigma_scale={w.sigma_scale}, err={w.error_scale_mrad} mrad, "
+                                   f"{w.B} suns per GPU",
+                       "global_batch": world * w.B, "parallelism": f"sun-batch sharded x{world}"
+                       + (", RCCL all-gather of images" if world > 1 else "")},
+        }
+        iters = 200 if w.B * w.N * w.R * w.R < 1e10 else 10
+        out["roofline"] = splat_roofline(field, suns_d, action.detach(), iters)
+        if world == 1:
+            if not args.no_large and args.workload != "cfg4":
+                try:
+                    out["roofline_large"] = large_leg(dev, args.seed)
+                except Exception as e:  # noqa: BLE001  (report, do not hide)
+                    out["roofline_large"] = {"error": repr(e)}
+            if not args.no_cpu:
+                out["cpu_baseline"] = cpu_baseline(w, args.seed)
+                out["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def large_leg(dev, seed):
+    """Splat-forward roofline and whole-render rate at BASELINE config 4."""
+    w = synthetic.CONFIGS["cfg4"]
+    helios, suns, errs, noise = synthetic.make_inputs(w, seed)
+    field = build_field(w, helios, errs, dev)
+    suns_d = suns.to(dev)
+    action = make_action(field, suns_d, noise)
+    r = splat_roofline(field, suns_d, action, iters=5)
+    with torch.no_grad():
+        for _ in range(2):
+            field.render(suns_d, action, None)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            field.render(suns_d, action, None)
+        torch.cuda.synchronize()
+        el = (time.perf_counter() - t0) / 5
+    r["workload"] = w.name + f", span={w.span} m, sigma_scale={w.sigma_scale}"
+    r["render_frames_per_s"] = round(w.B / el, 1)
+    r["render_ms"] = round(el * 1e3, 3)
+    fwd_bytes = 4.0 * w.B * w.R * w.R + 32.0 * w.B * w.N + 12.0 * w.N + 12.0 * w.B
+    r["render_hbm_GBs"] = round(fwd_bytes / el / 1e9, 1)
+    r["render_hbm_frac"] = round(fwd_bytes / el / 1e9 / HBM_PEAK_GBS, 4)
+    return r
+
+
+if __name__ == "__main__":
+    main()
