@@ -1,0 +1,260 @@
+"""HelioEnv — the reference's Gym-style environment on top of the HIP render path.
+
+Mirrors ``HelioEnv`` of DOODLE's ``test_environment.py`` (:175-525): constructor
+signature, ``reset()`` / ``step()`` / ``set_sun_pos()`` / ``seed()``, the observation and
+metric dictionaries, and the attributes the training scripts read
+(``train_with_env.py:171-216``).  The two ``HelioField`` renders and the ideal-normal
+computation per step run in libhelio.so; the loss block (:427-457) and the boundary
+loss (:101-130) are plain torch ops on the device ("next" rows).
+
+``gymnasium`` is optional: when it is absent the spaces are small records with the
+same fields (the reference only stores them, ``test_environment.py:241-252``).
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from .field import HelioField
+
+try:  # pragma: no cover - depends on the image
+    import gymnasium as _gym
+    from gymnasium import spaces as _spaces
+    _EnvBase = _gym.Env
+    _Box, _DictSpace = _spaces.Box, _spaces.Dict
+except Exception:  # gymnasium is not installed in this image
+    class _EnvBase:  # noqa: D401
+        """Stand-in for gymnasium.Env (no behaviour is inherited by the reference env)."""
+
+    class _Box:
+        def __init__(self, low, high, shape, dtype):
+            self.low, self.high, self.shape, self.dtype = low, high, tuple(shape), dtype
+
+    class _DictSpace(dict):
+        @property
+        def spaces(self):
+            return self
+
+
+BORDER_TOLERANCE = 0.75          # test_environment.py:113
+SUN_RANGE = math.hypot(10000, 10000)   # :324
+
+
+def direction_from_azimuth_elevation(azimuth_deg: float, elevation_deg: float, device=None) -> torch.Tensor:
+    """Unit vector for an azimuth (0° = +X, CCW towards +Y) and elevation (:18-40)."""
+    az, el = math.radians(azimuth_deg), math.radians(elevation_deg)
+    d = torch.tensor([math.cos(el) * math.cos(az), math.cos(el) * math.sin(az), math.sin(el)],
+                     dtype=torch.float32, device=device)
+    return d / torch.norm(d)
+
+
+def sample_cone_directions(n: int, axis: torch.Tensor, half_angle_deg: float, device=None,
+                           force_upper_hemisphere: bool = False) -> torch.Tensor:
+    """``n`` unit vectors uniform on the spherical cap around ``axis`` (:42-88).
+    Draws ``rand(n)`` twice, in the reference's order (cos θ first, then φ)."""
+    device = device or axis.device
+    a = F.normalize(axis.to(device), dim=0)
+    helper = torch.tensor([0.0, 0.0, 1.0], device=device)
+    if torch.abs(a[2]) > 0.999:
+        helper = torch.tensor([0.0, 1.0, 0.0], device=device)
+    e1 = F.normalize(torch.linalg.cross(helper, a), dim=0)
+    e2 = torch.linalg.cross(a, e1)
+    cos_t = 1.0 - torch.rand(n, device=device) * (1.0 - math.cos(math.radians(half_angle_deg)))
+    sin_t = torch.sqrt(torch.clamp(1.0 - cos_t ** 2, min=0.0))
+    phi = 2.0 * math.pi * torch.rand(n, device=device)
+    dirs = (e1[None, :] * (sin_t * torch.cos(phi))[:, None]
+            + e2[None, :] * (sin_t * torch.sin(phi))[:, None]
+            + a[None, :] * cos_t[:, None])
+    dirs = F.normalize(dirs, dim=1)
+    if force_upper_hemisphere:
+        dirs[:, 2] = torch.abs(dirs[:, 2])
+    return dirs
+
+
+def make_distance_maps(imgs: torch.Tensor, thr: float = 0.5) -> torch.Tensor:
+    """Euclidean distance to the region above ``thr``·max of each image (:92-97).
+    Host round trip through scipy, as in the reference; runs only in set_sun_pos."""
+    from scipy.ndimage import distance_transform_edt
+    maps = []
+    for img in imgs.detach().cpu().numpy():
+        hot = (img > thr * img.max()).astype(np.uint8)
+        maps.append(distance_transform_edt(1 - hot))
+    return torch.tensor(np.stack(maps), dtype=torch.float32, device=imgs.device)
+
+
+def boundary(vects, heliostat_pos, targ_pos, targ_norm, targ_area, target_east_axis, target_up_axis,
+             return_all: bool = False):
+    """Anti-spill loss of the reference (:101-130), formula kept as is: the normals are
+    treated as ray directions from the heliostats, intersected with the target plane,
+    and penalised by their distance outside 75 % of the 75 %-shrunk receiver."""
+    dots = -(vects * targ_norm).sum(-1)
+    valid = dots.abs() > 1e-6
+    t = (vects * targ_pos).sum(-1) / (dots + (~valid).float() * 1e-6)
+    local = heliostat_pos.unsqueeze(0) + vects * t.unsqueeze(2) - targ_pos
+    xl = (local * target_east_axis).sum(-1)
+    yl = (local * target_up_axis).sum(-1)
+    hw = targ_area[0] * BORDER_TOLERANCE / 2
+    hh = targ_area[1] * BORDER_TOLERANCE / 2
+    dx = F.relu(xl.abs() - hw * BORDER_TOLERANCE)
+    dy = F.relu(yl.abs() - hh * BORDER_TOLERANCE)
+    dist = torch.sqrt(dx * dx + dy * dy + 1e-8)
+    inside = (xl.abs() <= hw) & (yl.abs() <= hh) & valid
+    out = dist * (~inside).float()
+    return out if return_all else out.mean()
+
+
+def calculate_angles_mrad(v1: torch.Tensor, v2: torch.Tensor, epsilon: float = 1e-10) -> torch.Tensor:
+    """Angle between (unit) vectors in mrad, acos of the clamped dot product (:132-155)."""
+    v1 = v1.unsqueeze(0) if v1.dim() == 1 else v1
+    v2 = v2.unsqueeze(0) if v2.dim() == 1 else v2
+    cosang = torch.sum(v1 * v2, dim=-1)
+    one = torch.tensor(1.0, dtype=cosang.dtype)
+    hi = torch.nextafter(one, torch.tensor(0.0, dtype=cosang.dtype)).item()
+    return torch.acos(torch.clamp(cosang, min=-hi + epsilon, max=hi - epsilon)) * 1000
+
+
+class HelioEnv(_EnvBase):
+    """Batched heliostat-aiming environment (reference: test_environment.py:175)."""
+
+    def __init__(self, heliostat_pos, targ_pos, targ_area, targ_norm, sigma_scale=0.1,
+                 error_scale_mrad=180.0, initial_action_noise=0.0, resolution=128, batch_size=25,
+                 device="cuda", new_sun_pos_every_reset=False, new_errors_every_reset=True,
+                 use_error_mask=False, error_mask_ratio=0.2, exponential_risk=False,
+                 single_sun=False, azimuth=45.0, elevation=45.0):
+        super().__init__()
+        as_t = lambda x: x if isinstance(x, torch.Tensor) else torch.tensor(x, dtype=torch.float32, device=device)  # noqa: E731
+        heliostat_pos, targ_pos, targ_norm = as_t(heliostat_pos), as_t(targ_pos), as_t(targ_norm)
+
+        self.resolution, self.batch_size, self.device = resolution, batch_size, device
+        self.heliostat_pos = heliostat_pos
+        self.num_heliostats = heliostat_pos.shape[0]
+        self.targ_pos, self.targ_area, self.targ_norm = targ_pos, targ_area, targ_norm
+        self.azimuth, self.elevation = azimuth, elevation
+        self.sigma_scale, self.error_scale_mrad = sigma_scale, error_scale_mrad
+        self.initial_action_noise = initial_action_noise
+        self.sun_pos = None
+        self.sun_errors = None
+        self.new_sun_pos_every_reset = new_sun_pos_every_reset
+        self.new_errors_every_reset = new_errors_every_reset
+        self.single_sun = single_sun
+        self.use_error_mask, self.error_mask_ratio = use_error_mask, error_mask_ratio
+        self.exponential_risk = exponential_risk
+
+        n_act = self.num_heliostats * 3
+        self.action_space = _Box(low=-1.0, high=1.0, shape=(n_act,), dtype=np.float32)
+        self.observation_space = _DictSpace({
+            "img": _Box(low=0.0, high=np.inf, shape=(batch_size, resolution, resolution), dtype=np.float32),
+            "aux": _Box(low=-np.inf, high=np.inf, shape=(batch_size, 3 + n_act), dtype=np.float32),
+        })
+
+        # error-free reference field first, then the noisy one (RNG order of :255-277)
+        common = dict(heliostat_positions=heliostat_pos, target_position=targ_pos, target_area=targ_area,
+                      target_normal=targ_norm, sigma_scale=sigma_scale, resolution=resolution,
+                      max_batch_size=batch_size, device=device)
+        self.ref_field = HelioField(error_scale_mrad=0.0, **common)
+        self.noisy_field = HelioField(error_scale_mrad=error_scale_mrad, **common)
+
+        self.set_sun_pos(self._draw_sun_directions() * SUN_RANGE)
+
+    # ------------------------------------------------------------------ suns
+    def _draw_sun_directions(self) -> torch.Tensor:
+        """:286-321 — a 2° cone around (azimuth, elevation), or the whole upper hemisphere."""
+        n = 1 if self.single_sun else self.batch_size
+        if self.azimuth is not None and self.elevation is not None:
+            axis = direction_from_azimuth_elevation(self.azimuth, self.elevation, device=self.device)
+            dirs = sample_cone_directions(n, axis, 2.0, device=self.device, force_upper_hemisphere=True)
+            return dirs.repeat(self.batch_size, 1) if self.single_sun else dirs
+        dirs = F.normalize(torch.randn(n, 3, device=self.device), dim=1)
+        if self.single_sun:
+            dirs = dirs.repeat(self.batch_size, 1)
+        dirs[:, 2] = torch.abs(dirs[:, 2])
+        return dirs
+
+    def set_sun_pos(self, sun_positions: torch.Tensor):
+        """Fix the sun positions and precompute the reference image statistics (:359-370)."""
+        self.sun_pos = sun_positions.clone().detach()
+        self.ref_field.init_actions(self.sun_pos)
+        with torch.no_grad():
+            ideal = self.ref_field.calculate_ideal_normals(self.sun_pos)
+            timg, _ = self.ref_field.render(self.sun_pos, self.ref_field.initial_action, ideal)
+        self.distance_maps = make_distance_maps(timg)
+        self.ref_min = torch.min(timg)
+        self.ref_max = torch.max(timg)
+
+    # ------------------------------------------------------------------ gym API
+    def reset(self):
+        """→ ``{'img': [B,R,R], 'aux': [B, 3+3N]}`` (:372-400)."""
+        if self.new_sun_pos_every_reset:
+            # the reference branch (:378-385) calls an undefined method and cannot run
+            raise NotImplementedError("new_sun_pos_every_reset=True is broken in the reference "
+                                      "(test_environment.py:378-385); call set_sun_pos() instead")
+        if self.new_errors_every_reset:
+            self.noisy_field.reset_errors()
+        with torch.no_grad():
+            self.noisy_field.init_actions(self.sun_pos)
+            ideal = self.ref_field.calculate_ideal_normals(self.sun_pos)
+            img, _ = self.noisy_field.render(self.sun_pos, self.noisy_field.initial_action, ideal)
+        self.ideal_normals = ideal
+        return {"img": img, "aux": torch.cat([self.sun_pos, ideal.flatten(1)], dim=1)}
+
+    def step(self, action):
+        """Render ``action`` on the noisy field and score it (:402-516).
+
+        Returns ``(obs, metrics, monitor)`` with the reference's keys; gradients flow to
+        ``action`` through ``img`` (mse, dist) and ``actual`` (alignment_loss).
+        """
+        if isinstance(action, np.ndarray):
+            action = torch.tensor(action, dtype=torch.float32, device=self.device)
+        ideal = self.ref_field.calculate_ideal_normals(self.sun_pos)
+        img, actual, reflected = self.noisy_field.render(self.sun_pos, action, ideal, monitor=True)
+        aux = torch.cat([self.sun_pos.detach(), action.flatten(1)], dim=1)
+
+        with torch.no_grad():
+            target, _ = self.ref_field.render(self.sun_pos, ideal.flatten(1), ideal)
+        scale = target.amax((1, 2), keepdim=True).clamp_min(1e-6)       # :436
+        pred_n, targ_n = img / scale, target / scale
+        err = (pred_n - targ_n).abs()
+        per_image = err.mean(dim=[-2, -1])
+        angles = calculate_angles_mrad(ideal, actual)
+        alignment_loss = torch.mean(angles)
+        if self.use_error_mask:                                          # :445-452
+            cutoff = torch.quantile(per_image, 1 - self.error_mask_ratio)
+            keep = (per_image > cutoff).float().unsqueeze(-1).unsqueeze(-1)
+            mse = F.mse_loss(pred_n * keep, targ_n * keep)
+            dist_l = (keep * (err * self.distance_maps)).sum((1, 2)).mean()
+        else:                                                            # :455-457
+            mse = F.mse_loss(pred_n, targ_n)
+            dist_l = (err * self.distance_maps).sum((1, 2)).mean()
+
+        normals = action.view(self.batch_size, -1, 3)                    # :460
+        east = torch.tensor([1.0, 0.0, 0.0], device=self.device)
+        up = torch.tensor([0.0, 0.0, 1.0], device=self.device)
+        all_bounds = boundary(normals, self.heliostat_pos, self.targ_pos, self.targ_norm, self.targ_area,
+                              east, up, return_all=True)
+        bound = torch.mean(torch.exp(all_bounds + 1e-6)) if self.exponential_risk else all_bounds.mean()
+
+        finite = torch.isfinite(torch.stack([mse.detach(), dist_l.detach(), bound.detach()]))
+        if not bool(finite.all()):                                       # :495-501, one sync instead of six
+            names = ("MSE", "Distance loss", "Boundary loss")
+            raise AssertionError(f"{names[int((~finite).nonzero()[0])]} is NaN or Inf")
+
+        metrics = {"mse": mse, "dist": dist_l, "bound": bound, "alignment_loss": alignment_loss}
+        obs = {"img": img, "aux": aux}
+        monitor = {
+            "normals": normals,
+            "reflected_rays": reflected.view([-1, 3]),
+            "ideal_normals": ideal.view([-1, 3]),
+            "all_bounds": all_bounds,
+            "mae_image": per_image.view([-1, 1]),
+            "alignment_errors": angles.detach().view([-1]),
+        }
+        return obs, metrics, monitor
+
+    def seed(self, seed=None):
+        """Seed torch and numpy (:518-525)."""
+        if seed is not None:
+            torch.manual_seed(seed)
+            np.random.seed(seed)

@@ -63,7 +63,11 @@ def tilt(normals: torch.Tensor, err_mrad: torch.Tensor) -> torch.Tensor:
     about Up (Z) by column 1, then about East (X) by column 0."""
     east = err_mrad[:, 0] * 1e-3
     up = err_mrad[:, 1] * 1e-3
-    ce, se, cu, su = east.cos(), east.sin(), up.cos(), up.sin()
+    return tilt_trig(normals, east.cos(), east.sin(), up.cos(), up.sin())
+
+
+def tilt_trig(normals, ce, se, cu, su) -> torch.Tensor:
+    """The rotation of :93-104 with the four trig arrays of :90-91 given."""
     x, y, z = normals[:, 0], normals[:, 1], normals[:, 2]
     xr = cu * x - su * y
     yr = su * x + cu * y
@@ -72,11 +76,16 @@ def tilt(normals: torch.Tensor, err_mrad: torch.Tensor) -> torch.Tensor:
     return torch.stack([xr, yt, zt], dim=1)
 
 
-def ray_geometry(scene: Scene, sun: torch.Tensor, normals: torch.Tensor, errs: torch.Tensor):
+def ray_geometry(scene: Scene, sun: torch.Tensor, normals: torch.Tensor, errs: torch.Tensor, trig=None):
     """sun [B,3], normals [B,N,3], errs [B,N,2] → actual [B,N,3], refl [M,3],
-    inter [M,3], mask [M,1], origins [M,3].  Follows :356-389."""
+    inter [M,3], mask [M,1], origins [M,3].  Follows :356-389.  ``trig`` [B,N,4] =
+    (cos_e, sin_e, cos_u, sin_u) may replace ``errs`` (the kernels take the table)."""
     B, N = normals.shape[0], scene.helios.shape[0]
-    tilted = tilt(normals.reshape(-1, 3), errs.reshape(-1, 2))          # :359
+    if trig is not None:
+        t = trig.reshape(-1, 4)
+        tilted = tilt_trig(normals.reshape(-1, 3), t[:, 0], t[:, 1], t[:, 2], t[:, 3])
+    else:
+        tilted = tilt(normals.reshape(-1, 3), errs.reshape(-1, 2))      # :359
     z = torch.nn.functional.leaky_relu(tilted[:, -1])                   # :369
     tilted = tilted.clone()
     tilted[:, -1] = z                                                   # :371

@@ -1,0 +1,243 @@
+"""Host-side logic of the drop-in surface, on CPU, with the oracle-backed ops standing in
+for the HIP library (tests/oracle_backend.py).  Also: the C-ABI library loads and exports
+every symbol include/helio.h declares, and the product refuses to run without a GPU.
+"""
+import inspect
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, golden, render_fixture_names
+import oracle_backend
+
+NAMES = render_fixture_names()
+
+
+def field_from(g, device="cpu"):
+    from doodle_amd import HelioField
+    f = HelioField(g["helios"], g["target_position"], tuple(float(x) for x in g["target_area"]),
+                   g["target_normal"], error_scale_mrad=float(g["error_scale_mrad"]),
+                   sigma_scale=float(g["sigma_scale"]), resolution=int(g["resolution"]), device=device,
+                   max_batch_size=int(g["max_batch_size"]))
+    f.error_angles_mrad = torch.from_numpy(g["error_angles_mrad"])
+    f.batch_error_angles_mrad = torch.from_numpy(g["batch_error_angles_mrad"]) if g["batch_error_angles_mrad"].size else None
+    return f
+
+
+# ------------------------------------------------------------------ C ABI
+def test_library_exports_every_declared_symbol():
+    from doodle_amd import native
+    header = open(os.path.join(ROOT, "include", "helio.h")).read()
+    declared = set(re.findall(r"\b(helio_[a-z_0-9]+)\s*\(", header))
+    assert declared == set(native.EXPORTS), declared ^ set(native.EXPORTS)
+    lib = native.load_library()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.helio_abi_version() == 1
+    assert lib.helio_splat_bwd_blocks(128) == 2 and lib.helio_splat_bwd_blocks(100) == 2
+
+
+def test_abi_rejects_bad_arguments_without_launching():
+    from doodle_amd import native
+    lib = native.load_library()
+    plane = native.Plane()
+    assert lib.helio_geometry_fwd(0, 5, None, None, None, None, 0, plane, None, None, None, None) == -1
+    assert b"bad sizes" in lib.helio_last_error_string()
+    assert lib.helio_splat_fwd(1, 1, 8, None, None, None, None, 0, None) == -1
+    assert b"null pointer" in lib.helio_last_error_string()
+
+
+def test_no_cpu_fallback():
+    from doodle_amd import HelioField
+    f = HelioField(torch.rand(4, 3), [0.0, -5.0, 0.0], (15.0, 15.0), [0.0, 1.0, 0.0], device="cpu")
+    with pytest.raises(RuntimeError, match="no CPU fallback|HIP device"):
+        f.render(torch.rand(3) * 100, torch.rand(12), None)
+    with pytest.raises(RuntimeError, match="no CPU fallback|HIP device"):
+        f.calculate_ideal_normals(torch.rand(3) * 100)
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "doodle_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dirpath, fn)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), fn
+                assert "libhelio_oracle" not in src, fn
+
+
+# ------------------------------------------------------------------ surface
+def test_constructor_and_method_signatures_match_reference():
+    from doodle_amd import HelioField
+    from doodle_amd.env import HelioEnv
+    p = inspect.signature(HelioField.__init__).parameters
+    assert list(p) == ["self", "heliostat_positions", "target_position", "target_area", "target_normal",
+                       "error_scale_mrad", "sigma_scale", "initial_action_noise", "resolution", "device",
+                       "max_batch_size"]
+    assert [p[k].default for k in list(p)[5:]] == [1.0, 0.01, 0.01, 100, "cpu", 25]
+    r = inspect.signature(HelioField.render).parameters
+    assert list(r) == ["self", "sun_position", "action", "ideal_normals", "show_spillage", "monitor"]
+    e = inspect.signature(HelioEnv.__init__).parameters
+    assert list(e) == ["self", "heliostat_pos", "targ_pos", "targ_area", "targ_norm", "sigma_scale",
+                       "error_scale_mrad", "initial_action_noise", "resolution", "batch_size", "device",
+                       "new_sun_pos_every_reset", "new_errors_every_reset", "use_error_mask",
+                       "error_mask_ratio", "exponential_risk", "single_sun", "azimuth", "elevation"]
+    assert [e[k].default for k in list(e)[5:]] == [0.1, 180.0, 0.0, 128, 25, "cuda", False, True, False, 0.2,
+                                                   False, False, 45.0, 45.0]
+    f = HelioField(torch.rand(4, 3), [0.0, -5.0, 0.0], (15.0, 12.0), [0.3, 0.9, -0.2], device="cpu")
+    for attr in ("device", "max_batch_size", "heliostat_positions", "num_heliostats", "target_position",
+                 "target_width", "target_height", "target_normal", "error_scale_mrad", "initial_action_noise",
+                 "sigma_scale", "resolution", "error_angles_mrad", "batch_error_angles_mrad", "plane_u",
+                 "plane_v", "initial_action"):
+        assert hasattr(f, attr), attr
+    assert f.error_angles_mrad.shape == (4, 2) and f.batch_error_angles_mrad.shape == (25, 4, 2)
+    assert abs(float(f.target_normal.norm()) - 1) < 1e-6 and abs(float((f.plane_u * f.plane_v).sum())) < 1e-7
+    assert HelioField(torch.rand(4, 3), [0, -5, 0], (1, 1), [0, 1, 0], max_batch_size=0).batch_error_angles_mrad is None
+
+
+def test_rng_call_order_matches_reference():
+    """Same seed → same error tensors as the reference's constructor (randn(N,2) then
+    randn(max_batch,N,2)), checked against a fixture the reference produced."""
+    from doodle_amd import HelioField
+    g = golden("g1_train_n50_b25_r128")
+    torch.manual_seed(1)                                    # seed used by make_golden.py for this field
+    f = HelioField(g["helios"], g["target_position"], (15.0, 15.0), g["target_normal"], error_scale_mrad=90.0,
+                   sigma_scale=0.01, initial_action_noise=0.01, resolution=128, device="cpu", max_batch_size=25)
+    assert np.array_equal(f.error_angles_mrad.numpy(), g["error_angles_mrad"])
+    assert np.array_equal(f.batch_error_angles_mrad.numpy(), g["batch_error_angles_mrad"])
+    assert np.array_equal(f._xs.numpy(), g["xs"]) and np.array_equal(f._ys.numpy(), g["ys"])
+
+
+# ------------------------------------------------------------------ render through the CPU model
+@pytest.mark.parametrize("name", NAMES)
+def test_decomposition_matches_reference(name, monkeypatch):
+    """geometry → (a,b,k2,c2) → separable sum, and moments → cotangents → geometry adjoint,
+    evaluated on CPU, reproduce the reference's outputs and gradients."""
+    oracle_backend.install(monkeypatch)
+    g = golden(name)
+    f = field_from(g)
+    act = torch.from_numpy(g["action"]).clone().requires_grad_(True)
+    img, actual, refl = f.render(torch.from_numpy(g["sun"]), act, None, monitor=True)
+    assert tuple(img.shape) == g["image"].shape
+    assert np.array_equal(actual.detach().numpy(), g["actual"])
+    assert np.array_equal(refl.detach().numpy(), g["refl"])
+    np.testing.assert_allclose(img.detach().numpy(), g["image"], rtol=1e-5, atol=1e-8)
+    G, H, Q = (torch.from_numpy(g[k]) for k in ("G", "H", "Q"))
+    for loss, key in (((img * G.reshape(img.shape)).sum(), "grad_from_image"),
+                      ((actual * H).sum(), "grad_from_actual"), ((refl * Q).sum(), "grad_from_refl")):
+        (ga,) = torch.autograd.grad(loss, act, retain_graph=True)
+        ref = g[key]
+        assert np.abs(ga.numpy().reshape(ref.shape) - ref).max() <= 2e-4 * max(np.abs(ref).max(), 1e-30), key
+
+
+def test_return_conventions_and_error_selection(monkeypatch):
+    oracle_backend.install(monkeypatch)
+    g = golden("g1_single_1d_n50_r64")
+    f = field_from(g)
+    sun1 = torch.from_numpy(g["sun"])
+    a1 = torch.from_numpy(g["action"])
+    img, actual = f.render(sun1, a1, None)                    # 1-D sun
+    assert img.shape == (64, 64) and actual.shape == (1, 50, 3)
+    out = f.render(sun1, a1, None, monitor=True)
+    assert len(out) == 3 and out[2].shape == (50, 3)
+    img_b1, actual_b1 = f.render(sun1[None], a1[None], None)  # [1,3] sun: batched return, single-sun errors
+    assert img_b1.shape == (1, 64, 64) and torch.equal(img_b1[0], img)
+    # B == 1 uses error_angles_mrad, B >= 2 the prefix of batch_error_angles_mrad
+    suns = torch.stack([sun1, sun1 * torch.tensor([1.0, 0.9, 1.1]), sun1 * torch.tensor([0.8, 1.0, 1.0])])
+    acts = a1.repeat(3, 1)
+    i3, _ = f.render(suns, acts, None)
+    i2, _ = f.render(suns[:2], acts[:2], None)
+    assert torch.equal(i3[:2], i2)                            # prefix rule
+    assert not torch.equal(i3[0], img)                        # batch row 0 ≠ the single-sun tensor
+    f.batch_error_angles_mrad = f.error_angles_mrad[None].repeat(3, 1, 1)
+    i3b, _ = f.render(suns, acts, None)
+    assert torch.equal(i3b[0], img)                           # same errors → same image (cache was invalidated)
+    # duplicated suns get different errors → different images
+    f.reset_errors()
+    dup, _ = f.render(sun1[None].repeat(2, 1), a1[None].repeat(2, 1), None)
+    assert not torch.equal(dup[0], dup[1])
+    again, _ = f.render(sun1[None].repeat(2, 1), a1[None].repeat(2, 1), None)
+    assert torch.equal(dup, again)                            # deterministic until reset_errors()
+    f.reset_errors()
+    after, _ = f.render(sun1[None].repeat(2, 1), a1[None].repeat(2, 1), None)
+    assert not torch.equal(dup, after)
+    # B > max_batch_size: fresh errors every call
+    f2 = field_from(g)
+    f2.max_batch_size = 1
+    f2.reset_errors()
+    x, _ = f2.render(suns, acts, None)
+    y, _ = f2.render(suns, acts, None)
+    assert not torch.equal(x, y)
+    # in-place edits of the error tensor are seen (cache keyed on the tensor version)
+    f3 = field_from(g)
+    p, _ = f3.render(sun1, a1, None)
+    f3.error_angles_mrad.mul_(0.5)
+    q, _ = f3.render(sun1, a1, None)
+    assert not torch.equal(p, q)
+    # accepts lists / ndarrays / other dtypes like the reference's as_tensor calls
+    r, _ = f3.render(sun1.double().numpy(), a1.numpy().tolist(), None)
+    assert torch.equal(r, q)
+
+
+def test_init_actions(monkeypatch):
+    oracle_backend.install(monkeypatch)
+    from doodle_amd import HelioField
+    g = golden("g9_ideal_init")
+    f = HelioField(g["helios"], g["target_position"], (15.0, 15.0), [0.0, 1.0, 0.0], error_scale_mrad=1.0,
+                   initial_action_noise=float(g["initial_action_noise"]), resolution=16, device="cpu")
+    suns = torch.from_numpy(g["suns"])
+    assert np.array_equal(f.calculate_ideal_normals(suns).numpy(), g["ideal_batched"])
+    assert np.array_equal(f.calculate_ideal_normals(suns[3]).numpy(), g["ideal_single"])
+    torch.manual_seed(int(g["init_seed"]))
+    f.init_actions(suns)
+    assert np.array_equal(f.initial_action.numpy(), g["init_batched"])
+    torch.manual_seed(int(g["init_seed"]))
+    f.init_actions(suns[3])
+    assert np.array_equal(f.initial_action.numpy(), g["init_single"])
+
+
+# ------------------------------------------------------------------ HelioEnv
+@pytest.mark.parametrize("tag", ["train", "readme"])
+def test_env_reset_step_match_reference(tag, monkeypatch):
+    oracle_backend.install(monkeypatch)
+    from doodle_amd.env import HelioEnv
+    g = golden(f"g6_env_{tag}_n50_b25_r64")
+    torch.manual_seed(21)
+    env = HelioEnv(heliostat_pos=torch.from_numpy(g["helios"]), targ_pos=torch.tensor([0.0, -5.0, 0.0]),
+                   targ_area=(15.0, 15.0), targ_norm=torch.tensor([0.0, 1.0, 0.0]),
+                   sigma_scale=float(g["sigma_scale"]), error_scale_mrad=float(g["error_scale_mrad"]),
+                   initial_action_noise=0.0, resolution=64, batch_size=25, device="cpu",
+                   new_errors_every_reset=False)
+    # same seed, same RNG call order → same cone suns and the same error tensors
+    assert np.array_equal(env.sun_pos.numpy(), g["cone_suns"])
+    assert np.array_equal(env.noisy_field.batch_error_angles_mrad.numpy(), g["batch_error_angles_mrad"])
+    assert env.observation_space["img"].shape == (25, 64, 64) and env.action_space.shape == (150,)
+    env.set_sun_pos(torch.from_numpy(g["suns"]))
+    np.testing.assert_allclose(env.distance_maps.numpy(), g["distance_maps"], atol=1e-6)
+    np.testing.assert_allclose(float(env.ref_max), float(g["ref_max"]), rtol=1e-5)
+    obs0 = env.reset()
+    assert set(obs0) == {"img", "aux"}
+    np.testing.assert_allclose(obs0["img"].numpy(), g["reset_img"], rtol=1e-5, atol=1e-8)
+    assert np.array_equal(obs0["aux"].numpy(), g["reset_aux"])
+    act = torch.from_numpy(g["action"]).clone().requires_grad_(True)
+    obs, metrics, monitor = env.step(act)
+    assert set(metrics) == {"mse", "dist", "bound", "alignment_loss"}
+    assert set(monitor) == {"normals", "reflected_rays", "ideal_normals", "all_bounds", "mae_image", "alignment_errors"}
+    np.testing.assert_allclose(obs["img"].detach().numpy(), g["step_img"], rtol=1e-5, atol=1e-8)
+    assert np.array_equal(obs["aux"].detach().numpy(), g["step_aux"])
+    for k in metrics:
+        np.testing.assert_allclose(float(metrics[k]), float(g["metric_" + k]), rtol=2e-5, atol=1e-7, err_msg=k)
+        (ga,) = torch.autograd.grad(metrics[k], act, retain_graph=True, allow_unused=True)
+        ref = g["grad_" + k]
+        got = ga.numpy() if ga is not None else np.zeros_like(ref)
+        assert np.abs(got - ref).max() <= 5e-4 * max(np.abs(ref).max(), 1e-30), k
+    for k in monitor:
+        np.testing.assert_allclose(monitor[k].detach().numpy(), g["monitor_" + k], rtol=1e-4, atol=2e-3, err_msg=k)
+    # ndarray actions are accepted (:411-412); the dead reference branch is refused loudly
+    env.step(g["action"])
+    env.new_sun_pos_every_reset = True
+    with pytest.raises(NotImplementedError):
+        env.reset()

@@ -1,0 +1,88 @@
+"""Sun-batch sharding (doodle_amd/sharded.py): CPU, gloo, world_size 2 — plus the
+single-process statement of the same property.  The sharded result must equal the
+unsharded one BIT FOR BIT (images are independent per sun)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import golden
+import oracle_backend
+from test_host_logic import field_from
+
+
+def test_shard_rows_cover_the_batch():
+    from doodle_amd.sharded import shard_rows
+    for B in (1, 2, 7, 25, 26, 4096):
+        for world in (1, 2, 3, 4, 8):
+            rows = [shard_rows(B, world, r) for r in range(world)]
+            assert rows[0][0] == 0 and rows[-1][1] == B
+            assert all(rows[r][1] == rows[r + 1][0] for r in range(world - 1))
+            assert all(b1 - b0 <= chunk for b0, b1, chunk in rows)
+            assert len({chunk for _, _, chunk in rows}) == 1
+
+
+def test_render_rows_equals_full_render(monkeypatch):
+    oracle_backend.install(monkeypatch)
+    g = golden("g8_ragged_n201_b7_r48")
+    f = field_from(g)
+    sun, act = torch.from_numpy(g["sun"]), torch.from_numpy(g["action"])
+    full, actual, refl = f.render(sun, act, None, monitor=True)
+    for b0, b1 in ((0, 3), (3, 4), (4, 7)):
+        img, a, r = f.render_rows(sun[b0:b1], act[b0:b1], b0, 7, monitor=True)
+        assert torch.equal(img, full[b0:b1]) and torch.equal(a, actual[b0:b1])
+        assert torch.equal(r, refl.view(7, -1, 3)[b0:b1].reshape(-1, 3))
+    assert np.array_equal(full.numpy(), g["image"]) or np.allclose(full.numpy(), g["image"], rtol=1e-5, atol=1e-8)
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import doodle_amd.field as field_mod
+        ops = oracle_backend.OracleOps()
+        field_mod._get_ops = lambda: ops
+        from doodle_amd.sharded import ShardedRenderer
+        g = golden("g8_ragged_n201_b7_r48")          # B = 7: ragged over 2 ranks (4 + 3 rows)
+        f = field_from(g)
+        sun = torch.from_numpy(g["sun"])
+        act = torch.from_numpy(g["action"]).clone().requires_grad_(True)
+        sr = ShardedRenderer(f)
+        images, actual, refl = sr.render(sun, act, monitor=True, gather_geometry=True)
+        G = torch.from_numpy(g["G"])
+        (ga,) = torch.autograd.grad((images * G).sum(), act)   # replicated loss; no backward collective
+        b0, b1 = sr.local_rows(7)
+        # second call with the same inputs: sharded renders stay deterministic
+        images2, _ = sr.render(sun, act.detach())
+        torch.save({"images": images.detach(), "actual": actual.detach(), "refl": refl.detach(),
+                    "grad": ga, "rows": (b0, b1), "same": torch.equal(images.detach(), images2)},
+                   os.path.join(out_dir, f"rank{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gloo_two_ranks_bit_identical_to_unsharded(tmp_path, monkeypatch):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    oracle_backend.install(monkeypatch)
+    g = golden("g8_ragged_n201_b7_r48")
+    f = field_from(g)
+    act = torch.from_numpy(g["action"]).clone().requires_grad_(True)
+    full, actual, refl = f.render(torch.from_numpy(g["sun"]), act, None, monitor=True)
+    (gfull,) = torch.autograd.grad((full * torch.from_numpy(g["G"])).sum(), act)
+    outs = [torch.load(os.path.join(tmp_path, f"rank{r}.pt")) for r in range(2)]
+    assert [o["rows"] for o in outs] == [(0, 4), (4, 7)]
+    for o in outs:
+        assert o["same"]
+        assert torch.equal(o["images"], full.detach())             # every rank holds the full batch
+        assert torch.equal(o["actual"], actual.detach()) and torch.equal(o["refl"], refl.detach())
+        b0, b1 = o["rows"]
+        assert torch.equal(o["grad"][b0:b1], gfull[b0:b1])         # own rows: full gradient
+        other = torch.cat([o["grad"][:b0], o["grad"][b1:]])
+        assert float(other.abs().max()) == 0.0                     # foreign rows: none (no collective)
