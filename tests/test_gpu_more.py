@@ -1,0 +1,202 @@
+"""More MI355X parity tests through the C ABI: seeded inputs against the oracle at odd
+sizes, the env against the reference's fixtures, sharding, and size-independent
+properties at BASELINE.json's full sizes.  Run with ``-m gpu``."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+from oracle import torch_oracle as to
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def make_case(N, B, R, sigma=0.02, err=40.0, seed=0, normal=(0.0, 1.0, 0.0), span=10.0):
+    from doodle_amd import HelioField, synthetic
+    w = synthetic.Workload("t", N=N, B=B, R=R, sigma_scale=sigma, error_scale_mrad=err, span=span)
+    helios, suns, errs, noise = synthetic.make_inputs(w, seed)
+    sc = to.Scene.build(helios, synthetic.TARGET_POSITION, synthetic.TARGET_AREA, normal, R, sigma)
+    ideal = to.ideal_normals(helios, sc.target_position, suns)
+    act = ideal + noise
+    act = (act / act.norm(dim=2, keepdim=True)).reshape(B, -1)
+    f = HelioField(helios, synthetic.TARGET_POSITION, synthetic.TARGET_AREA, normal, error_scale_mrad=err,
+                   sigma_scale=sigma, resolution=R, device=DEV, max_batch_size=max(B, 2))
+    f.error_angles_mrad = errs[0]
+    f.batch_error_angles_mrad = errs if B > 1 else errs.repeat(2, 1, 1)
+    return f, sc, suns, errs, act
+
+
+@pytest.mark.parametrize("N,B,R", [(1, 1, 1), (2, 1, 3), (3, 2, 5), (65, 3, 33), (130, 2, 129), (7, 4, 260),
+                                   (257, 2, 64)])
+@pytest.mark.parametrize("normal", [(0.0, 1.0, 0.0), (0.2, 0.95, -0.1)])
+def test_odd_sizes_against_oracle(N, B, R, normal):
+    f, sc, suns, errs, act = make_case(N, B, R, normal=normal, seed=N + B + R)
+    a_cpu = act.clone().requires_grad_(True)
+    img_o, actual_o, refl_o = to.render(sc, suns, a_cpu, errs if B > 1 else errs[:1], monitor=True)
+    g = torch.Generator().manual_seed(1)
+    G, H = torch.randn(img_o.shape, generator=g), torch.randn(actual_o.shape, generator=g)
+    (grad_o,) = torch.autograd.grad((img_o * G).sum() + (actual_o * H).sum(), a_cpu)
+    a_dev = act.to(DEV).requires_grad_(True)
+    for variant in (1, 2):
+        from doodle_amd import native
+        native.get_ops().splat_variant = variant
+        try:
+            img, actual, refl = f.render(suns, a_dev, None, monitor=True)
+        finally:
+            native.get_ops().splat_variant = 0
+        assert np.array_equal(actual.detach().cpu().numpy(), actual_o.detach().numpy())
+        assert np.array_equal(refl.detach().cpu().numpy(), refl_o.detach().numpy())
+        np.testing.assert_allclose(img.detach().cpu().numpy(), img_o.detach().numpy(), rtol=1e-5, atol=1e-8)
+    (grad,) = torch.autograd.grad((img * G.to(DEV)).sum() + (actual * H.to(DEV)).sum(), a_dev)
+    scale = grad_o.abs().max().item()
+    assert (grad.cpu() - grad_o).abs().max().item() <= 2e-4 * scale
+
+
+def test_abi_size_limits_fail_cleanly():
+    from doodle_amd import HelioField
+    f = HelioField(torch.rand(2, 3) * 10 + 80, [0.0, -5.0, 0.0], (15.0, 15.0), [0.0, 1.0, 0.0], device=DEV,
+                   resolution=8, max_batch_size=2)
+    with pytest.raises(RuntimeError, match="bad sizes"):
+        f.render(torch.rand(70000, 3) * 1e4, torch.rand(70000, 6), None)
+    with pytest.raises(RuntimeError):   # CPU tensors never reach the kernels
+        from doodle_amd import native
+        native.get_ops().splat_fwd(torch.zeros(1, 2, 4), f._xs, f._ys)
+
+
+@pytest.mark.parametrize("tag", ["train", "readme"])
+def test_env_matches_reference_fixture(tag):
+    from doodle_amd.env import HelioEnv
+    g = golden(f"g6_env_{tag}_n50_b25_r64")
+    env = HelioEnv(heliostat_pos=torch.from_numpy(g["helios"]).to(DEV), targ_pos=torch.tensor([0.0, -5.0, 0.0], device=DEV),
+                   targ_area=(15.0, 15.0), targ_norm=torch.tensor([0.0, 1.0, 0.0], device=DEV),
+                   sigma_scale=float(g["sigma_scale"]), error_scale_mrad=float(g["error_scale_mrad"]),
+                   initial_action_noise=0.0, resolution=64, batch_size=25, device=DEV, new_errors_every_reset=False)
+    env.noisy_field.error_angles_mrad = torch.from_numpy(g["error_angles_mrad"])
+    env.noisy_field.batch_error_angles_mrad = torch.from_numpy(g["batch_error_angles_mrad"])
+    env.set_sun_pos(torch.from_numpy(g["suns"]).to(DEV))
+    obs0 = env.reset()
+    # set_sun_pos()/reset() render init_actions() output, which carries the HelioField
+    # default 0.01 action noise drawn from the DEVICE RNG (the reference env never forwards
+    # its own initial_action_noise, test_environment.py:255-277): not comparable across
+    # devices.  tests/test_host_logic.py pins them on CPU with the reference's seed; here
+    # the reference's distance maps are injected and step() is compared.
+    assert obs0["img"].shape == (25, 64, 64) and torch.isfinite(obs0["img"]).all()
+    assert np.array_equal(obs0["aux"].cpu().numpy(), g["reset_aux"])
+    assert env.distance_maps.shape == (25, 64, 64) and float(env.ref_max) > 0
+    env.distance_maps = torch.from_numpy(g["distance_maps"]).to(DEV)
+    act = torch.from_numpy(g["action"]).to(DEV).requires_grad_(True)
+    obs, metrics, monitor = env.step(act)
+    np.testing.assert_allclose(obs["img"].detach().cpu().numpy(), g["step_img"], rtol=1e-5, atol=1e-8)
+    for k in metrics:
+        np.testing.assert_allclose(metrics[k].item(), float(g["metric_" + k]), rtol=5e-5, atol=1e-6, err_msg=k)
+        (ga,) = torch.autograd.grad(metrics[k], act, retain_graph=True, allow_unused=True)
+        ref = g["grad_" + k]
+        got = ga.cpu().numpy() if ga is not None else np.zeros_like(ref)
+        # alignment_loss = mean acos(<ideal,actual>): torch's acos near 1 turns a 1-ulp
+        # difference of the (device-side torch) dot product into ~1e-2 mrad, so its
+        # cross-device tolerance is wider; the HIP outputs feeding it are bit-exact
+        tol = 3e-2 if k == "alignment_loss" else 1e-3
+        assert np.abs(got - ref).max() <= tol * max(np.abs(ref).max(), 1e-30), k
+    for k in monitor:
+        atol = 3e-2 if k == "alignment_errors" else 2e-3
+        np.testing.assert_allclose(monitor[k].detach().cpu().numpy(), g["monitor_" + k], rtol=1e-4, atol=atol, err_msg=k)
+
+
+def test_alignment_descent_converges():
+    """The reference's env_sanity_check.py scenario: Adam on raw normals through env.step
+    drives alignment_loss down (geometry backward)."""
+    from doodle_amd.env import HelioEnv
+    torch.manual_seed(666)
+    hp = torch.rand(1, 3, device=DEV) * 10 + 1500
+    hp[:, 2] = 0
+    env = HelioEnv(hp, torch.tensor([0.0, -5.0, 0.0], device=DEV), (15.0, 15.0), torch.tensor([0.0, 1.0, 0.0], device=DEV),
+                   sigma_scale=0.01, error_scale_mrad=2.0, resolution=32, batch_size=64, device=DEV,
+                   new_errors_every_reset=False)
+    env.reset()
+    raw = torch.nn.Parameter(env.ideal_normals.clone() + 0.05 * torch.randn(64, 1, 3, device=DEV))
+    opt = torch.optim.Adam([raw], lr=2e-2)
+    first = None
+    for _ in range(60):
+        opt.zero_grad()
+        _, losses, _ = env.step(torch.nn.functional.normalize(raw, dim=2))
+        losses["alignment_loss"].backward()
+        opt.step()
+        first = first if first is not None else losses["alignment_loss"].item()
+    assert losses["alignment_loss"].item() < 0.2 * first
+
+
+def test_shards_equal_full_render_bit_for_bit():
+    f, _, suns, _, act = make_case(N=300, B=13, R=96, seed=5)
+    a = act.to(DEV)
+    full, actual, refl = f.render(suns, a, None, monitor=True)
+    for b0, b1 in ((0, 5), (5, 6), (6, 13)):
+        img, ac, rf = f.render_rows(suns[b0:b1], a[b0:b1], b0, 13, monitor=True)
+        assert torch.equal(img, full[b0:b1]) and torch.equal(ac, actual[b0:b1])
+        assert torch.equal(rf, refl.view(13, -1, 3)[b0:b1].reshape(-1, 3))
+
+
+# ---------------------------------------------------------------- full-size properties
+def test_config4_properties():
+    """N=2000, B=512 (a 24-sun slice is rendered), R=512.  (1) the image of the whole
+    field equals the sum of the images of two disjoint halves of the heliostats;
+    (2) MFMA and VALU kernels agree; (3) one sun is checked against the oracle (CPU, chunked)."""
+    from doodle_amd import HelioField, native, synthetic
+    w = synthetic.CONFIGS["cfg4"]
+    Bs = 24
+    helios, suns, errs, noise = synthetic.make_inputs(w, 0, b_offset=0, b_count=Bs)
+    sc = to.Scene.build(helios, synthetic.TARGET_POSITION, synthetic.TARGET_AREA, synthetic.TARGET_NORMAL, w.R, w.sigma_scale)
+    ideal = to.ideal_normals(helios, sc.target_position, suns)
+    act = ideal + noise
+    act = act / act.norm(dim=2, keepdim=True)
+
+    def field(hsel):
+        f = HelioField(helios[hsel], synthetic.TARGET_POSITION, synthetic.TARGET_AREA, synthetic.TARGET_NORMAL,
+                       error_scale_mrad=w.error_scale_mrad, sigma_scale=w.sigma_scale, resolution=w.R,
+                       device=DEV, max_batch_size=Bs)
+        f.batch_error_angles_mrad = errs[:, hsel].contiguous()
+        return f
+
+    everything = slice(0, w.N)
+    first, second = slice(0, 1111), slice(1111, w.N)
+    img, actual = field(everything).render(suns, act.reshape(Bs, -1), None)
+    ia, _ = field(first).render(suns, act[:, first].reshape(Bs, -1), None)
+    ib, _ = field(second).render(suns, act[:, second].reshape(Bs, -1), None)
+    peak = img.max().item()
+    assert (img - (ia + ib)).abs().max().item() <= 2e-6 * peak                 # additivity over heliostats
+    native.get_ops().splat_variant = 1
+    try:
+        img_valu, _ = field(everything).render(suns, act.reshape(Bs, -1), None)
+    finally:
+        native.get_ops().splat_variant = 0
+    assert (img - img_valu).abs().max().item() <= 2e-6 * peak                  # two kernels, one answer
+    img_o, actual_o = to.render_chunked(sc, suns[:1], act[:1].reshape(1, -1), errs[:1], b_chunk=1, n_chunk=50)
+    assert np.array_equal(actual[:1].cpu().numpy(), actual_o.numpy())
+    np.testing.assert_allclose(img[:1].cpu().numpy(), img_o.numpy(), rtol=1e-5, atol=1e-8)
+    assert (img[:1].cpu() - img_o).abs().max().item() <= 1e-5 * img_o.max().item()
+
+
+def test_config5_shard_properties():
+    """N=5000, R=256: an 8-sun slice of one rank's shard; sharding invariance and the
+    backward's linearity in the image cotangent."""
+    from doodle_amd import HelioField, synthetic
+    w = synthetic.CONFIGS["cfg5"]
+    Bs = 8
+    helios, suns, errs, noise = synthetic.make_inputs(w, 0, b_offset=1024, b_count=Bs)
+    f = HelioField(helios, synthetic.TARGET_POSITION, synthetic.TARGET_AREA, synthetic.TARGET_NORMAL,
+                   error_scale_mrad=w.error_scale_mrad, sigma_scale=w.sigma_scale, resolution=w.R, device=DEV,
+                   max_batch_size=Bs)
+    f.batch_error_angles_mrad = errs
+    ideal = f.calculate_ideal_normals(suns)
+    act = ideal + noise.to(DEV)
+    act = (act / act.norm(dim=2, keepdim=True)).reshape(Bs, -1).requires_grad_(True)
+    img, actual = f.render(suns, act, None)
+    part, _, _ = f.render_rows(suns[3:6], act.detach()[3:6], 3, Bs)
+    assert torch.equal(part, img.detach()[3:6])
+    g = torch.Generator(device=DEV).manual_seed(0)
+    G1, G2 = (torch.randn(img.shape, device=DEV, generator=g) for _ in range(2))
+    (g1,) = torch.autograd.grad((img * G1).sum(), act, retain_graph=True)
+    (g2,) = torch.autograd.grad((img * G2).sum(), act, retain_graph=True)
+    (g12,) = torch.autograd.grad((img * (G1 + 2 * G2)).sum(), act)
+    assert (g12 - (g1 + 2 * g2)).abs().max().item() <= 1e-4 * g12.abs().max().item()
+    assert torch.isfinite(g12).all()
