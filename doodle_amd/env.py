@@ -51,6 +51,9 @@ def direction_from_azimuth_elevation(azimuth_deg: float, elevation_deg: float, d
     return d / torch.norm(d)
 
 
+azimuth_elevation_to_primary_direction = direction_from_azimuth_elevation   # the reference's name
+
+
 def sample_cone_directions(n: int, axis: torch.Tensor, half_angle_deg: float, device=None,
                            force_upper_hemisphere: bool = False) -> torch.Tensor:
     """``n`` unit vectors uniform on the spherical cap around ``axis`` (:42-88).
