@@ -10,16 +10,22 @@
 // It is a gather (every pixel visits every ray): one workgroup owns an output
 // tile, no atomics, deterministic.
 //
-// Two kernels compute that sum:
+// Three kernels compute that sum:
 //   * splat_fwd_valu — the factors of a chunk of rays are staged in LDS, every
 //     thread keeps an 8×8 (or 4×4) register tile of pixels and does FMAs.
-//   * splat_fwd_mfma — the outer-product sum is issued on the matrix pipe with
+//   * splat_fwd_mfma_regs — the outer-product sum is issued on the matrix pipe with
 //     v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate: an exact fmaf chain, same
 //     numerics as the VALU kernel); every lane computes its own A/E operand in
-//     registers, so the VALU only generates exponentials while the matrix pipe
-//     does the accumulation.  No LDS traffic in the inner loop.
-// Both accumulate in two levels (a chunk of rays, then the running total) so that
-// the rounding error of the sum over N stays at the cascade-sum level of torch.
+//     registers.  Used for small problems (64×64 tiles fill the chip sooner).
+//   * splat_fwd_mfma_tile — the throughput kernel: every factor of the workgroup's
+//     tile is computed ONCE into LDS in MFMA-operand order and the MFMA loop only reads
+//     operands.  Why: measured on MI355X, the f32 MFMA and the VALU do not overlap on
+//     a SIMD (f32 MFMA runs at the f32 VALU rate — same multiply-add lanes), so every
+//     VALU instruction removed per MFMA is time gained.
+// Measured at N=2000, B=512, R=512 (config 4): valu 75, mfma_regs 116, mfma_tile<2> see
+// DESIGN.md, mfma_tile<4> 134 TFLOP/s (f32 peak 157.3).
+// The 4-wave kernels accumulate in two levels (a chunk of rays, then the running total);
+// the 16-wave kernel (128-VGPR budget) in one level: measured 1.5e-6 of peak apart at N=2000.
 #include <hip/hip_runtime.h>
 #include "helio.h"
 
@@ -123,120 +129,270 @@ splat_fwd_valu(int B, int N, int R, const float* __restrict__ rays, const float*
 }
 
 // ----------------------------------------------------------------------------------------------
-// f32 MFMA variant
+// f32 MFMA kernels
 // ----------------------------------------------------------------------------------------------
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) float lds_f;
+typedef __attribute__((address_space(3))) const float lds_cf;
 
-// A workgroup = 4 waves = one 128×128 tile (WT=64: each wave a 64×64 quadrant, 2×2 MFMA
-// blocks) or one 64×64 tile (WT=32: each wave one 32×32 block).  MFMA operand maps
-// (cdna_hip_programming.md §3): lane l supplies A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31];
-// the two k of one instruction are two consecutive heliostats.
-template <int WT, int NC>
+// MFMA operand maps (cdna_hip_programming.md §3): lane l supplies A[i = l&31][k = l>>5] and
+// B[k = l>>5][j = l&31]; the two k of one instruction are two consecutive heliostats.
+// C/D map: column = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+__device__ __forceinline__ void store_block(float* __restrict__ img, int R, int i0, int j0, int lr, int lh,
+                                            const f32x16& v) {
+    const int j = j0 + lr;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int i = i0 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        if (i < R && j < R) img[(long)i * R + j] = v[e];
+    }
+}
+
+// Operands in registers.  Workgroup = WI×WJ = 4 waves, wave tile = 32·MBI × 32·MBJ; two
+// k-pairs (4 heliostats) per loop trip with the ray fetch one trip ahead; the LDS chunk is
+// padded with rays whose A factor is exactly 0, so the loop has no tail logic.
+template <int MBI, int MBJ, int WI, int WJ, int NC, bool TWO_LEVEL>
 __global__ void __launch_bounds__(256)
-splat_fwd_mfma(int B, int N, int R, const float* __restrict__ rays, const float* __restrict__ xs,
-               const float* __restrict__ ys, float* __restrict__ image) {
-    constexpr int MB = WT / 32;          // MFMA blocks per wave along each axis
-    constexpr int TILE = 2 * WT;
-    __shared__ float4 sRay[NC];
+splat_fwd_mfma_regs(int B, int N, int R, const float* __restrict__ rays, const float* __restrict__ xs,
+                    const float* __restrict__ ys, float* __restrict__ image) {
+    static_assert(WI * WJ == 4 && NC % 4 == 0, "4 waves per workgroup");
+    constexpr int TI = 32 * MBI * WI, TJ = 32 * MBJ * WJ;
+    __shared__ float4 sRay[NC + 4];
 
-    const int tiles = (R + TILE - 1) / TILE;
+    const int tiles_j = (R + TJ - 1) / TJ;
     const int b = blockIdx.y;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int lr = lane & 31, lh = lane >> 5;
-    const int i0 = (blockIdx.x / tiles) * TILE + (wave >> 1) * WT;
-    const int j0 = (blockIdx.x % tiles) * TILE + (wave & 1) * WT;
+    const int i0 = (blockIdx.x / tiles_j) * TI + (wave / WJ) * 32 * MBI;
+    const int j0 = (blockIdx.x % tiles_j) * TJ + (wave % WJ) * 32 * MBJ;
 
-    float xv[MB], yv[MB];
+    float xv[MBI], yv[MBJ];
 #pragma unroll
-    for (int m = 0; m < MB; ++m) {
-        xv[m] = xs[min(i0 + 32 * m + lr, R - 1)];
-        yv[m] = ys[min(j0 + 32 * m + lr, R - 1)];
-    }
-    f32x16 tot[MB][MB], acc[MB][MB];
+    for (int m = 0; m < MBI; ++m) xv[m] = xs[min(i0 + 32 * m + lr, R - 1)];
 #pragma unroll
-    for (int mi = 0; mi < MB; ++mi)
-#pragma unroll
-        for (int mj = 0; mj < MB; ++mj)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) tot[mi][mj][e] = 0.0f;
+    for (int m = 0; m < MBJ; ++m) yv[m] = ys[min(j0 + 32 * m + lr, R - 1)];
 
+    f32x16 tot[MBI][MBJ], acc[MBI][MBJ];
+#pragma unroll
+    for (int mi = 0; mi < MBI; ++mi)
+#pragma unroll
+        for (int mj = 0; mj < MBJ; ++mj)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { tot[mi][mj][e] = 0.0f; acc[mi][mj][e] = 0.0f; }
+
+    // a padded ray: k2 = 1, c2 = 1e30  →  A = exp2(-1e30) = 0 exactly, E finite
+    const float4 pad = make_float4(0.f, 0.f, 1.f, 1e30f);
     const float4* __restrict__ rb = reinterpret_cast<const float4*>(rays) + (long)b * N;
     for (int n0 = 0; n0 < N; n0 += NC) {
         __syncthreads();
-        for (int k = tid; k < NC; k += 256)
-            sRay[k] = (n0 + k < N) ? rb[n0 + k] : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = tid; k < NC + 4; k += 256) sRay[k] = (k < NC && n0 + k < N) ? rb[n0 + k] : pad;
         __syncthreads();
-#pragma unroll
-        for (int mi = 0; mi < MB; ++mi)
-#pragma unroll
-            for (int mj = 0; mj < MB; ++mj)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[mi][mj][e] = 0.0f;
         const int cnt = min(NC, N - n0);
-#pragma unroll 2
-        for (int k = 0; k < cnt; k += 2) {
-            const float4 q = sRay[k + lh];
-            const float live = (k + lh < cnt) ? 1.0f : 0.0f;   // odd tail: the missing ray adds 0
-            float fa[MB], fe[MB];
+        float4 q0 = sRay[lh], q1 = sRay[2 + lh];
+        for (int k = 0; k < cnt; k += 4) {
+            const float4 p0 = q0, p1 = q1;
+            q0 = sRay[k + 4 + lh];
+            q1 = sRay[k + 6 + lh];
+            float fa0[MBI], fe0[MBJ], fa1[MBI], fe1[MBJ];
 #pragma unroll
-            for (int m = 0; m < MB; ++m) {
-                const float t = xv[m] + q.x, u = yv[m] + q.y;
-                fa[m] = live * exp2_fast(-(__builtin_fmaf(t, t, q.w) * q.z));
-                fe[m] = exp2_fast(-((u * u) * q.z));
+            for (int m = 0; m < MBI; ++m) {
+                const float t0 = xv[m] + p0.x, t1 = xv[m] + p1.x;
+                fa0[m] = exp2_fast(-(__builtin_fmaf(t0, t0, p0.w) * p0.z));
+                fa1[m] = exp2_fast(-(__builtin_fmaf(t1, t1, p1.w) * p1.z));
             }
 #pragma unroll
-            for (int mi = 0; mi < MB; ++mi)
+            for (int m = 0; m < MBJ; ++m) {
+                const float u0 = yv[m] + p0.y, u1 = yv[m] + p1.y;
+                fe0[m] = exp2_fast(-((u0 * u0) * p0.z));
+                fe1[m] = exp2_fast(-((u1 * u1) * p1.z));
+            }
 #pragma unroll
-                for (int mj = 0; mj < MB; ++mj)
-                    acc[mi][mj] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[mi], fe[mj], acc[mi][mj], 0, 0, 0);
+            for (int mi = 0; mi < MBI; ++mi)
+#pragma unroll
+                for (int mj = 0; mj < MBJ; ++mj)
+                    acc[mi][mj] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[mi], fe0[mj], acc[mi][mj], 0, 0, 0);
+#pragma unroll
+            for (int mi = 0; mi < MBI; ++mi)
+#pragma unroll
+                for (int mj = 0; mj < MBJ; ++mj)
+                    acc[mi][mj] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[mi], fe1[mj], acc[mi][mj], 0, 0, 0);
         }
+        if (TWO_LEVEL) {
 #pragma unroll
-        for (int mi = 0; mi < MB; ++mi)
+            for (int mi = 0; mi < MBI; ++mi)
 #pragma unroll
-            for (int mj = 0; mj < MB; ++mj) tot[mi][mj] += acc[mi][mj];
+                for (int mj = 0; mj < MBJ; ++mj) {
+                    tot[mi][mj] += acc[mi][mj];
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[mi][mj][e] = 0.0f;
+                }
+        }
     }
 
-    // C/D map of the 32×32 MFMA: column = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
     float* __restrict__ img = image + (long)b * R * R;
 #pragma unroll
-    for (int mi = 0; mi < MB; ++mi)
+    for (int mi = 0; mi < MBI; ++mi)
 #pragma unroll
-        for (int mj = 0; mj < MB; ++mj) {
-            const int j = j0 + 32 * mj + lr;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int i = i0 + 32 * mi + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                if (i < R && j < R) img[(long)i * R + j] = tot[mi][mj][e];
-            }
-        }
+        for (int mj = 0; mj < MBJ; ++mj)
+            store_block(img, R, i0 + 32 * mi, j0 + 32 * mj, lr, lh, TWO_LEVEL ? tot[mi][mj] : acc[mi][mj]);
 }
 
+// Operands through LDS.  Workgroup = W×W waves of 64×64 pixels (W = 2: 256 threads, 128×128
+// tile, two-level sums, two workgroups per CU; W = 4: 1024 threads, 256×256 tile, one level,
+// one workgroup per CU).  Per chunk of 64 rays:
+//   producer phase — thread `lane` of every wave owns ray `lane` of the chunk (parameters in
+//     registers, prefetched one chunk ahead) and fills 32-pixel groups of the factor tables,
+//     pixel index wave-uniform (coordinates broadcast from LDS):
+//       factor = exp2(-(q² + cc)),  q = fma(coord, sk, shift·sk),  sk = sqrt(k2)   (2 VALU + 1 exp)
+//     Table rows are padded to an odd length, so the per-ray writes (lanes ↔ rays) and the
+//     per-pixel operand reads (lanes ↔ rows) are both bank-conflict free.
+//   consumer phase — 32 k-pairs × 4 MFMAs per wave, fully unrolled; operands are ds_read_b32
+//     from four base registers + 16-bit immediates (no VALU instruction in the loop).
+template <int W, bool TWO_LEVEL>
+__global__ void __launch_bounds__(64 * W * W)
+splat_fwd_mfma_tile(int B, int N, int R, const float* __restrict__ rays, const float* __restrict__ xs,
+                    const float* __restrict__ ys, float* __restrict__ image) {
+    constexpr int NC = 64, T = 64 * W, LD = T + 1, NW = W * W;
+    constexpr int GROUPS = 2 * T / 32 / NW;          // 32-pixel factor groups per wave (1 or 2)
+    static_assert(GROUPS * NW * 32 == 2 * T, "groups must tile the two tables");
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // sA[NC][LD] sE[NC][LD] xs[T] ys[T]
+    float* __restrict__ sXY = smem + 2 * NC * LD;
+
+    const int tiles_j = (R + T - 1) / T;
+    const int b = blockIdx.y;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int ti0 = (blockIdx.x / tiles_j) * T, tj0 = (blockIdx.x % tiles_j) * T;
+    const int wi = (wave / W) * 64, wj = (wave % W) * 64;
+
+    for (int k = tid; k < 2 * T; k += 64 * NW)
+        sXY[k] = k < T ? xs[min(ti0 + k, R - 1)] : ys[min(tj0 + k - T, R - 1)];
+
+    f32x16 tot[4], acc[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { tot[m][e] = 0.0f; acc[m][e] = 0.0f; }
+
+    const float4 pad = make_float4(0.f, 0.f, 1.f, 1e30f);   // A = exp2(-1e30) = 0 exactly
+    const float4* __restrict__ rb = reinterpret_cast<const float4*>(rays) + (long)b * N;
+    float4 g = (lane < N) ? rb[lane] : pad;
+
+    lds_cf* pa = (lds_cf*)smem + lh * LD + wi + lr;
+    lds_cf* pe = (lds_cf*)smem + NC * LD + lh * LD + wj + lr;
+    lds_cf* pa1 = pa + 32;
+    lds_cf* pe1 = pe + 32;
+    // four independent base registers: a merged ds_read2_b32 has 8-bit offsets and one
+    // shared base cannot reach the second (>64 KB away) table with a 16-bit immediate
+    asm volatile("" : "+v"(pa));
+    asm volatile("" : "+v"(pe));
+    asm volatile("" : "+v"(pa1));
+    asm volatile("" : "+v"(pe1));
+
+    for (int n0 = 0; n0 < N; n0 += NC) {
+        const float4 q = g;
+        const float sk = __builtin_sqrtf(q.z);
+        __syncthreads();                                     // tables free (and sXY visible)
+        if (n0 + NC < N) g = (n0 + NC + lane < N) ? rb[n0 + NC + lane] : pad;   // in flight during the chunk
+#pragma unroll
+        for (int gi = 0; gi < GROUPS; ++gi) {
+            const int grp = wave * GROUPS + gi;              // wave-uniform: [0, T/32) → A, rest → E
+            const bool is_a = grp < T / 32;
+            const int p0 = (is_a ? grp : grp - T / 32) * 32;
+            const float shift = (is_a ? q.x : q.y) * sk;
+            const float cc = is_a ? q.w * q.z : 0.0f;
+            lds_f* wdst = (lds_f*)smem + (is_a ? 0 : NC * LD) + lane * LD + p0;
+            const float* __restrict__ coord = sXY + (is_a ? 0 : T) + p0;
+#pragma unroll
+            for (int j4 = 0; j4 < 32; j4 += 4) {
+                const float4 cv = *reinterpret_cast<const float4*>(&coord[j4]);
+                const float ca[4] = {cv.x, cv.y, cv.z, cv.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float t = __builtin_fmaf(ca[j], sk, shift);
+                    wdst[j4 + j] = exp2_fast(-__builtin_fmaf(t, t, cc));
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kp = 0; kp < NC / 2; ++kp) {
+            const float a0 = pa[kp * 2 * LD], a1 = pa1[kp * 2 * LD];
+            const float e0 = pe[kp * 2 * LD], e1 = pe1[kp * 2 * LD];
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, e0, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, e1, acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, e0, acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, e1, acc[3], 0, 0, 0);
+        }
+        if (TWO_LEVEL) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                tot[m] += acc[m];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[m][e] = 0.0f;
+            }
+        }
+    }
+
+    float* __restrict__ img = image + (long)b * R * R;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+        store_block(img, R, ti0 + wi + 32 * (m >> 1), tj0 + wj + 32 * (m & 1), lr, lh, TWO_LEVEL ? tot[m] : acc[m]);
+}
+
+template <int MBI, int MBJ, int WI, int WJ, int NC, bool TWO_LEVEL>
+static void launch_regs(int B, int N, int R, const float* rays, const float* xs, const float* ys,
+                        float* image, hipStream_t st) {
+    constexpr int TI = 32 * MBI * WI, TJ = 32 * MBJ * WJ;
+    const int ti = (R + TI - 1) / TI, tj = (R + TJ - 1) / TJ;
+    hipLaunchKernelGGL((splat_fwd_mfma_regs<MBI, MBJ, WI, WJ, NC, TWO_LEVEL>), dim3(ti * tj, B), dim3(256), 0, st,
+                       B, N, R, rays, xs, ys, image);
+}
+
+template <int W, bool TWO_LEVEL>
+static void launch_tile(int B, int N, int R, const float* rays, const float* xs, const float* ys,
+                        float* image, hipStream_t st) {
+    constexpr int T = 64 * W;
+    const int t = (R + T - 1) / T;
+    const size_t lds = (2 * 64 * (T + 1) + 2 * T) * sizeof(float);
+    static bool configured = false;   // raising the dynamic-LDS cap is idempotent; a race is harmless
+    if (!configured) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(splat_fwd_mfma_tile<W, TWO_LEVEL>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        configured = true;
+    }
+    hipLaunchKernelGGL((splat_fwd_mfma_tile<W, TWO_LEVEL>), dim3(t * t, B), dim3(64 * W * W), lds, st,
+                       B, N, R, rays, xs, ys, image);
+}
+
+// variant: 0/2 = MFMA, kernel chosen by problem size; 1 = VALU; 3/4/5/6 force one MFMA kernel
+// (regs 128², tile 128², tile 256², regs 64²) — used by the tests and tools/bench_splat.py.
 int launch_splat_fwd(int B, int N, int R, const float* rays, const float* xs, const float* ys,
                      float* image, int variant, hipStream_t st) {
-    if (variant == 0) variant = 2;
-    // Small problems (few, small images) want more, smaller workgroups to fill 256 CUs.
-    const long big_tiles = (long)B * ((R + 127) / 128) * ((R + 127) / 128);
-    const bool small = big_tiles < 512;
-    if (variant == 1) {
-        if (small) {
+    const long t128 = (long)B * ((R + 127) / 128) * ((R + 127) / 128);
+    const long t256 = (long)B * ((R + 255) / 256) * ((R + 255) / 256);
+    if (variant == 0 || variant == 2) {
+        if (N >= 48 && R > 128 && t256 >= 192) variant = 5;
+        else if (N >= 48 && t128 >= 384) variant = 4;
+        else if (t128 >= 512) variant = 3;
+        else variant = 6;
+    }
+    switch (variant) {
+    case 1:
+        if (t128 < 512) {
             const int t = (R + 63) / 64;
             hipLaunchKernelGGL((splat_fwd_valu<64, 32>), dim3(t * t, B), dim3(256), 0, st, B, N, R, rays, xs, ys, image);
         } else {
             const int t = (R + 127) / 128;
             hipLaunchKernelGGL((splat_fwd_valu<128, 32>), dim3(t * t, B), dim3(256), 0, st, B, N, R, rays, xs, ys, image);
         }
-    } else if (variant == 2) {
-        if (small) {
-            const int t = (R + 63) / 64;
-            hipLaunchKernelGGL((splat_fwd_mfma<32, 128>), dim3(t * t, B), dim3(256), 0, st, B, N, R, rays, xs, ys, image);
-        } else {
-            const int t = (R + 127) / 128;
-            hipLaunchKernelGGL((splat_fwd_mfma<64, 128>), dim3(t * t, B), dim3(256), 0, st, B, N, R, rays, xs, ys, image);
-        }
-    } else {
-        return HELIO_E_INVALID;
+        return HELIO_OK;
+    case 3: launch_regs<2, 2, 2, 2, 128, true>(B, N, R, rays, xs, ys, image, st); return HELIO_OK;
+    case 4: launch_tile<2, true>(B, N, R, rays, xs, ys, image, st); return HELIO_OK;
+    case 5: launch_tile<4, false>(B, N, R, rays, xs, ys, image, st); return HELIO_OK;
+    case 6: launch_regs<1, 1, 2, 2, 128, true>(B, N, R, rays, xs, ys, image, st); return HELIO_OK;
+    default: return HELIO_E_INVALID;
     }
-    return HELIO_OK;
 }
 
 }  // namespace helio

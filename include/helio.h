@@ -88,7 +88,8 @@ int helio_geometry_fwd(int B, int N,
  *   image_d[b,i,j] = sum_n exp2(-((xs[i]+a)^2 + (ys[j]+b)^2 + c2) * k2)
  * xs_d/ys_d [R] are the reference's torch.linspace pixel coordinates (:129-130);
  * image dim0 runs along plane_u, dim1 along plane_v.
- * variant: 0 = default for this build, 1 = VALU LDS-tiled, 2 = f32 MFMA.
+ * variant: 0 or 2 = f32 MFMA (kernel chosen by problem size), 1 = VALU LDS-tiled;
+ * 3..6 force one MFMA kernel (regs 128x128, LDS-tile 128x128, LDS-tile 256x256, regs 64x64).
  */
 int helio_splat_fwd(int B, int N, int R,
                     const float *rays_d, const float *xs_d, const float *ys_d,
