@@ -69,21 +69,33 @@ def time_kernel(fn, iters, warm=3):
 
 
 def splat_roofline(field, suns, action, iters, variant=None):
-    """Roofline entry for the splat-forward kernel on (field, suns)."""
+    """Roofline entry for the dominant kernel of one render on (field, suns): the fused
+    render kernel when the problem takes the single-launch path, else the splat-forward
+    kernel.  One launch per timed iteration, HIP events on the launch stream."""
     ops = native.get_ops()
     B, N, R = suns.shape[0], field.num_heliostats, field.resolution
     trig, stride = field._select_trig(B)
     normals = action.reshape(B, N, 3).contiguous()
-    _, _, rays = ops.geometry_fwd(field.heliostat_positions, suns, normals, trig, stride, field._plane)
+    actual, _, rays = ops.geometry_fwd(field.heliostat_positions, suns, normals, trig, stride, field._plane)
     image = torch.empty((B, R, R), dtype=torch.float32, device=suns.device)
-    lib, st = ops.lib, torch.cuda.current_stream().cuda_stream
+    lib, st = ops.lib, native._stream()
     var = ops.splat_variant if variant is None else variant
-    args = (B, N, R, rays.data_ptr(), field._xs.data_ptr(), field._ys.data_ptr(), image.data_ptr(), var, st)
-    t = time_kernel(lambda: lib.helio_splat_fwd(*args), iters)
+    fused = var in (0, 2) and lib.helio_render_fwd_launches(B, N, R) == 1
+    if fused:
+        kernel = "render_fwd_fused_small"
+        args = (B, N, R, field.heliostat_positions.data_ptr(), suns.data_ptr(), normals.data_ptr(), trig.data_ptr(),
+                stride, field._plane, field._xs.data_ptr(), field._ys.data_ptr(), actual.data_ptr(), None,
+                rays.data_ptr(), image.data_ptr(), var, st)
+        t = time_kernel(lambda: lib.helio_render_fwd(*args), iters)
+        bytes_alg = 4.0 * B * R * R + 32.0 * B * N + 16.0 * B * N + 12.0 * N + 12.0 * B + 8.0 * R
+    else:
+        kernel = "splat_fwd"
+        args = (B, N, R, rays.data_ptr(), field._xs.data_ptr(), field._ys.data_ptr(), image.data_ptr(), var, st)
+        t = time_kernel(lambda: lib.helio_splat_fwd(*args), iters)
+        bytes_alg = 4.0 * B * R * R + 16.0 * B * N + 8.0 * R   # image store + ray parameters + xs/ys
     flops = 2.0 * B * N * R * R                       # one FMA per (ray, pixel)
-    bytes_alg = 4.0 * B * R * R + 16.0 * B * N + 8.0 * R   # image store + ray parameters + xs/ys
     return {
-        "bound": "mfma", "kernel": "splat_fwd", "achieved": round(flops / t / 1e12, 3),
+        "bound": "mfma", "kernel": kernel, "achieved": round(flops / t / 1e12, 3),
         "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": round(flops / t / 1e12 / F32_MFMA_PEAK_TF, 4),
         "traffic": None, "kernel_us": round(t * 1e6, 2),
         "hbm_achieved_GBs": round(bytes_alg / t / 1e9, 1), "hbm_frac": round(bytes_alg / t / 1e9 / HBM_PEAK_GBS, 4),
@@ -124,6 +136,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-large", action="store_true", help="skip the config-4 roofline leg")
     ap.add_argument("--mode", default="fwd", choices=["fwd", "fwdbwd"])
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed and all-gather even with one rank (testing)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -134,9 +148,11 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29517"), ("RANK", "0"), ("WORLD_SIZE", "1")):
+            os.environ.setdefault(k, v)          # only matters for a bare --force-dist run
         dist.init_process_group("nccl", device_id=dev)
 
     w = synthetic.CONFIGS[args.workload]
@@ -144,7 +160,7 @@ def main():
     field = build_field(w, helios, errs, dev)
     suns_d = suns.to(dev)
     action = make_action(field, suns_d, noise)
-    gathered = torch.empty((world * w.B, w.R, w.R), dtype=torch.float32, device=dev) if world > 1 else None
+    gathered = torch.empty((world * w.B, w.R, w.R), dtype=torch.float32, device=dev) if dist is not None else None
     if args.mode == "fwdbwd":
         action.requires_grad_(True)
         G = torch.ones((w.B, w.R, w.R), device=dev)
@@ -189,7 +205,7 @@ def main():
                                    f"HelioField.render, sigma_scale={w.sigma_scale}, err={w.error_scale_mrad} mrad, "
                                    f"{w.B} suns per GPU",
                        "global_batch": world * w.B, "parallelism": f"sun-batch sharded x{world}"
-                       + (", RCCL all-gather of images" if world > 1 else "")},
+                       + (", RCCL all-gather of images" if dist is not None else "")},
         }
         iters = 200 if w.B * w.N * w.R * w.R < 1e10 else 10
         out["roofline"] = splat_roofline(field, suns_d, action.detach(), iters)

@@ -15,7 +15,8 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libhelio.so")
 SOURCES = ["abi.hip", "geometry.hip", "splat_fwd.hip", "splat_bwd.hip"]
-HEADERS = [os.path.join(CSRC, "helio_math.h"), os.path.join(ROOT, "include", "helio.h")]
+HEADERS = [os.path.join(CSRC, "helio_math.h"), os.path.join(CSRC, "ray_trace.h"),
+           os.path.join(ROOT, "include", "helio.h")]
 # -ffp-contract=off: the geometry stage is bit-faithful to the reference's fp32 CPU
 # arithmetic; FMAs appear only where written (helio_math.h).  Division and sqrt stay
 # correctly rounded (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt).

@@ -16,8 +16,11 @@ void launch_geometry_bwd(int, int, int, const float*, const float*, const float*
                          const helio_plane*, const float*, const float*, const float*, float*, hipStream_t);
 void launch_ideal_normals(int, int, const float*, const float*, const float*, float*, hipStream_t);
 int launch_splat_fwd(int, int, int, const float*, const float*, const float*, float*, int, hipStream_t);
-void launch_splat_bwd(int, int, int, const float*, const float*, const float*, const float*, float*, hipStream_t);
+int launch_splat_bwd(int, int, int, const float*, const float*, const float*, const float*, float*, int, hipStream_t);
 int splat_bwd_blocks(int);
+bool render_is_fused(int, int, int);
+void launch_render_fused(int, int, int, const float*, const float*, const float*, const float*, long,
+                         const helio_plane*, const float*, const float*, float*, float*, float*, float*, hipStream_t);
 }  // namespace helio
 
 namespace {
@@ -81,14 +84,44 @@ int helio_splat_fwd(int B, int N, int R, const float* rays_d, const float* xs_d,
     return after_launch("splat_fwd");
 }
 
+int helio_render_fwd(int B, int N, int R, const float* helios_d, const float* sun_d, const float* action_d,
+                     const float* trig_d, long trig_b_stride, const helio_plane* plane, const float* xs_d,
+                     const float* ys_d, float* actual_d, float* refl_d, float* rays_d, float* image_d,
+                     int variant, void* stream) {
+    if (!sizes_ok(B, N) || R < 1 || R > 16384) return fail(HELIO_E_INVALID, "render_fwd: bad sizes B=%d N=%d R=%d", B, N, R);
+    if (!helios_d || !sun_d || !action_d || !trig_d || !plane || !xs_d || !ys_d || !actual_d || !image_d)
+        return fail(HELIO_E_INVALID, "render_fwd: null pointer");
+    if (trig_b_stride != 0 && trig_b_stride != 4l * N)
+        return fail(HELIO_E_INVALID, "render_fwd: trig_b_stride must be 0 or 4*N");
+    if (!aligned16(trig_d) || (rays_d && !aligned16(rays_d)) || !aligned16(image_d))
+        return fail(HELIO_E_INVALID, "render_fwd: trig/rays/image must be 16-byte aligned");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if ((variant == 0 || variant == 2) && helio::render_is_fused(B, N, R)) {
+        helio::launch_render_fused(B, N, R, helios_d, sun_d, action_d, trig_d, trig_b_stride, plane, xs_d, ys_d,
+                                   actual_d, refl_d, rays_d, image_d, st);
+        return after_launch("render_fwd(fused)");
+    }
+    if (!rays_d) return fail(HELIO_E_INVALID, "render_fwd: this problem size needs the rays work buffer");
+    helio::launch_geometry_fwd(B, N, helios_d, sun_d, action_d, trig_d, trig_b_stride, plane, actual_d, refl_d, rays_d, st);
+    if (helio::launch_splat_fwd(B, N, R, rays_d, xs_d, ys_d, image_d, variant, st) != HELIO_OK)
+        return fail(HELIO_E_INVALID, "render_fwd: unknown variant %d", variant);
+    return after_launch("render_fwd");
+}
+
+int helio_render_fwd_launches(int B, int N, int R) {
+    return (sizes_ok(B, N) && R >= 1 && helio::render_is_fused(B, N, R)) ? 1 : 2;
+}
+
 int helio_splat_bwd_blocks(int R) { return R >= 1 ? helio::splat_bwd_blocks(R) : 0; }
 
 int helio_splat_bwd(int B, int N, int R, const float* rays_d, const float* xs_d, const float* ys_d,
-                    const float* grad_image_d, float* moments_d, void* stream) {
+                    const float* grad_image_d, float* moments_d, int variant, void* stream) {
     if (!sizes_ok(B, N) || R < 1 || R > 16384) return fail(HELIO_E_INVALID, "splat_bwd: bad sizes B=%d N=%d R=%d", B, N, R);
     if (!rays_d || !xs_d || !ys_d || !grad_image_d || !moments_d) return fail(HELIO_E_INVALID, "splat_bwd: null pointer");
     if (!aligned16(rays_d) || !aligned16(grad_image_d)) return fail(HELIO_E_INVALID, "splat_bwd: rays/grad_image must be 16-byte aligned");
-    helio::launch_splat_bwd(B, N, R, rays_d, xs_d, ys_d, grad_image_d, moments_d, static_cast<hipStream_t>(stream));
+    if (helio::launch_splat_bwd(B, N, R, rays_d, xs_d, ys_d, grad_image_d, moments_d, variant,
+                                static_cast<hipStream_t>(stream)) != HELIO_OK)
+        return fail(HELIO_E_INVALID, "splat_bwd: unknown variant %d", variant);
     return after_launch("splat_bwd");
 }
 

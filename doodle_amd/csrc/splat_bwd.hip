@@ -131,12 +131,195 @@ splat_bwd_valu(int B, int N, int R, const float* __restrict__ rays, const float*
     }
 }
 
+// ----------------------------------------------------------------------------------------------
+// f32 MFMA backward (large problems)
+// ----------------------------------------------------------------------------------------------
+// The five moments need only TWO contractions of grad_image with a factor table:
+//   pass 0:  U[j,n] = Σ_i G[i,j]·A_n[i]   →  (M0, Ms, Mss) = Σ_j E_n[j]·(1, s_j, s_j²)·U[j,n]
+//   pass 1:  V[i,n] = Σ_j G[i,j]·E_n[j]   →  (Mt, Mtt)     = Σ_i A_n[i]·(t_i, t_i²)·V[i,n]
+// i.e. 2 FMAs per (ray, pixel) instead of the VALU kernel's 3.  Each pass is the forward
+// tile kernel with other operands: D[c][n] += Gm[c][k]·F_n[k] on v_mfma_f32_32x32x2_f32,
+// c = the image axis that survives (columns in pass 0, rows in pass 1), k = the contracted
+// axis, F = the contracted-axis factor.  The surviving axis is put on the MFMA's M
+// dimension so that in the C/D register map a lane holds ONE ray (column = lane&31) and 16
+// values of c in registers: the epilogue (weight by the other factor, sum over c) is
+// in-register apart from one lane^32 exchange.
+// Workgroup = 16 waves = 256 c × 256 rays (4×4 waves of 64×64); per 64-deep k-chunk the
+// grad-image slab Gm[k][c] and the factor table F[k][ray] are staged in LDS in MFMA operand
+// order (lanes ↔ consecutive c / consecutive rays: conflict-free reads and writes).
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) float lds_f;
+typedef __attribute__((address_space(3))) const float lds_cf;
+
+template <int PASS>
+__global__ void __launch_bounds__(1024)
+splat_bwd_mfma(int B, int N, int R, const float* __restrict__ rays, const float* __restrict__ xs,
+               const float* __restrict__ ys, const float* __restrict__ gimg, float* __restrict__ moments) {
+    constexpr int KC = 64, T = 256, LD = T + 1;
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // sG[KC][LD] sF[KC][LD] ccoord[T] kcoord[KC]
+    float* __restrict__ sCc = smem + 2 * KC * LD;
+    float* __restrict__ sKc = sCc + T;
+
+    const int c_tiles = (R + T - 1) / T;
+    const int b = blockIdx.y;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int c0 = (blockIdx.x % c_tiles) * T, n0 = (blockIdx.x / c_tiles) * T;
+    const int wc = (wave >> 2) * 64, wn = (wave & 3) * 64;
+    const float* __restrict__ ccoord = PASS == 0 ? ys : xs;   // coordinates along c
+    const float* __restrict__ kcoord = PASS == 0 ? xs : ys;   // coordinates along k
+    const float* __restrict__ G = gimg + (long)b * R * R;
+
+    if (tid < T) sCc[tid] = ccoord[min(c0 + tid, R - 1)];
+
+    // producer role for the factor table: ray (wave&3)*64 + lane of the tile, 16 k of every chunk
+    const int pr = (wave & 3) * 64 + lane;
+    const int pk0 = (wave >> 2) * 16;
+    float4 q = make_float4(0.f, 0.f, 1.f, 1e30f);
+    if (n0 + pr < N) q = reinterpret_cast<const float4*>(rays)[(long)b * N + n0 + pr];
+    const float sk = __builtin_sqrtf(q.z);
+    const float fshift = (PASS == 0 ? q.x : q.y) * sk;
+    const float fcc = PASS == 0 ? q.w * q.z : 0.0f;
+    lds_f* fdst = (lds_f*)smem + KC * LD + pk0 * LD + pr;
+
+    // loader role for the grad-image slab Gm[k][c]: 16 dwords per thread and chunk, element
+    // idx = tid + 1024·v.  Lanes run along the axis that is contiguous in G (coalesced 256-B
+    // wave loads) and the LDS image is written without bank conflicts:
+    //   pass 0: Gm[k][c] = G[k0+k][c0+c]:  k = idx>>8, c = idx&255  (lanes ↔ c, stride 1 in LDS)
+    //   pass 1: Gm[k][c] = G[c0+c][k0+k]:  k = idx&63, c = idx>>6   (lanes ↔ k, stride LD = 257)
+    float gv[16];
+    auto load_slab = [&](int k0) {
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int idx = tid + 1024 * v;
+            const int k = PASS == 0 ? idx >> 8 : idx & 63, c = PASS == 0 ? idx & 255 : idx >> 6;
+            const int row = PASS == 0 ? k0 + k : c0 + c, col = PASS == 0 ? c0 + c : k0 + k;
+            gv[v] = (row < R && col < R) ? G[(long)row * R + col] : 0.0f;
+        }
+    };
+    auto store_slab = [&]() {
+        lds_f* dst = (lds_f*)smem;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int idx = tid + 1024 * v;
+            const int k = PASS == 0 ? idx >> 8 : idx & 63, c = PASS == 0 ? idx & 255 : idx >> 6;
+            dst[k * LD + c] = gv[v];
+        }
+    };
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[m][e] = 0.0f;
+
+    // consumer: A operand = Gm[k = 2kp + lh][c = wc + 32·blk + lr], B operand = F[k][ray = wn + 32·blk + lr]
+    lds_cf* pg = (lds_cf*)smem + lh * LD + wc + lr;
+    lds_cf* pf = (lds_cf*)smem + KC * LD + lh * LD + wn + lr;
+    lds_cf* pg1 = pg + 32;
+    lds_cf* pf1 = pf + 32;
+    asm volatile("" : "+v"(pg));
+    asm volatile("" : "+v"(pf));
+    asm volatile("" : "+v"(pg1));
+    asm volatile("" : "+v"(pf1));
+
+    load_slab(0);
+    for (int k0 = 0; k0 < R; k0 += KC) {
+        __syncthreads();                                   // previous chunk consumed
+        store_slab();
+        if (tid < KC) sKc[tid] = kcoord[min(k0 + tid, R - 1)];
+        __syncthreads();                                   // coordinates of this chunk visible
+        if (k0 + KC < R) load_slab(k0 + KC);               // in flight during the chunk
+#pragma unroll
+        for (int j4 = 0; j4 < 16; j4 += 4) {
+            const float4 cv = *reinterpret_cast<const float4*>(&sKc[pk0 + j4]);
+            const float ca[4] = {cv.x, cv.y, cv.z, cv.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float t = __builtin_fmaf(ca[j], sk, fshift);
+                float f = __builtin_amdgcn_exp2f(-__builtin_fmaf(t, t, fcc));
+                if (k0 + pk0 + j4 + j >= R) f = 0.0f;      // rows/cols past the image contract nothing
+                fdst[(j4 + j) * LD] = f;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kp = 0; kp < KC / 2; ++kp) {
+            const float g0 = pg[kp * 2 * LD], g1 = pg1[kp * 2 * LD];
+            const float f0 = pf[kp * 2 * LD], f1 = pf1[kp * 2 * LD];
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(g0, f0, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(g0, f1, acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(g1, f0, acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(g1, f1, acc[3], 0, 0, 0);
+        }
+    }
+
+    // epilogue: this lane's ray is column lr of ray block nb; the 16 registers of an
+    // accumulator block are c = (e&3) + 8(e>>2) + 4·lh of c block cb
+    const int JB = (R + 63) / 64;
+    const int cblock = (c0 + wc) / 64;
+    if (c0 + wc >= R) return;                              // (wave-uniform) nothing of the image here
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+        const int n = n0 + wn + 32 * nb + lr;
+        float4 h = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n < N) h = reinterpret_cast<const float4*>(rays)[(long)b * N + n];
+        const float hshift = PASS == 0 ? h.y : h.x;
+        const float hcc = PASS == 0 ? 0.0f : h.w;
+        float m0 = 0.f, m1 = 0.f, m2 = 0.f;
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int cl = wc + 32 * cb + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                const float s = sCc[cl] + hshift;
+                const float w = __builtin_amdgcn_exp2f(-(__builtin_fmaf(s, s, hcc) * h.z)) * acc[2 * cb + nb][e];
+                m0 += w;
+                m1 = __builtin_fmaf(s, w, m1);
+                m2 = __builtin_fmaf(s * s, w, m2);
+            }
+        }
+        m0 += __shfl_xor(m0, 32); m1 += __shfl_xor(m1, 32); m2 += __shfl_xor(m2, 32);
+        if (lh == 0 && n < N) {
+            float* o = moments + (((long)b * JB + cblock) * N + n) * HELIO_MOMENT_STRIDE;
+            if (PASS == 0) { o[0] = m0; o[2] = m1; o[4] = m2; }
+            else { o[1] = m1; o[3] = m2; }
+        }
+    }
+}
+
+template <int PASS>
+static void launch_bwd_mfma(int B, int N, int R, const float* rays, const float* xs, const float* ys,
+                            const float* gimg, float* moments, hipStream_t st) {
+    const size_t lds = (2 * 64 * 257 + 256 + 64) * sizeof(float);
+    static bool configured = false;
+    if (!configured) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(splat_bwd_mfma<PASS>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        configured = true;
+    }
+    const int ct = (R + 255) / 256, nt = (N + 255) / 256;
+    hipLaunchKernelGGL(splat_bwd_mfma<PASS>, dim3(ct * nt, B), dim3(1024), lds, st, B, N, R, rays, xs, ys, gimg, moments);
+}
+
 int splat_bwd_blocks(int R) { return (R + BW_JT - 1) / BW_JT; }
 
-void launch_splat_bwd(int B, int N, int R, const float* rays, const float* xs, const float* ys,
-                      const float* gimg, float* moments, hipStream_t st) {
+// variant: 0 = by problem size, 1 = VALU kernel, 2 = MFMA kernels
+int launch_splat_bwd(int B, int N, int R, const float* rays, const float* xs, const float* ys,
+                     const float* gimg, float* moments, int variant, hipStream_t st) {
+    if (variant == 0) {
+        const long wgs = (long)B * ((R + 255) / 256) * ((N + 255) / 256);
+        variant = (R >= 128 && N >= 96 && wgs >= 128) ? 2 : 1;
+    }
+    if (variant == 2) {
+        launch_bwd_mfma<0>(B, N, R, rays, xs, ys, gimg, moments, st);
+        launch_bwd_mfma<1>(B, N, R, rays, xs, ys, gimg, moments, st);
+        return HELIO_OK;
+    }
+    if (variant != 1) return HELIO_E_INVALID;
     const int JB = splat_bwd_blocks(R), NB = (N + BW_NT - 1) / BW_NT;
     hipLaunchKernelGGL(splat_bwd_valu, dim3(JB * NB, B), dim3(256), 0, st, B, N, R, rays, xs, ys, gimg, moments);
+    return HELIO_OK;
 }
 
 }  // namespace helio

@@ -28,6 +28,7 @@
 // the 16-wave kernel (128-VGPR budget) in one level: measured 1.5e-6 of peak apart at N=2000.
 #include <hip/hip_runtime.h>
 #include "helio.h"
+#include "ray_trace.h"
 
 namespace helio {
 
@@ -338,6 +339,90 @@ splat_fwd_mfma_tile(int B, int N, int R, const float* __restrict__ rays, const f
 #pragma unroll
     for (int m = 0; m < 4; ++m)
         store_block(img, R, ti0 + wi + 32 * (m >> 1), tj0 + wj + 32 * (m & 1), lr, lh, TWO_LEVEL ? tot[m] : acc[m]);
+}
+
+// Small problems are launch-latency bound (config 2 is 41 MFLOP ≈ 0.3 µs at peak): one
+// launch instead of two.  Every workgroup (64×64 pixel tile, 4 waves of one 32×32 MFMA block)
+// traces the rays of its own sun itself — threads 0..127 of a chunk run the bit-faithful
+// trace() of ray_trace.h straight into the LDS ray table — and the workgroup of tile 0 also
+// writes `actual`, `refl` and the `rays` work buffer.  The redundant geometry (once per tile
+// of an image) is a few hundred flops per ray.
+__global__ void __launch_bounds__(256)
+render_fwd_fused_small(int B, int N, int R, const float* __restrict__ helios, const float* __restrict__ sun,
+                       const float* __restrict__ action, const float* __restrict__ trig, long trig_b_stride,
+                       PlaneK P, const float* __restrict__ xs, const float* __restrict__ ys,
+                       float* __restrict__ actual, float* __restrict__ refl, float* __restrict__ rays,
+                       float* __restrict__ image) {
+    constexpr int NC = 128;
+    __shared__ float4 sRay[NC + 4];
+
+    const int tiles_j = (R + 63) / 64;
+    const int b = blockIdx.y;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int i0 = (blockIdx.x / tiles_j) * 64 + (wave >> 1) * 32;
+    const int j0 = (blockIdx.x % tiles_j) * 64 + (wave & 1) * 32;
+    const bool writer = blockIdx.x == 0;
+
+    const float xv = xs[min(i0 + lr, R - 1)], yv = ys[min(j0 + lr, R - 1)];
+    const vec3 s = ld3(sun + 3l * b);
+    f32x16 tot, acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { tot[e] = 0.0f; acc[e] = 0.0f; }
+
+    const float4 pad = make_float4(0.f, 0.f, 1.f, 1e30f);   // A = exp2(-1e30) = 0 exactly
+    for (int n0 = 0; n0 < N; n0 += NC) {
+        __syncthreads();
+        if (tid < NC + 4) {
+            float4 v = pad;
+            const int n = n0 + tid;
+            if (tid < NC && n < N) {
+                const long m = (long)b * N + n;
+                const float4 tg = *reinterpret_cast<const float4*>(trig + (long)b * trig_b_stride + 4l * n);
+                const Ray q = trace(ld3(action + 3 * m), tg.x, tg.y, tg.z, tg.w, ld3(helios + 3l * n), s, P);
+                v = make_float4(q.a, q.b, q.k2, q.c2);
+                if (writer) {
+                    st3(actual + 3 * m, q.act);
+                    if (refl) st3(refl + 3 * m, q.r);
+                    if (rays) *reinterpret_cast<float4*>(rays + 4 * m) = v;
+                }
+            }
+            sRay[tid] = v;
+        }
+        __syncthreads();
+        const int cnt = min(NC, N - n0);
+        float4 q0 = sRay[lh], q1 = sRay[2 + lh];
+        for (int k = 0; k < cnt; k += 4) {
+            const float4 p0 = q0, p1 = q1;
+            q0 = sRay[k + 4 + lh];
+            q1 = sRay[k + 6 + lh];
+            const float t0 = xv + p0.x, t1 = xv + p1.x, u0 = yv + p0.y, u1 = yv + p1.y;
+            const float fa0 = exp2_fast(-(__builtin_fmaf(t0, t0, p0.w) * p0.z));
+            const float fa1 = exp2_fast(-(__builtin_fmaf(t1, t1, p1.w) * p1.z));
+            const float fe0 = exp2_fast(-((u0 * u0) * p0.z));
+            const float fe1 = exp2_fast(-((u1 * u1) * p1.z));
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0, fe0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1, fe1, acc, 0, 0, 0);
+        }
+        tot += acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+    }
+    store_block(image + (long)b * R * R, R, i0, j0, lr, lh, tot);
+}
+
+// true when launch_render_fwd() would take the single-launch path
+bool render_is_fused(int B, int N, int R) {
+    const long t128 = (long)B * ((R + 127) / 128) * ((R + 127) / 128);
+    return t128 < 512 && N <= 4096;
+}
+
+void launch_render_fused(int B, int N, int R, const float* helios, const float* sun, const float* action,
+                         const float* trig, long trig_b_stride, const helio_plane* plane, const float* xs,
+                         const float* ys, float* actual, float* refl, float* rays, float* image, hipStream_t st) {
+    const int t = (R + 63) / 64;
+    hipLaunchKernelGGL(render_fwd_fused_small, dim3(t * t, B), dim3(256), 0, st, B, N, R, helios, sun, action,
+                       trig, trig_b_stride, to_k(plane), xs, ys, actual, refl, rays, image);
 }
 
 template <int MBI, int MBJ, int WI, int WJ, int NC, bool TWO_LEVEL>

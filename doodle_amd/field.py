@@ -27,10 +27,8 @@ class _Render(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, normals, field, sun, trig, trig_stride):
-        ops = _get_ops()
-        actual, refl, rays = ops.geometry_fwd(field.heliostat_positions, sun, normals, trig, trig_stride,
-                                              field._plane)
-        image = ops.splat_fwd(rays, field._xs, field._ys)
+        image, actual, refl, rays = _get_ops().render_fwd(
+            field.heliostat_positions, sun, normals, trig, trig_stride, field._plane, field._xs, field._ys)
         ctx.field, ctx.trig_stride = field, trig_stride
         ctx.save_for_backward(normals, sun, trig, rays)
         return image, actual, refl
@@ -105,6 +103,7 @@ class HelioField:
         self._ys = torch.linspace(-self.target_height / 2, self.target_height / 2, self.resolution).to(self.device)
 
         self._trig_cache = {}
+        self._ray_ws = None
         self.reset_errors()
         self.initial_action = None
 
@@ -209,8 +208,11 @@ class HelioField:
         if torch.is_grad_enabled() and normals.requires_grad:
             images, actual, refl = _Render.apply(normals, self, sun, trig, stride)
         else:
-            ops = _get_ops()
-            actual, refl, rays = ops.geometry_fwd(self.heliostat_positions, sun, normals, trig, stride,
-                                                  self._plane, want_refl=monitor)
-            images = ops.splat_fwd(rays, self._xs, self._ys)
+            # no autograd: the ray work buffer is scratch, reuse it between calls
+            ws = self._ray_ws
+            if ws is None or ws.shape[0] != B or ws.device != normals.device:
+                ws = self._ray_ws = torch.empty((B, N, native.RAY_STRIDE), dtype=torch.float32, device=normals.device)
+            images, actual, refl, _ = _get_ops().render_fwd(
+                self.heliostat_positions, sun, normals, trig, stride, self._plane, self._xs, self._ys,
+                want_refl=monitor, rays=ws)
         return images, actual, (refl.view(-1, 3) if refl is not None else None)

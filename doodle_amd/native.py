@@ -20,7 +20,7 @@ MOMENT_STRIDE = 5
 
 EXPORTS = (
     "helio_abi_version", "helio_last_error_string", "helio_device_arch", "helio_geometry_fwd",
-    "helio_splat_fwd", "helio_splat_bwd_blocks", "helio_splat_bwd", "helio_geometry_bwd",
+    "helio_splat_fwd", "helio_render_fwd", "helio_render_fwd_launches", "helio_splat_bwd_blocks", "helio_splat_bwd", "helio_geometry_bwd",
     "helio_ideal_normals",
 )
 
@@ -53,8 +53,10 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
         "helio_device_arch": (_i, [_i, ctypes.c_char_p, _i]),
         "helio_geometry_fwd": (_i, [_i, _i, _vp, _vp, _vp, _vp, _l, pp, _vp, _vp, _vp, _vp]),
         "helio_splat_fwd": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp]),
+        "helio_render_fwd": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _l, pp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+        "helio_render_fwd_launches": (_i, [_i, _i, _i]),
         "helio_splat_bwd_blocks": (_i, [_i]),
-        "helio_splat_bwd": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+        "helio_splat_bwd": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
         "helio_geometry_bwd": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _l, pp, _vp, _vp, _vp, _vp, _vp]),
         "helio_ideal_normals": (_i, [_i, _i, _vp, _vp, ctypes.c_float * 3, _vp, _vp]),
     }
@@ -79,7 +81,14 @@ def _dev(t: torch.Tensor) -> int:
     return t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream() -> int:
+    """torch's current HIP stream handle (the raw getter is ~30x cheaper than building a
+    torch.cuda.Stream object per call, which matters for the launch-bound small configs)."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -96,6 +105,7 @@ class HipOps:
         if not self.arch.startswith("gfx950"):
             raise RuntimeError(f"libhelio.so is built for gfx950 (MI355X); device is {self.arch}")
         self.splat_variant = int(os.environ.get("HELIO_SPLAT_VARIANT", "0"))
+        self.bwd_variant = int(os.environ.get("HELIO_BWD_VARIANT", "0"))
 
     # -- forward ---------------------------------------------------------------------------
     def geometry_fwd(self, helios, sun, normals, trig, trig_b_stride, plane, want_refl=True, want_rays=True):
@@ -109,6 +119,21 @@ class HipOps:
             rays.data_ptr() if want_rays else None, _stream()))
         return actual, refl, rays
 
+    def render_fwd(self, helios, sun, normals, trig, trig_b_stride, plane, xs, ys, want_refl=True, rays=None):
+        """geometry + splat in ONE C call (one fused launch for small problems).
+        ``rays``: a caller-provided [B,N,4] work buffer to reuse, else a fresh one."""
+        B, N, R = normals.shape[0], normals.shape[1], xs.shape[0]
+        actual = torch.empty_like(normals)
+        refl = torch.empty_like(normals) if want_refl else None
+        if rays is None:
+            rays = torch.empty((B, N, RAY_STRIDE), dtype=torch.float32, device=normals.device)
+        image = torch.empty((B, R, R), dtype=torch.float32, device=normals.device)
+        _check(self.lib, self.lib.helio_render_fwd(
+            B, N, R, _dev(helios), _dev(sun), _dev(normals), _dev(trig), trig_b_stride, plane,
+            _dev(xs), _dev(ys), actual.data_ptr(), refl.data_ptr() if want_refl else None,
+            rays.data_ptr(), image.data_ptr(), self.splat_variant, _stream()))
+        return image, actual, refl, rays
+
     def splat_fwd(self, rays, xs, ys, variant=None):
         B, N, R = rays.shape[0], rays.shape[1], xs.shape[0]
         image = torch.empty((B, R, R), dtype=torch.float32, device=rays.device)
@@ -118,12 +143,13 @@ class HipOps:
         return image
 
     # -- backward --------------------------------------------------------------------------
-    def splat_bwd(self, rays, xs, ys, grad_image):
+    def splat_bwd(self, rays, xs, ys, grad_image, variant=None):
         B, N, R = rays.shape[0], rays.shape[1], xs.shape[0]
         jb = self.lib.helio_splat_bwd_blocks(R)
         moments = torch.empty((B, jb, N, MOMENT_STRIDE), dtype=torch.float32, device=rays.device)
         _check(self.lib, self.lib.helio_splat_bwd(
-            B, N, R, _dev(rays), _dev(xs), _dev(ys), _dev(grad_image), moments.data_ptr(), _stream()))
+            B, N, R, _dev(rays), _dev(xs), _dev(ys), _dev(grad_image), moments.data_ptr(),
+            self.bwd_variant if variant is None else variant, _stream()))
         return moments
 
     def geometry_bwd(self, helios, sun, normals, trig, trig_b_stride, plane, moments, grad_actual, grad_refl):

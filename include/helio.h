@@ -95,6 +95,23 @@ int helio_splat_fwd(int B, int N, int R,
                     const float *rays_d, const float *xs_d, const float *ys_d,
                     float *image_d, int variant, void *stream);
 
+/*
+ * The whole forward of HelioField.render (:356-406) in one call: helio_geometry_fwd followed
+ * by helio_splat_fwd on the same stream, or — for small problems, which are launch-latency
+ * bound — ONE fused kernel in which every workgroup traces the rays of its own sun.  Results
+ * are identical either way.  rays_d may be NULL only if the caller never runs the backward AND
+ * the problem takes the fused path; pass the work buffer to be safe.  refl_d may be NULL.
+ */
+int helio_render_fwd(int B, int N, int R,
+                     const float *helios_d, const float *sun_d, const float *action_d,
+                     const float *trig_d, long trig_b_stride, const helio_plane *plane,
+                     const float *xs_d, const float *ys_d,
+                     float *actual_d, float *refl_d, float *rays_d, float *image_d,
+                     int variant, void *stream);
+
+/* Kernel launches helio_render_fwd(variant 0) issues for this size: 1 (fused) or 2. */
+int helio_render_fwd_launches(int B, int N, int R);
+
 /* Column blocks the backward splat splits an R-wide image into (the size of the
  * second dimension of moments_d). */
 int helio_splat_bwd_blocks(int R);
@@ -105,11 +122,14 @@ int helio_splat_bwd_blocks(int R);
  * Gg = grad_image[b] * gauss_bn,
  *   moments_d[b,jb,n,:] = sum_{i, j in block} Gg * (1, t, s, t^2, s^2),
  *   t = xs[i]+a, s = ys[j]+b.
- * moments_d has shape [B, helio_splat_bwd_blocks(R), N, HELIO_MOMENT_STRIDE].
+ * moments_d has shape [B, helio_splat_bwd_blocks(R), N, HELIO_MOMENT_STRIDE]; a block is
+ * 64 image columns for (M0, Ms, Mss) and — in the MFMA kernels — 64 image rows for (Mt, Mtt);
+ * only the sum over blocks is meaningful.
+ * variant: 0 = by problem size, 1 = VALU kernel, 2 = f32 MFMA kernels.
  */
 int helio_splat_bwd(int B, int N, int R,
                     const float *rays_d, const float *xs_d, const float *ys_d,
-                    const float *grad_image_d, float *moments_d, void *stream);
+                    const float *grad_image_d, float *moments_d, int variant, void *stream);
 
 /*
  * Backward of helio_geometry_fwd: chains d(image)/d(ray parameters) (from the

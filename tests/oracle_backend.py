@@ -47,6 +47,10 @@ class OracleOps:
             actual, refl, rays = self._forward(helios, sun, normals, trig, trig_b_stride, plane)
         return actual.contiguous(), (refl.contiguous() if want_refl else None), (rays.contiguous() if want_rays else None)
 
+    def render_fwd(self, helios, sun, normals, trig, trig_b_stride, plane, xs, ys, want_refl=True, rays=None):
+        actual, refl, r = self.geometry_fwd(helios, sun, normals, trig, trig_b_stride, plane, want_refl, True)
+        return self.splat_fwd(r, xs, ys), actual, refl, r
+
     @staticmethod
     def _factors(rays, xs, ys):
         a, b, k2, c2 = (rays[..., i:i + 1] for i in range(4))
@@ -63,7 +67,7 @@ class OracleOps:
             out.append(A[0].t().contiguous() @ E[0])
         return torch.stack(out).contiguous()
 
-    def splat_bwd(self, rays, xs, ys, grad_image):
+    def splat_bwd(self, rays, xs, ys, grad_image, variant=None):
         t, s, A, E = self._factors(rays.double(), xs.double(), ys.double())
         G = grad_image.double()
         U = lambda wa, we: torch.einsum("bni,bij,bnj->bn", wa, G, we)  # noqa: E731

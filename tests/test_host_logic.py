@@ -47,6 +47,7 @@ def test_abi_rejects_bad_arguments_without_launching():
     assert lib.helio_geometry_fwd(0, 5, None, None, None, None, 0, plane, None, None, None, None) == -1
     assert b"bad sizes" in lib.helio_last_error_string()
     assert lib.helio_splat_fwd(1, 1, 8, None, None, None, None, 0, None) == -1
+    assert lib.helio_render_fwd_launches(25, 50, 128) == 1 and lib.helio_render_fwd_launches(512, 2000, 512) == 2
     assert b"null pointer" in lib.helio_last_error_string()
 
 

@@ -70,10 +70,13 @@ def test_ray_parameters_match_reference_intersections(name):
     assert np.array_equal(rays[:, 2] > 0, mask > 0)
 
 
+@pytest.mark.parametrize("bwd_variant", [1, 2])
 @pytest.mark.parametrize("name", NAMES)
-def test_backward_matches_reference_autograd(name):
+def test_backward_matches_reference_autograd(name, bwd_variant, monkeypatch):
+    from doodle_amd import native
     g = golden(name)
     f = field_from(g)
+    monkeypatch.setattr(native.get_ops(), "bwd_variant", bwd_variant)
     act = torch.from_numpy(g["action"]).to(DEV).requires_grad_(True)
     img, actual, refl = f.render(torch.from_numpy(g["sun"]), act, None, monitor=True)
     G, H, Q = (torch.from_numpy(g[k]).to(DEV) for k in ("G", "H", "Q"))
