@@ -136,6 +136,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-large", action="store_true", help="skip the config-4 roofline leg")
     ap.add_argument("--mode", default="fwd", choices=["fwd", "fwdbwd"])
+    ap.add_argument("--overlap", action="store_true",
+                    help="run the all-gather on a side stream (overlaps the next render)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed and all-gather even with one rank (testing)")
     args = ap.parse_args()
@@ -160,7 +162,12 @@ def main():
     field = build_field(w, helios, errs, dev)
     suns_d = suns.to(dev)
     action = make_action(field, suns_d, noise)
-    gathered = torch.empty((world * w.B, w.R, w.R), dtype=torch.float32, device=dev) if dist is not None else None
+    gather, gathered = None, None
+    if dist is not None:
+        from doodle_amd.comm import ImageGather
+        gather = ImageGather()                 # RCCL all-gather on a side stream (libhelio_comm.so)
+        gathered = [torch.empty((world * w.B, w.R, w.R), dtype=torch.float32, device=dev) for _ in range(2)]
+    stepno = [0]
     if args.mode == "fwdbwd":
         action.requires_grad_(True)
         G = torch.ones((w.B, w.R, w.R), device=dev)
@@ -172,13 +179,17 @@ def main():
         else:
             img, actual = field.render(suns_d, action, None)
             torch.autograd.grad((img * G).sum() + actual.sum(), action)
-        if gathered is not None:
-            dist.all_gather_into_tensor(gathered, img.detach())
+        if gather is not None:
+            # stream-ordered behind the render by default; --overlap puts it on a side stream
+            gather.gather(img.detach(), gathered[stepno[0] & 1], overlap=args.overlap)
+            stepno[0] += 1
 
     for _ in range(args.warmup):
         step()
 
     def fence():
+        if gather is not None:
+            gather.wait()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
@@ -205,7 +216,9 @@ def main():
                                    f"HelioField.render, sigma_scale={w.sigma_scale}, err={w.error_scale_mrad} mrad, "
                                    f"{w.B} suns per GPU",
                        "global_batch": world * w.B, "parallelism": f"sun-batch sharded x{world}"
-                       + (", RCCL all-gather of images" if dist is not None else "")},
+                       + (f", RCCL all-gather of images ({gather.transport} transport, "
+                          f"{'side stream' if args.overlap else 'stream-ordered'})"
+                          if gather is not None else "")},
         }
         iters = 200 if w.B * w.N * w.R * w.R < 1e10 else 10
         out["roofline"] = splat_roofline(field, suns_d, action.detach(), iters)
@@ -219,6 +232,8 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(w, args.seed)
                 out["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
         print(json.dumps(out), flush=True)
+    if gather is not None:
+        gather.close()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -14,9 +14,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libhelio.so")
+COMM_LIB = os.path.join(HERE, "libhelio_comm.so")      # RCCL wrapper, separate so that the
+COMM_SOURCES = ["comm.hip"]                             # kernels library has no RCCL dependency
 SOURCES = ["abi.hip", "geometry.hip", "splat_fwd.hip", "splat_bwd.hip"]
 HEADERS = [os.path.join(CSRC, "helio_math.h"), os.path.join(CSRC, "ray_trace.h"),
-           os.path.join(ROOT, "include", "helio.h")]
+           os.path.join(ROOT, "include", "helio.h"), os.path.join(ROOT, "include", "helio_comm.h")]
 # -ffp-contract=off: the geometry stage is bit-faithful to the reference's fp32 CPU
 # arithmetic; FMAs appear only where written (helio_math.h).  Division and sqrt stay
 # correctly rounded (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt).
@@ -32,10 +34,10 @@ def hipcc() -> str:
 
 
 def is_stale() -> bool:
-    if not os.path.exists(LIB):
+    if not os.path.exists(LIB) or not os.path.exists(COMM_LIB):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + HEADERS
+    t = min(os.path.getmtime(LIB), os.path.getmtime(COMM_LIB))
+    deps = [os.path.join(CSRC, s) for s in SOURCES + COMM_SOURCES] + HEADERS
     return any(os.path.getmtime(d) > t for d in deps)
 
 
@@ -44,6 +46,13 @@ def build(force: bool = False, verbose: bool = False) -> str:
         return LIB
     cmd = [hipcc(), *FLAGS, "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-o", LIB,
            *[os.path.join(CSRC, s) for s in SOURCES]]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    rocm_lib = os.path.join(os.path.dirname(os.path.dirname(os.path.realpath(hipcc()))), "lib")
+    cmd = [hipcc(), "-O2", "--offload-arch=gfx950", "-fPIC", "-shared", "-std=c++17",
+           "-I", os.path.join(ROOT, "include"), "-o", COMM_LIB,
+           *[os.path.join(CSRC, s) for s in COMM_SOURCES], "-L", rocm_lib, "-lrccl"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

@@ -13,6 +13,8 @@ from __future__ import annotations
 import torch
 import torch.distributed as dist
 
+from .comm import ImageGather
+
 
 def shard_rows(B: int, world: int, rank: int):
     """Rows [b0, b1) of a global batch of ``B`` owned by ``rank``: fixed-size chunks of
@@ -26,15 +28,16 @@ class _GatherRows(torch.autograd.Function):
     """all-gather of equally sized row blocks; backward = this rank's block of the cotangent."""
 
     @staticmethod
-    def forward(ctx, local, group, rank, world):
-        out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-        dist.all_gather_into_tensor(out, local.contiguous(), group=group)
-        ctx.rows, ctx.rank = local.shape[0], rank
+    def forward(ctx, local, gather):
+        out = torch.empty((gather.world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype,
+                          device=local.device)
+        gather.gather(local, out)
+        ctx.rows, ctx.rank = local.shape[0], gather.rank
         return out
 
     @staticmethod
     def backward(ctx, g):
-        return g[ctx.rank * ctx.rows:(ctx.rank + 1) * ctx.rows], None, None, None
+        return g[ctx.rank * ctx.rows:(ctx.rank + 1) * ctx.rows], None
 
 
 class ShardedRenderer:
@@ -46,11 +49,11 @@ class ShardedRenderer:
     ``gather_geometry`` is set.
     """
 
-    def __init__(self, field, group=None):
+    def __init__(self, field, group=None, transport: str = "auto"):
         self.field = field
         self.group = group
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.gather = ImageGather(group, transport)     # RCCL directly on GPUs, torch.distributed otherwise
+        self.world, self.rank = self.gather.world, self.gather.rank
 
     def local_rows(self, B: int):
         return shard_rows(B, self.world, self.rank)[:2]
@@ -75,9 +78,9 @@ class ShardedRenderer:
         else:
             if img.shape[0] < chunk:    # pad the ragged tail so every rank sends `chunk` rows
                 img = torch.cat([img, img.new_zeros((chunk - img.shape[0], R, R))], dim=0)
-            images = _GatherRows.apply(img, self.group, self.rank, self.world)[:B]
+            images = _GatherRows.apply(img, self.gather)[:B]
             if gather_geometry:
                 pad = lambda t, rows: torch.cat([t, t.new_zeros((rows - t.shape[0],) + tuple(t.shape[1:]))], 0)  # noqa: E731
-                actual = _GatherRows.apply(pad(actual, chunk), self.group, self.rank, self.world)[:B]
-                refl = _GatherRows.apply(pad(refl.view(-1, N, 3), chunk), self.group, self.rank, self.world)[:B].reshape(-1, 3)
+                actual = _GatherRows.apply(pad(actual, chunk), self.gather)[:B]
+                refl = _GatherRows.apply(pad(refl.view(-1, N, 3), chunk), self.gather)[:B].reshape(-1, 3)
         return (images, actual, refl) if monitor else (images, actual)

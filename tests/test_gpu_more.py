@@ -205,3 +205,36 @@ def test_config5_shard_properties():
     (g12,) = torch.autograd.grad((img * (G1 + 2 * G2)).sum(), act)
     assert (g12 - (g1 + 2 * g2)).abs().max().item() <= 1e-4 * g12.abs().max().item()
     assert torch.isfinite(g12).all()
+
+
+def test_rccl_gather_single_rank_process_group():
+    """One-rank 'nccl' group on the one GPU of the box: the RCCL transport (libhelio_comm.so:
+    unique id → ncclCommInitRank → ncclAllGather on a side stream) must give the unsharded
+    render, forward and backward.  Multi-rank behaviour is covered on CPU with gloo."""
+    import os
+    import torch.distributed as dist
+    from doodle_amd.sharded import ShardedRenderer
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", RANK="0", WORLD_SIZE="1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        f, _, suns, _, act = make_case(N=70, B=6, R=64, seed=9)
+        a = act.to(DEV).requires_grad_(True)
+        sr = ShardedRenderer(f)
+        assert sr.gather.transport == "rccl"
+        full, actual = f.render(suns, a, None)
+        img, act2 = sr.render(suns, a)
+        assert torch.equal(img, full) and torch.equal(act2, actual)
+        G = torch.randn_like(full)
+        (g1,) = torch.autograd.grad((full * G).sum(), a, retain_graph=True)
+        (g2,) = torch.autograd.grad((img * G).sum(), a)
+        assert torch.equal(g1, g2)
+        # overlapped form: enqueue on the side stream, wait, compare
+        out = torch.empty_like(full)
+        sr.gather.gather(full.detach(), out, overlap=True)
+        sr.gather.wait()
+        torch.cuda.synchronize()
+        assert torch.equal(out, full.detach())
+        sr.gather.close()
+    finally:
+        dist.destroy_process_group()

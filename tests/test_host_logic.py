@@ -40,6 +40,17 @@ def test_library_exports_every_declared_symbol():
     assert lib.helio_splat_bwd_blocks(128) == 2 and lib.helio_splat_bwd_blocks(100) == 2
 
 
+def test_comm_library_exports_every_declared_symbol():
+    from doodle_amd import comm
+    header = open(os.path.join(ROOT, "include", "helio_comm.h")).read()
+    declared = set(re.findall(r"\b(helio_comm_[a-z_0-9]+)\s*\(", header))
+    assert declared == set(comm.COMM_EXPORTS), declared ^ set(comm.COMM_EXPORTS)
+    lib = comm.load_comm_library()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.helio_comm_allgather_f32(None, None, None, 0, None) == -1      # validates before touching RCCL
+
+
 def test_abi_rejects_bad_arguments_without_launching():
     from doodle_amd import native
     lib = native.load_library()
