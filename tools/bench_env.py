@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""HelioEnv.step timing on MI355X at the README/training configuration (N=50, B=25, R=128)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from doodle_amd.env import HelioEnv
+
+dev = "cuda"
+torch.manual_seed(0)
+N, B, R = 50, 25, 128
+hp = torch.rand(N, 3, device=dev) * 10 + 80; hp[:, 2] = 0
+env = HelioEnv(hp, torch.tensor([0., -5., 0.], device=dev), (15., 15.), torch.tensor([0., 1., 0.], device=dev),
+               sigma_scale=0.01, error_scale_mrad=90.0, resolution=R, batch_size=B, device=dev)
+obs = env.reset()
+act = (env.ideal_normals + 0.003 * torch.randn_like(env.ideal_normals))
+act = torch.nn.functional.normalize(act, dim=2).reshape(B, -1)
+
+def timeit(fn, n=300):
+    for _ in range(20): fn()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(n): fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e6
+
+with torch.no_grad():
+    t_fwd = timeit(lambda: env.step(act))
+a = act.clone().requires_grad_(True)
+def fb(key):
+    _, m, _ = env.step(a)
+    m[key].backward()
+    a.grad = None
+t_align = timeit(lambda: fb("alignment_loss"))
+t_dist = timeit(lambda: fb("dist"))
+print(f"env.step forward-only {t_fwd:8.1f} us = {B/t_fwd*1e6:10.0f} frames/s | step+backward(alignment) {t_align:8.1f} us | step+backward(dist) {t_dist:8.1f} us")
+with torch.no_grad():
+    print(f"reset() {timeit(lambda: env.reset(), 100):8.1f} us")
+if "--profile" in sys.argv:
+    from torch.profiler import profile, ProfilerActivity
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+        with torch.no_grad():
+            for _ in range(50): env.step(act)
+        torch.cuda.synchronize()
+    print(prof.key_averages().table(sort_by="self_cpu_time_total", row_limit=25, max_name_column_width=60))
