@@ -1,0 +1,293 @@
+// Fused loss block of HelioEnv.step for gfx950 (SURVEY.md §8 f, rows 1, 2 and 4).
+//
+// Reference: test_environment.py :436-457 (peak-normalised MSE, |pred-targ|, per-image mean,
+// EDT-weighted distance loss), :101-130 (boundary / anti-spill loss), :132-155 (alignment
+// angle).  The reference runs this as ≈60 elementwise/reduction launches over [B,R,R] and
+// [B,N] tensors; here it is two launches forward (partials, then one finishing workgroup) and
+// one launch backward.  The image part is genuinely HBM-bound: it streams img, target and the
+// distance map once (12 B/pixel, float4 loads) and writes nothing but partial sums.
+// Reductions are two-stage in a fixed order (no atomics): bit-reproducible run to run.
+#include <hip/hip_runtime.h>
+#include "helio.h"
+
+namespace helio {
+
+constexpr int SL_THREADS = 256;
+constexpr int SL_PIX_PER_WG = 4096;     // 16 pixels per thread
+constexpr int SL_RAYS_PER_WG = 256;
+
+struct LossGeom {                        // host constants of boundary(), by value
+    float tp[3], tn[3];                  // target position / normal (as the env stores them)
+    float hw, hh;                        // 0.75·W/2, 0.75·H/2   (test_environment.py:123)
+    float hwt, hht;                      // hw·0.75, hh·0.75     (:124)
+    int exponential_risk;
+};
+
+__device__ __forceinline__ float block_sum(float v, float* scratch) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (scratch[0] + scratch[1]) + (scratch[2] + scratch[3]);
+}
+
+// per-ray forward of the two ray losses; shared by forward and backward
+struct RayLoss {
+    float c, ang;            // clamped cosine, angle [mrad]
+    bool clamped;
+    float out;               // boundary term
+    // intermediates for the adjoint
+    float t, den, xl, yl, dx, dy, dist;
+    bool inside;
+};
+
+__device__ __forceinline__ RayLoss ray_loss(const float* __restrict__ ideal, const float* __restrict__ actual,
+                                            const float* __restrict__ v, const float* __restrict__ h,
+                                            const LossGeom& g) {
+    RayLoss r;
+    // :144-155  acos(clamp(<ideal,actual>)) · 1000
+    const float c0 = (ideal[0] * actual[0] + ideal[1] * actual[1]) + ideal[2] * actual[2];
+    const float hi = 0.99999994f;        // nextafter(1,0) - 1e-10, rounded to fp32
+    r.clamped = !(c0 > -hi && c0 < hi);
+    r.c = fminf(fmaxf(c0, -hi), hi);
+    r.ang = acosf(r.c) * 1000.0f;
+    // :115-130  boundary()
+    const float dots = -((v[0] * g.tn[0] + v[1] * g.tn[1]) + v[2] * g.tn[2]);
+    const bool valid = fabsf(dots) > 1e-6f;
+    r.den = dots + (valid ? 0.0f : 1e-6f);
+    r.t = ((g.tp[0] * v[0] + g.tp[1] * v[1]) + g.tp[2] * v[2]) / r.den;
+    r.xl = (h[0] + v[0] * r.t) - g.tp[0];            // local·(1,0,0)
+    r.yl = (h[2] + v[2] * r.t) - g.tp[2];            // local·(0,0,1)
+    r.dx = fmaxf(fabsf(r.xl) - g.hwt, 0.0f);
+    r.dy = fmaxf(fabsf(r.yl) - g.hht, 0.0f);
+    r.dist = sqrtf((r.dx * r.dx + r.dy * r.dy) + 1e-8f);
+    r.inside = fabsf(r.xl) <= g.hw && fabsf(r.yl) <= g.hh && valid;
+    r.out = r.inside ? 0.0f : r.dist;
+    return r;
+}
+
+// grid.x = image workgroups (B·chunks) followed by ray workgroups
+__global__ void __launch_bounds__(SL_THREADS)
+step_losses_partial(int B, int N, int R, int chunks, const float* __restrict__ img,
+                    const float* __restrict__ target, const float* __restrict__ tx,
+                    const float* __restrict__ dmaps, const float* __restrict__ ideal,
+                    const float* __restrict__ actual, const float* __restrict__ action,
+                    const float* __restrict__ helios, LossGeom g,
+                    float* __restrict__ part_img,      // [B, chunks, 3]
+                    float* __restrict__ part_ray,      // [ray_wgs, 2]
+                    float* __restrict__ align_err, float* __restrict__ all_bounds) {
+    __shared__ float scratch[4];
+    const int img_wgs = B * chunks;
+    const int tid = threadIdx.x;
+    if ((int)blockIdx.x < img_wgs) {
+        const int b = blockIdx.x / chunks, ch = blockIdx.x % chunks;
+        const long P = (long)R * R;
+        const long base = (long)b * P;
+        const float s = tx[b];
+        float sq = 0.f, ab = 0.f, ds = 0.f;
+        auto one = [&](float x, float y, float dm) {
+            const float d = x / s - y / s;       // pred_n - targ_n, as the reference divides (:438-441)
+            const float e = fabsf(d);
+            sq = __builtin_fmaf(d, d, sq);
+            ab += e;
+            ds = __builtin_fmaf(e, dm, ds);
+        };
+        const long p0 = (long)ch * SL_PIX_PER_WG;
+        if ((P & 3) == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const long p = p0 + 4l * (tid + SL_THREADS * k);
+                if (p < P) {
+                    const float4 a = *reinterpret_cast<const float4*>(img + base + p);
+                    const float4 t = *reinterpret_cast<const float4*>(target + base + p);
+                    const float4 m = *reinterpret_cast<const float4*>(dmaps + base + p);
+                    one(a.x, t.x, m.x); one(a.y, t.y, m.y); one(a.z, t.z, m.z); one(a.w, t.w, m.w);
+                }
+            }
+        } else {
+            for (int k = 0; k < 16; ++k) {
+                const long p = p0 + tid + (long)SL_THREADS * k;
+                if (p < P) one(img[base + p], target[base + p], dmaps[base + p]);
+            }
+        }
+        sq = block_sum(sq, scratch);
+        ab = block_sum(ab, scratch);
+        ds = block_sum(ds, scratch);
+        if (tid == 0) {
+            float* o = part_img + 3l * blockIdx.x;
+            o[0] = sq; o[1] = ab; o[2] = ds;
+        }
+    } else {
+        const int wg = blockIdx.x - img_wgs;
+        const long m = (long)wg * SL_RAYS_PER_WG + tid;
+        float sa = 0.f, sb = 0.f;
+        if (m < (long)B * N) {
+            const int n = (int)(m % N);
+            const RayLoss r = ray_loss(ideal + 3 * m, actual + 3 * m, action + 3 * m, helios + 3l * n, g);
+            align_err[m] = r.ang;
+            all_bounds[m] = r.out;
+            sa = r.ang;
+            sb = g.exponential_risk ? expf(r.out + 1e-6f) : r.out;
+        }
+        sa = block_sum(sa, scratch);
+        sb = block_sum(sb, scratch);
+        if (tid == 0) { part_ray[2l * wg] = sa; part_ray[2l * wg + 1] = sb; }
+    }
+}
+
+// one workgroup: out[0..3] = mse, dist, bound, alignment_loss; out[4] = 1 if any of the first
+// three is NaN/Inf else 0 (the reference's six asserts, :495-501, in one flag); mae[b]
+__global__ void __launch_bounds__(SL_THREADS)
+step_losses_final(int B, int N, int R, int chunks, int ray_wgs, const float* __restrict__ part_img,
+                  const float* __restrict__ part_ray, float* __restrict__ out, float* __restrict__ mae) {
+    __shared__ double red[4][SL_THREADS];
+    const int tid = threadIdx.x;
+    double sq = 0, ds = 0, sa = 0, sb = 0;
+    const double P = (double)R * R;
+    for (int b = tid; b < B; b += SL_THREADS) {
+        double bsq = 0, bab = 0, bds = 0;
+        for (int c = 0; c < chunks; ++c) {
+            const float* p = part_img + 3l * ((long)b * chunks + c);
+            bsq += p[0]; bab += p[1]; bds += p[2];
+        }
+        mae[b] = (float)(bab / P);
+        sq += bsq; ds += bds;
+    }
+    for (int w = tid; w < ray_wgs; w += SL_THREADS) { sa += part_ray[2l * w]; sb += part_ray[2l * w + 1]; }
+    red[0][tid] = sq; red[1][tid] = ds; red[2][tid] = sa; red[3][tid] = sb;
+    __syncthreads();
+    for (int s = SL_THREADS / 2; s > 0; s >>= 1) {
+        if (tid < s)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) red[k][tid] += red[k][tid + s];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const double M = (double)B * N;
+        const float mse = (float)(red[0][0] / (B * P)), dist = (float)(red[1][0] / B);
+        const float bound = (float)(red[3][0] / M), align = (float)(red[2][0] / M);
+        out[0] = mse; out[1] = dist; out[2] = bound; out[3] = align;
+        out[4] = (isfinite(mse) && isfinite(dist) && isfinite(bound)) ? 0.0f : 1.0f;
+    }
+}
+
+// backward: cotangents of the four scalars (device pointers, may be null) → grad_img,
+// grad_actual (alignment), grad_action (boundary).  Same grid split as the forward.
+__global__ void __launch_bounds__(SL_THREADS)
+step_losses_bwd(int B, int N, int R, int chunks, const float* __restrict__ img,
+                const float* __restrict__ target, const float* __restrict__ tx,
+                const float* __restrict__ dmaps, const float* __restrict__ ideal,
+                const float* __restrict__ actual, const float* __restrict__ action,
+                const float* __restrict__ helios, LossGeom g,
+                const float* __restrict__ g_mse, const float* __restrict__ g_dist,
+                const float* __restrict__ g_bound, const float* __restrict__ g_align,
+                float* __restrict__ grad_img, float* __restrict__ grad_actual, float* __restrict__ grad_action) {
+    const int img_wgs = grad_img ? B * chunks : 0;
+    const int tid = threadIdx.x;
+    if ((int)blockIdx.x < img_wgs) {
+        const int b = blockIdx.x / chunks, ch = blockIdx.x % chunks;
+        const long P = (long)R * R, base = (long)b * P;
+        const float s = tx[b];
+        const float km = (g_mse ? *g_mse : 0.0f) * 2.0f / ((float)B * (float)P);   // d mean(d²)
+        const float kd = (g_dist ? *g_dist : 0.0f) / (float)B;                      // d mean_b Σ e·dm
+        auto one = [&](float x, float y, float dm) -> float {
+            const float d = x / s - y / s;
+            const float sg = d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f);
+            return (km * d + kd * sg * dm) / s;
+        };
+        const long p0 = (long)ch * SL_PIX_PER_WG;
+        if ((P & 3) == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const long p = p0 + 4l * (tid + SL_THREADS * k);
+                if (p < P) {
+                    const float4 a = *reinterpret_cast<const float4*>(img + base + p);
+                    const float4 t = *reinterpret_cast<const float4*>(target + base + p);
+                    const float4 m = *reinterpret_cast<const float4*>(dmaps + base + p);
+                    *reinterpret_cast<float4*>(grad_img + base + p) =
+                        make_float4(one(a.x, t.x, m.x), one(a.y, t.y, m.y), one(a.z, t.z, m.z), one(a.w, t.w, m.w));
+                }
+            }
+        } else {
+            for (int k = 0; k < 16; ++k) {
+                const long p = p0 + tid + (long)SL_THREADS * k;
+                if (p < P) grad_img[base + p] = one(img[base + p], target[base + p], dmaps[base + p]);
+            }
+        }
+    } else {
+        const long m = (long)(blockIdx.x - img_wgs) * SL_RAYS_PER_WG + tid;
+        if (m >= (long)B * N) return;
+        const int n = (int)(m % N);
+        const float* v = action + 3 * m;
+        const float* id = ideal + 3 * m;
+        const RayLoss r = ray_loss(id, actual + 3 * m, v, helios + 3l * n, g);
+        const float inv = 1.0f / ((float)B * (float)N);
+        if (grad_actual) {
+            // d acos(c)·1000 / dc = -1000 / sqrt(1 - c²); zero where the clamp is active
+            const float ga = (g_align ? *g_align : 0.0f) * inv;
+            const float k = r.clamped ? 0.0f : ga * (-1000.0f / sqrtf(1.0f - r.c * r.c));
+            grad_actual[3 * m] = k * id[0]; grad_actual[3 * m + 1] = k * id[1]; grad_actual[3 * m + 2] = k * id[2];
+        }
+        if (grad_action) {
+            float go = (g_bound ? *g_bound : 0.0f) * inv;
+            if (g.exponential_risk) go *= expf(r.out + 1e-6f);
+            float gv[3] = {0.f, 0.f, 0.f};
+            if (!r.inside) {
+                const float gdx = go * r.dx / r.dist, gdy = go * r.dy / r.dist;
+                const float gxl = (fabsf(r.xl) - g.hwt > 0.0f) ? (r.xl > 0.0f ? gdx : (r.xl < 0.0f ? -gdx : 0.0f)) : 0.0f;
+                const float gyl = (fabsf(r.yl) - g.hht > 0.0f) ? (r.yl > 0.0f ? gdy : (r.yl < 0.0f ? -gdy : 0.0f)) : 0.0f;
+                // xl = h.x + v.x t - tp.x ; yl = h.z + v.z t - tp.z
+                const float gt = gxl * v[0] + gyl * v[2];
+                gv[0] = gxl * r.t; gv[2] = gyl * r.t;
+                // t = (tp·v) / den ; den = -(v·tn) (+1e-6)
+                const float gnum = gt / r.den, gden = -gt * r.t / r.den;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) gv[k] += gnum * g.tp[k] - gden * g.tn[k];
+            }
+            grad_action[3 * m] = gv[0]; grad_action[3 * m + 1] = gv[1]; grad_action[3 * m + 2] = gv[2];
+        }
+    }
+}
+
+static LossGeom make_geom(const float* tp, const float* tn, float W, float H, int exponential_risk) {
+    LossGeom g;
+    for (int k = 0; k < 3; ++k) { g.tp[k] = tp[k]; g.tn[k] = tn[k]; }
+    g.hw = (W * 0.75f) / 2.0f; g.hh = (H * 0.75f) / 2.0f;
+    g.hwt = g.hw * 0.75f; g.hht = g.hh * 0.75f;
+    g.exponential_risk = exponential_risk;
+    return g;
+}
+
+int step_losses_chunks(int R) { return (int)(((long)R * R + SL_PIX_PER_WG - 1) / SL_PIX_PER_WG); }
+int step_losses_ray_wgs(int B, int N) { return (int)(((long)B * N + SL_RAYS_PER_WG - 1) / SL_RAYS_PER_WG); }
+
+void launch_step_losses_fwd(int B, int N, int R, const float* img, const float* target, const float* tx,
+                            const float* dmaps, const float* ideal, const float* actual, const float* action,
+                            const float* helios, const float* tp, const float* tn, float W, float H,
+                            int exponential_risk, float* workspace, float* out, float* mae, float* align_err,
+                            float* all_bounds, hipStream_t st) {
+    const int chunks = step_losses_chunks(R), rw = step_losses_ray_wgs(B, N);
+    float* part_img = workspace;
+    float* part_ray = workspace + 3l * B * chunks;
+    hipLaunchKernelGGL(step_losses_partial, dim3(B * chunks + rw), dim3(SL_THREADS), 0, st, B, N, R, chunks, img,
+                       target, tx, dmaps, ideal, actual, action, helios, make_geom(tp, tn, W, H, exponential_risk),
+                       part_img, part_ray, align_err, all_bounds);
+    hipLaunchKernelGGL(step_losses_final, dim3(1), dim3(SL_THREADS), 0, st, B, N, R, chunks, rw, part_img, part_ray,
+                       out, mae);
+}
+
+void launch_step_losses_bwd(int B, int N, int R, const float* img, const float* target, const float* tx,
+                            const float* dmaps, const float* ideal, const float* actual, const float* action,
+                            const float* helios, const float* tp, const float* tn, float W, float H,
+                            int exponential_risk, const float* g_mse, const float* g_dist, const float* g_bound,
+                            const float* g_align, float* grad_img, float* grad_actual, float* grad_action,
+                            hipStream_t st) {
+    const int chunks = step_losses_chunks(R), rw = step_losses_ray_wgs(B, N);
+    const int grid = (grad_img ? B * chunks : 0) + rw;
+    hipLaunchKernelGGL(step_losses_bwd, dim3(grid), dim3(SL_THREADS), 0, st, B, N, R, chunks, img, target, tx, dmaps,
+                       ideal, actual, action, helios, make_geom(tp, tn, W, H, exponential_risk), g_mse, g_dist,
+                       g_bound, g_align, grad_img, grad_actual, grad_action);
+}
+
+}  // namespace helio

@@ -18,7 +18,10 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
+import ctypes
+
 from .field import HelioField
+from .losses import StepConstants, step_losses
 
 try:  # pragma: no cover - depends on the image
     import gymnasium as _gym
@@ -145,6 +148,11 @@ class HelioEnv(_EnvBase):
         self.single_sun = single_sun
         self.use_error_mask, self.error_mask_ratio = use_error_mask, error_mask_ratio
         self.exponential_risk = exponential_risk
+        self.check_finite = True        # the NaN/Inf asserts of :495-501 (one host sync per step)
+        self._ref_cache = None
+        f3 = ctypes.c_float * 3
+        self._tp3 = f3(*[float(x) for x in targ_pos.detach().cpu().tolist()])
+        self._tn3 = f3(*[float(x) for x in targ_norm.detach().cpu().tolist()])
 
         n_act = self.num_heliostats * 3
         self.action_space = _Box(low=-1.0, high=1.0, shape=(n_act,), dtype=np.float32)
@@ -176,9 +184,28 @@ class HelioEnv(_EnvBase):
         dirs[:, 2] = torch.abs(dirs[:, 2])
         return dirs
 
+    def _reference(self):
+        """Ideal normals, the error-free field's image of them and its per-image peak
+        (:414, :429-436).  The reference recomputes all three on every step although they
+        depend only on the sun positions and the (zero) reference errors; here they are
+        cached until either changes."""
+        errs = self.ref_field.batch_error_angles_mrad
+        single = self.ref_field.error_angles_mrad
+        key = (self.sun_pos.data_ptr(), self.sun_pos._version,
+               None if errs is None else (errs.data_ptr(), errs._version), single.data_ptr(), single._version,
+               self.ref_field.sigma_scale)
+        if self._ref_cache is None or self._ref_cache[0] != key:
+            with torch.no_grad():
+                ideal = self.ref_field.calculate_ideal_normals(self.sun_pos)
+                target, _ = self.ref_field.render(self.sun_pos, ideal.flatten(1), ideal)
+                tx = target.amax((1, 2)).clamp_min(1e-6)
+            self._ref_cache = (key, ideal, target, tx, (errs, single))
+        return self._ref_cache[1:4]
+
     def set_sun_pos(self, sun_positions: torch.Tensor):
         """Fix the sun positions and precompute the reference image statistics (:359-370)."""
         self.sun_pos = sun_positions.clone().detach()
+        self._ref_cache = None
         self.ref_field.init_actions(self.sun_pos)
         with torch.no_grad():
             ideal = self.ref_field.calculate_ideal_normals(self.sun_pos)
@@ -211,6 +238,33 @@ class HelioEnv(_EnvBase):
         """
         if isinstance(action, np.ndarray):
             action = torch.tensor(action, dtype=torch.float32, device=self.device)
+        if self.use_error_mask:
+            return self._step_torch(action)
+        ideal, target, tx = self._reference()
+        img, actual, reflected = self.noisy_field.render(self.sun_pos, action, ideal, monitor=True)
+        aux = torch.cat([self.sun_pos.detach(), action.flatten(1)], dim=1)
+        normals = action.view(self.batch_size, -1, 3)                    # :460
+        consts = StepConstants(target, tx, self.distance_maps, ideal, self.noisy_field.heliostat_positions,
+                               self._tp3, self._tn3, float(self.targ_area[0]), float(self.targ_area[1]),
+                               bool(self.exponential_risk))
+        mse, dist_l, bound, alignment_loss, mae, angles, all_bounds, flag = step_losses(img, actual, normals, consts)
+        if self.check_finite and bool(flag):                             # :495-501, one sync instead of six
+            raise AssertionError("MSE, distance loss or boundary loss is NaN or Inf")
+        metrics = {"mse": mse, "dist": dist_l, "bound": bound, "alignment_loss": alignment_loss}
+        obs = {"img": img, "aux": aux}
+        monitor = {
+            "normals": normals,
+            "reflected_rays": reflected.view([-1, 3]),
+            "ideal_normals": ideal.view([-1, 3]),
+            "all_bounds": all_bounds,
+            "mae_image": mae.view([-1, 1]),
+            "alignment_errors": angles.view([-1]),
+        }
+        return obs, metrics, monitor
+
+    def _step_torch(self, action):
+        """The ``use_error_mask=True`` branch (:444-452, torch.quantile), kept as torch ops on
+        the device around the two HIP renders."""
         ideal = self.ref_field.calculate_ideal_normals(self.sun_pos)
         img, actual, reflected = self.noisy_field.render(self.sun_pos, action, ideal, monitor=True)
         aux = torch.cat([self.sun_pos.detach(), action.flatten(1)], dim=1)

@@ -1,0 +1,62 @@
+"""Fused loss block of HelioEnv.step on the HIP kernels of csrc/step_losses.hip.
+
+Replaces, for the ``use_error_mask=False`` branch, the ≈60 small torch launches of the
+reference's ``step`` (test_environment.py:436-488) by two launches forward and one backward
+(C ABI: ``helio_step_losses_fwd`` / ``helio_step_losses_bwd``).  Gradients flow to ``img``
+(mse, dist), ``actual`` (alignment_loss) and ``action`` (bound), exactly the edges autograd
+builds in the reference.
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass
+
+import torch
+
+from . import field as _field
+
+
+@dataclass
+class StepConstants:
+    """Everything of the loss block that does not depend on the action."""
+    target: torch.Tensor      # [B,R,R]  reference-field image of the ideal normals (detached)
+    tx: torch.Tensor          # [B]      clamp_min(amax(target[b]), 1e-6)
+    dmaps: torch.Tensor       # [B,R,R]  distance maps
+    ideal: torch.Tensor       # [B,N,3]
+    helios: torch.Tensor      # [N,3]
+    tp: ctypes.Array          # target position, float[3]
+    tn: ctypes.Array          # target normal as the env holds it, float[3]
+    W: float
+    H: float
+    exp_risk: bool
+
+
+class _StepLosses(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, img, actual, action, consts):
+        out, mae, align, allb = _field._get_ops().step_losses_fwd(img, actual, action, consts)
+        ctx.consts = consts
+        ctx.save_for_backward(img, actual, action)
+        flag = out[4]
+        ctx.mark_non_differentiable(mae, align, allb, flag)
+        return out[0], out[1], out[2], out[3], mae, align, allb, flag
+
+    @staticmethod
+    def backward(ctx, g_mse, g_dist, g_bound, g_align, *_unused):
+        img, actual, action = ctx.saved_tensors
+        want = ctx.needs_input_grad
+        c = lambda g: g.contiguous() if g is not None else None  # noqa: E731
+        gi, ga, gn = _field._get_ops().step_losses_bwd(
+            img, actual, action, ctx.consts, c(g_mse), c(g_dist), c(g_bound), c(g_align),
+            want[0] and (g_mse is not None or g_dist is not None), want[1] and g_align is not None,
+            want[2] and g_bound is not None)
+        return gi, ga, gn, None
+
+
+def step_losses(img, actual, action, consts: StepConstants):
+    """→ (mse, dist, bound, alignment_loss, mae [B], angles [B,N], all_bounds [B,N], flag)."""
+    img, actual, action = img.contiguous(), actual.contiguous(), action.contiguous()
+    if torch.is_grad_enabled() and (img.requires_grad or actual.requires_grad or action.requires_grad):
+        return _StepLosses.apply(img, actual, action, consts)
+    out, mae, align, allb = _field._get_ops().step_losses_fwd(img, actual, action, consts)
+    return out[0], out[1], out[2], out[3], mae, align, allb, out[4]

@@ -21,7 +21,7 @@ MOMENT_STRIDE = 5
 EXPORTS = (
     "helio_abi_version", "helio_last_error_string", "helio_device_arch", "helio_geometry_fwd",
     "helio_splat_fwd", "helio_render_fwd", "helio_render_fwd_launches", "helio_splat_bwd_blocks", "helio_splat_bwd", "helio_geometry_bwd",
-    "helio_ideal_normals",
+    "helio_ideal_normals", "helio_step_losses_workspace", "helio_step_losses_fwd", "helio_step_losses_bwd",
 )
 
 
@@ -33,6 +33,7 @@ class Plane(ctypes.Structure):
 
 
 _vp, _i, _l = ctypes.c_void_p, ctypes.c_int, ctypes.c_long
+_f, _f3 = ctypes.c_float, ctypes.c_float * 3
 _lib = None
 
 
@@ -59,6 +60,9 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
         "helio_splat_bwd": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
         "helio_geometry_bwd": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _l, pp, _vp, _vp, _vp, _vp, _vp]),
         "helio_ideal_normals": (_i, [_i, _i, _vp, _vp, ctypes.c_float * 3, _vp, _vp]),
+        "helio_step_losses_workspace": (_l, [_i, _i, _i]),
+        "helio_step_losses_fwd": (_i, [_i, _i, _i] + [_vp] * 8 + [_f3, _f3, _f, _f, _i] + [_vp] * 5 + [_vp]),
+        "helio_step_losses_bwd": (_i, [_i, _i, _i] + [_vp] * 8 + [_f3, _f3, _f, _f, _i] + [_vp] * 4 + [_vp] * 3 + [_vp]),
     }
     for name, (res, args) in protos.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
@@ -171,6 +175,39 @@ class HipOps:
         _check(self.lib, self.lib.helio_ideal_normals(
             B, N, _dev(helios), _dev(sun), (ctypes.c_float * 3)(*target_xyz), out.data_ptr(), _stream()))
         return out
+
+
+    # -- HelioEnv.step loss block --------------------------------------------------------------
+    def step_losses_fwd(self, img, actual, action, c):
+        """``c``: the env's per-sun constants (target, tx, dmaps, ideal, helios, tp, tn, W, H, exp_risk).
+        Returns out[5] = (mse, dist, bound, alignment_loss, nonfinite flag), mae [B],
+        alignment errors [B,N] (mrad), boundary terms [B,N]."""
+        B, N, R = action.shape[0], action.shape[1], img.shape[-1]
+        dev = img.device
+        ws = torch.empty(self.lib.helio_step_losses_workspace(B, N, R), dtype=torch.float32, device=dev)
+        out = torch.empty(5, dtype=torch.float32, device=dev)
+        mae = torch.empty(B, dtype=torch.float32, device=dev)
+        align = torch.empty((B, N), dtype=torch.float32, device=dev)
+        allb = torch.empty((B, N), dtype=torch.float32, device=dev)
+        _check(self.lib, self.lib.helio_step_losses_fwd(
+            B, N, R, _dev(img), _dev(c.target), _dev(c.tx), _dev(c.dmaps), _dev(c.ideal), _dev(actual),
+            _dev(action), _dev(c.helios), c.tp, c.tn, c.W, c.H, int(c.exp_risk),
+            ws.data_ptr(), out.data_ptr(), mae.data_ptr(), align.data_ptr(), allb.data_ptr(), _stream()))
+        return out, mae, align, allb
+
+    def step_losses_bwd(self, img, actual, action, c, g_mse, g_dist, g_bound, g_align, want_img, want_actual,
+                        want_action):
+        B, N, R = action.shape[0], action.shape[1], img.shape[-1]
+        grad_img = torch.empty_like(img) if want_img else None
+        grad_actual = torch.empty_like(actual) if want_actual else None
+        grad_action = torch.empty_like(action) if want_action else None
+        ptr = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
+        _check(self.lib, self.lib.helio_step_losses_bwd(
+            B, N, R, _dev(img), _dev(c.target), _dev(c.tx), _dev(c.dmaps), _dev(c.ideal), _dev(actual),
+            _dev(action), _dev(c.helios), c.tp, c.tn, c.W, c.H, int(c.exp_risk),
+            ptr(g_mse), ptr(g_dist), ptr(g_bound), ptr(g_align), ptr(grad_img), ptr(grad_actual),
+            ptr(grad_action), _stream()))
+        return grad_img, grad_actual, grad_action
 
 
 _ops = None

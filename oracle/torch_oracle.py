@@ -198,3 +198,52 @@ def ideal_normals(helios: torch.Tensor, target_position: torch.Tensor, sun) -> t
     s = (to_sun / to_sun.norm(dim=2, keepdim=True).clamp_min(_TINY)
          + to_tgt / to_tgt.norm(dim=2, keepdim=True).clamp_min(_TINY))
     return s / s.norm(dim=2, keepdim=True).clamp_min(_TINY)
+
+
+# ------------------------------------------------------------------------------------------
+# HelioEnv.step loss block (reference: test_environment.py) — oracle for the fused HIP losses
+# ------------------------------------------------------------------------------------------
+def angles_mrad(v1: torch.Tensor, v2: torch.Tensor, epsilon: float = 1e-10) -> torch.Tensor:
+    """calculate_angles_mrad, test_environment.py:132-155."""
+    cosang = torch.sum(v1 * v2, dim=-1)
+    one = torch.tensor(1.0, dtype=cosang.dtype)
+    upper = torch.nextafter(one, torch.tensor(0.0, dtype=cosang.dtype))
+    return torch.acos(torch.clamp(cosang, min=(-upper).item() + epsilon, max=upper.item() - epsilon)) * 1000
+
+
+def boundary_all(vects, heliostat_pos, targ_pos, targ_norm, targ_area):
+    """boundary(..., return_all=True), test_environment.py:101-130, with the axes step() passes
+    (:461-462): east (1,0,0), up (0,0,1)."""
+    u = torch.tensor([1.0, 0.0, 0.0])
+    v = torch.tensor([0.0, 0.0, 1.0])
+    tol = 0.75
+    dots = torch.einsum('bij,j->bi', -vects, targ_norm)
+    valid = dots.abs() > 1e-6
+    t = torch.einsum('j,bij->bi', targ_pos, vects) / (dots + (~valid).float() * 1e-6)
+    inter = heliostat_pos.unsqueeze(0) + vects * t.unsqueeze(2)
+    local = inter - targ_pos
+    xl = torch.einsum('bij,j->bi', local, u)
+    yl = torch.einsum('bij,j->bi', local, v)
+    hw, hh = (targ_area[0] * tol) / 2, (targ_area[1] * tol) / 2
+    dx = torch.relu(xl.abs() - hw * tol)
+    dy = torch.relu(yl.abs() - hh * tol)
+    dist = torch.sqrt(dx * dx + dy * dy + 1e-8)
+    inside = (xl.abs() <= hw) & (yl.abs() <= hh) & valid
+    return dist * (~inside).float()
+
+
+def step_losses(img, target, distance_maps, ideal, actual, action, heliostat_pos, targ_pos, targ_norm,
+                targ_area, exponential_risk: bool = False):
+    """The use_error_mask=False branch of HelioEnv.step, test_environment.py:436-488.
+    Returns (mse, dist, bound, alignment_loss, mae_image [B], all_bounds [B,N], angles [B,N])."""
+    tx = target.amax((1, 2), keepdim=True).clamp_min(1e-6)
+    pred_n, targ_n = img / tx, target / tx
+    err = (pred_n - targ_n).abs()
+    mae = err.mean(dim=[-2, -1])
+    ang = angles_mrad(ideal, actual)
+    mse = torch.nn.functional.mse_loss(pred_n, targ_n)
+    dist_l = (err * distance_maps).sum((1, 2)).mean()
+    normals = action.view(img.shape[0], -1, 3)
+    allb = boundary_all(normals, heliostat_pos, targ_pos, targ_norm, targ_area)
+    bound = torch.mean(torch.exp(allb + 1e-6)) if exponential_risk else allb.mean()
+    return mse, dist_l, bound, torch.mean(ang), mae, allb, ang

@@ -97,6 +97,29 @@ class OracleOps:
         (gn,) = torch.autograd.grad(outs, n, cots)
         return gn
 
+    # -- HelioEnv.step loss block: the oracle's restatement plus torch autograd ---------------
+    @staticmethod
+    def _losses(img, actual, action, c):
+        return to.step_losses(img, c.target, c.dmaps, c.ideal, actual, action, c.helios,
+                              torch.tensor(list(c.tp)), torch.tensor(list(c.tn)), (c.W, c.H), c.exp_risk)
+
+    def step_losses_fwd(self, img, actual, action, c):
+        with torch.no_grad():
+            mse, dist, bound, align, mae, allb, ang = self._losses(img, actual, action, c)
+        bad = ~torch.isfinite(torch.stack([mse, dist, bound])).all()
+        return torch.stack([mse, dist, bound, align, bad.float()]), mae, ang, allb
+
+    def step_losses_bwd(self, img, actual, action, c, g_mse, g_dist, g_bound, g_align, want_img, want_actual,
+                        want_action):
+        with torch.enable_grad():
+            i, a, n = (t.detach().clone().requires_grad_(True) for t in (img, actual, action))
+            outs = self._losses(i, a, n, c)[:4]
+            total = sum(o * g for o, g in zip(outs, (g_mse, g_dist, g_bound, g_align)) if g is not None)
+            gi, ga, gn = torch.autograd.grad(total, (i, a, n), allow_unused=True)
+        z = lambda g, like: torch.zeros_like(like) if g is None else g  # noqa: E731
+        return (z(gi, img) if want_img else None, z(ga, actual) if want_actual else None,
+                z(gn, action) if want_action else None)
+
     def ideal_normals(self, helios, sun, target_xyz):
         return to.ideal_normals(helios, torch.tensor(list(target_xyz)), sun)
 

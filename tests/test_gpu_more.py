@@ -238,3 +238,47 @@ def test_rccl_gather_single_rank_process_group():
         sr.gather.close()
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("B,N,R,exp_risk", [(3, 7, 33, False), (25, 50, 128, False), (5, 300, 64, True), (2, 1, 1, False)])
+def test_fused_step_losses_against_oracle(B, N, R, exp_risk):
+    """helio_step_losses_fwd/bwd vs the oracle's restatement of the reference's loss block
+    (oracle/torch_oracle.step_losses, itself bit-exact with the reference env on CPU)."""
+    import ctypes
+    from doodle_amd.losses import StepConstants, step_losses
+    g = torch.Generator().manual_seed(B * 1000 + N + R)
+    rnd = lambda *s: torch.rand(*s, generator=g)  # noqa: E731
+    unit = lambda t: t / t.norm(dim=-1, keepdim=True)  # noqa: E731
+    img, target = rnd(B, R, R) * 3, rnd(B, R, R) * 3
+    dmaps = rnd(B, R, R) * 40
+    ideal = unit(rnd(B, N, 3) - 0.3)
+    actual = unit(ideal + 0.05 * (rnd(B, N, 3) - 0.5))
+    action = unit(ideal + 0.2 * (rnd(B, N, 3) - 0.5))
+    helios = rnd(N, 3) * 10 + 80
+    tp, tn = torch.tensor([0.0, -5.0, 0.0]), torch.tensor([0.0, 1.0, 0.0])
+    # oracle (CPU)
+    ci, ca, cn = (t.clone().requires_grad_(True) for t in (img, actual, action))
+    ref = to.step_losses(ci, target, dmaps, ideal, ca, cn, helios, tp, tn, (15.0, 12.0), exp_risk)
+    w = [0.7, 1.3, -0.4, 2.1]
+    gi_o, ga_o, gn_o = torch.autograd.grad(sum(wi * r for wi, r in zip(w, ref[:4])), (ci, ca, cn))
+    # HIP
+    f3 = ctypes.c_float * 3
+    c = StepConstants(target.to(DEV), target.amax((1, 2)).clamp_min(1e-6).to(DEV), dmaps.to(DEV), ideal.to(DEV),
+                      helios.to(DEV), f3(*tp.tolist()), f3(*tn.tolist()), 15.0, 12.0, exp_risk)
+    di, da, dn = (t.to(DEV).requires_grad_(True) for t in (img, actual, action))
+    out = step_losses(di, da, dn, c)
+    for k in range(4):
+        np.testing.assert_allclose(out[k].item(), ref[k].item(), rtol=2e-5, atol=1e-7)
+    np.testing.assert_allclose(out[4].cpu().numpy(), ref[4].detach().numpy(), rtol=2e-5, atol=1e-7)      # mae
+    np.testing.assert_allclose(out[5].cpu().numpy(), ref[6].detach().numpy(), rtol=1e-4, atol=3e-2)      # angles (acos)
+    np.testing.assert_allclose(out[6].cpu().numpy(), ref[5].detach().numpy(), rtol=1e-5, atol=1e-5)      # bounds
+    # the flag restates the reference's NaN/Inf asserts (exp() of a large boundary term overflows)
+    assert out[7].item() == float(not all(torch.isfinite(r).item() for r in ref[:3]))
+    gi, ga, gn = torch.autograd.grad(sum(wi * o for wi, o in zip(w, out[:4])), (di, da, dn))
+    for got, want, tol in ((gi, gi_o, 1e-4), (ga, ga_o, 3e-2), (gn, gn_o, 1e-4)):
+        scale = max(want.abs().max().item(), 1e-30)
+        assert (got.cpu() - want).abs().max().item() <= tol * scale
+    # a NaN in the image raises the flag
+    bad = img.clone()
+    bad[0, 0, 0] = float("nan")
+    assert step_losses(bad.to(DEV), da.detach(), dn.detach(), c)[7].item() == 1.0

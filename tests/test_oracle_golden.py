@@ -122,3 +122,34 @@ def test_tiny_scene_properties():
     par = golden("g4_parallel_n2_b2_r16")
     assert par["mask"].reshape(2, 2)[0, 0] == 0.0               # the plane-parallel ray
     assert par["image"][0].min() >= 1.0                         # contributes 1.0 everywhere
+
+
+import pytest as _pytest
+
+
+@_pytest.mark.parametrize("tag", ["train", "readme"])
+def test_step_loss_oracle_matches_reference_env(tag):
+    """oracle.step_losses on the reference's recorded step() inputs reproduces its metrics,
+    monitors and gradients bit for bit (same ATen ops in the same order)."""
+    g = golden(f"g6_env_{tag}_n50_b25_r64")
+    helios = torch.from_numpy(g["helios"])
+    tp, tn = torch.tensor([0.0, -5.0, 0.0]), torch.tensor([0.0, 1.0, 0.0])
+    sc = to.Scene.build(helios, tp, (15.0, 15.0), tn, 64, float(g["sigma_scale"]))
+    suns = torch.from_numpy(g["suns"])
+    act = torch.from_numpy(g["action"]).clone().requires_grad_(True)
+    errs = torch.from_numpy(g["batch_error_angles_mrad"])
+    ideal = to.ideal_normals(helios, tp, suns)
+    img, actual = to.render(sc, suns, act, errs)
+    with torch.no_grad():
+        target, _ = to.render(sc, suns, ideal.flatten(1), torch.zeros_like(errs))
+    out = to.step_losses(img, target, torch.from_numpy(g["distance_maps"]), ideal, actual, act, helios, tp, tn,
+                         (15.0, 15.0))
+    names = ("mse", "dist", "bound", "alignment_loss")
+    for k, v in zip(names, out[:4]):
+        assert np.array_equal(v.detach().numpy(), g["metric_" + k]), k
+        (ga,) = torch.autograd.grad(v, act, retain_graph=True, allow_unused=True)
+        got = ga.numpy() if ga is not None else np.zeros_like(g["grad_" + k])
+        assert np.array_equal(got, g["grad_" + k]), k
+    assert np.array_equal(out[4].detach().numpy().reshape(-1, 1), g["monitor_mae_image"])
+    assert np.array_equal(out[5].detach().numpy(), g["monitor_all_bounds"])
+    assert np.array_equal(out[6].detach().numpy().reshape(-1), g["monitor_alignment_errors"])
