@@ -254,17 +254,21 @@ def test_fused_step_losses_against_oracle(B, N, R, exp_risk):
     ideal = unit(rnd(B, N, 3) - 0.3)
     actual = unit(ideal + 0.05 * (rnd(B, N, 3) - 0.5))
     action = unit(ideal + 0.2 * (rnd(B, N, 3) - 0.5))
-    helios = rnd(N, 3) * 10 + 80
-    tp, tn = torch.tensor([0.0, -5.0, 0.0]), torch.tensor([0.0, 1.0, 0.0])
+    # exponential risk: keep the boundary terms O(1) so that exp() stays finite (a scene in
+    # metres overflows it — the reference then trips its own Inf assert)
+    helios = rnd(N, 3) * 2 if exp_risk else rnd(N, 3) * 10 + 80
+    tp = torch.tensor([0.0, -0.5, 0.0]) if exp_risk else torch.tensor([0.0, -5.0, 0.0])
+    tn = torch.tensor([0.0, 1.0, 0.0])
+    area = (1.5, 1.2) if exp_risk else (15.0, 12.0)
     # oracle (CPU)
     ci, ca, cn = (t.clone().requires_grad_(True) for t in (img, actual, action))
-    ref = to.step_losses(ci, target, dmaps, ideal, ca, cn, helios, tp, tn, (15.0, 12.0), exp_risk)
+    ref = to.step_losses(ci, target, dmaps, ideal, ca, cn, helios, tp, tn, area, exp_risk)
     w = [0.7, 1.3, -0.4, 2.1]
     gi_o, ga_o, gn_o = torch.autograd.grad(sum(wi * r for wi, r in zip(w, ref[:4])), (ci, ca, cn))
     # HIP
     f3 = ctypes.c_float * 3
     c = StepConstants(target.to(DEV), target.amax((1, 2)).clamp_min(1e-6).to(DEV), dmaps.to(DEV), ideal.to(DEV),
-                      helios.to(DEV), f3(*tp.tolist()), f3(*tn.tolist()), 15.0, 12.0, exp_risk)
+                      helios.to(DEV), f3(*tp.tolist()), f3(*tn.tolist()), area[0], area[1], exp_risk)
     di, da, dn = (t.to(DEV).requires_grad_(True) for t in (img, actual, action))
     out = step_losses(di, da, dn, c)
     for k in range(4):
