@@ -19,6 +19,7 @@ int launch_splat_fwd(int, int, int, const float*, const float*, const float*, fl
 int launch_splat_bwd(int, int, int, const float*, const float*, const float*, const float*, float*, int, hipStream_t);
 int splat_bwd_blocks(int);
 bool render_is_fused(int, int, int);
+void launch_distance_maps(int, int, const float*, float, int*, float*, int*, float*, hipStream_t);
 int step_losses_chunks(int);
 int step_losses_ray_wgs(int, int);
 void launch_step_losses_fwd(int, int, int, const float*, const float*, const float*, const float*, const float*,
@@ -156,6 +157,21 @@ int helio_ideal_normals(int B, int N, const float* helios_d, const float* sun_d,
     if (!helios_d || !sun_d || !target_position || !out_d) return fail(HELIO_E_INVALID, "ideal_normals: null pointer");
     helio::launch_ideal_normals(B, N, helios_d, sun_d, target_position, out_d, static_cast<hipStream_t>(stream));
     return after_launch("ideal_normals");
+}
+
+long helio_distance_maps_workspace(int B, int R) {
+    if (B < 1 || R < 1 || R > 16384) return 0;
+    return (long)B * R * R + 2l * B;                 // int g[B,R,R], float max[B], int any_hot[B]
+}
+
+int helio_distance_maps(int B, int R, const float* img_d, float thr, void* workspace_d, float* out_d, void* stream) {
+    if (B < 1 || B > 65535 || R < 1 || R > 16384) return fail(HELIO_E_INVALID, "distance_maps: bad sizes B=%d R=%d", B, R);
+    if (!img_d || !workspace_d || !out_d) return fail(HELIO_E_INVALID, "distance_maps: null pointer");
+    int* g = static_cast<int*>(workspace_d);
+    float* mx = reinterpret_cast<float*>(g + (long)B * R * R);
+    int* any_hot = reinterpret_cast<int*>(mx + B);
+    helio::launch_distance_maps(B, R, img_d, thr, g, mx, any_hot, out_d, static_cast<hipStream_t>(stream));
+    return after_launch("distance_maps");
 }
 
 long helio_step_losses_workspace(int B, int N, int R) {

@@ -82,7 +82,11 @@ def sample_cone_directions(n: int, axis: torch.Tensor, half_angle_deg: float, de
 
 def make_distance_maps(imgs: torch.Tensor, thr: float = 0.5) -> torch.Tensor:
     """Euclidean distance to the region above ``thr``·max of each image (:92-97).
-    Host round trip through scipy, as in the reference; runs only in set_sun_pos."""
+    On a HIP device: the exact device EDT of csrc/edt.hip (no host round trip).  For CPU
+    tensors: scipy, as in the reference."""
+    if imgs.is_cuda:
+        from . import field as _field
+        return _field._get_ops().distance_maps(imgs.detach().to(torch.float32), float(thr))
     from scipy.ndimage import distance_transform_edt
     maps = []
     for img in imgs.detach().cpu().numpy():

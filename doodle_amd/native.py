@@ -22,6 +22,7 @@ EXPORTS = (
     "helio_abi_version", "helio_last_error_string", "helio_device_arch", "helio_geometry_fwd",
     "helio_splat_fwd", "helio_render_fwd", "helio_render_fwd_launches", "helio_splat_bwd_blocks", "helio_splat_bwd", "helio_geometry_bwd",
     "helio_ideal_normals", "helio_step_losses_workspace", "helio_step_losses_fwd", "helio_step_losses_bwd",
+    "helio_distance_maps_workspace", "helio_distance_maps",
 )
 
 
@@ -60,6 +61,8 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
         "helio_splat_bwd": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
         "helio_geometry_bwd": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _l, pp, _vp, _vp, _vp, _vp, _vp]),
         "helio_ideal_normals": (_i, [_i, _i, _vp, _vp, ctypes.c_float * 3, _vp, _vp]),
+        "helio_distance_maps_workspace": (_l, [_i, _i]),
+        "helio_distance_maps": (_i, [_i, _i, _vp, _f, _vp, _vp, _vp]),
         "helio_step_losses_workspace": (_l, [_i, _i, _i]),
         "helio_step_losses_fwd": (_i, [_i, _i, _i] + [_vp] * 8 + [_f3, _f3, _f, _f, _i] + [_vp] * 5 + [_vp]),
         "helio_step_losses_bwd": (_i, [_i, _i, _i] + [_vp] * 8 + [_f3, _f3, _f, _f, _i] + [_vp] * 4 + [_vp] * 3 + [_vp]),
@@ -176,6 +179,15 @@ class HipOps:
             B, N, _dev(helios), _dev(sun), (ctypes.c_float * 3)(*target_xyz), out.data_ptr(), _stream()))
         return out
 
+
+    # -- distance maps -----------------------------------------------------------------------
+    def distance_maps(self, imgs, thr=0.5):
+        B, R = imgs.shape[0], imgs.shape[-1]
+        imgs = imgs.contiguous()
+        ws = torch.empty(self.lib.helio_distance_maps_workspace(B, R), dtype=torch.int32, device=imgs.device)
+        out = torch.empty_like(imgs)
+        _check(self.lib, self.lib.helio_distance_maps(B, R, _dev(imgs), thr, ws.data_ptr(), out.data_ptr(), _stream()))
+        return out
 
     # -- HelioEnv.step loss block --------------------------------------------------------------
     def step_losses_fwd(self, img, actual, action, c):

@@ -170,6 +170,15 @@ int helio_ideal_normals(int B, int N, const float *helios_d, const float *sun_d,
  *   mae_d [B] (monitor 'mae_image'), align_err_d [B,N] (mrad), all_bounds_d [B,N]
  */
 long helio_step_losses_workspace(int B, int N, int R);
+
+/*
+ * Replaces make_distance_maps, test_environment.py:92-97 (host round trip through scipy's
+ * distance_transform_edt): out_d[b,i,j] = Euclidean pixel distance to the nearest pixel of
+ * image b above thr·max(image b); exact (integer squared distances, fp64 sqrt).
+ * workspace_d: helio_distance_maps_workspace(B,R) 4-byte words.
+ */
+long helio_distance_maps_workspace(int B, int R);
+int helio_distance_maps(int B, int R, const float *img_d, float thr, void *workspace_d, float *out_d, void *stream);
 int helio_step_losses_fwd(int B, int N, int R,
                           const float *img_d, const float *target_d, const float *tx_d, const float *dmaps_d,
                           const float *ideal_d, const float *actual_d, const float *action_d,

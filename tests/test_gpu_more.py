@@ -286,3 +286,19 @@ def test_fused_step_losses_against_oracle(B, N, R, exp_risk):
     bad = img.clone()
     bad[0, 0, 0] = float("nan")
     assert step_losses(bad.to(DEV), da.detach(), dn.detach(), c)[7].item() == 1.0
+
+
+@pytest.mark.parametrize("B,R", [(3, 17), (25, 128), (2, 300), (1, 1)])
+def test_device_distance_maps_match_scipy(B, R):
+    """csrc/edt.hip vs the reference's scipy.ndimage.distance_transform_edt (:92-97): exact."""
+    from scipy.ndimage import distance_transform_edt
+    from doodle_amd.env import make_distance_maps
+    g = torch.Generator().manual_seed(B + R)
+    imgs = torch.rand(B, R, R, generator=g) ** 8            # few pixels above half the maximum
+    if B > 1:
+        imgs[1] = 0.0                                       # degenerate image: nothing above the threshold
+    if B > 2:
+        imgs[2, R // 3: R // 2, R // 4: R // 2] = 5.0       # a block of hot pixels
+    want = np.stack([distance_transform_edt(1 - (im > 0.5 * im.max()).astype(np.uint8)) for im in imgs.numpy()])
+    got = make_distance_maps(imgs.to(DEV)).cpu().numpy()
+    assert np.array_equal(got, want.astype(np.float32))
