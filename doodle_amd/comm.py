@@ -50,11 +50,19 @@ class ImageGather:
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.comm = None
         self.stream = None
-        if transport == "auto":
-            transport = "rccl" if (torch.cuda.is_available() and dist.is_initialized()
-                                   and dist.get_backend(group) == "nccl") else "torch"
+        auto = transport == "auto"
+        if auto:
+            transport = os.environ.get("HELIO_COMM") or (
+                "rccl" if (torch.cuda.is_available() and dist.is_initialized()
+                           and dist.get_backend(group) == "nccl") else "torch")
         if transport == "rccl":
-            self._init_rccl()
+            try:
+                self._init_rccl()
+            except (RuntimeError, OSError) as e:
+                if not auto:
+                    raise
+                import warnings
+                warnings.warn(f"libhelio_comm RCCL transport unavailable ({e}); using torch.distributed")
         self.transport = "rccl" if self.comm is not None else "torch"
 
     def _init_rccl(self):
