@@ -302,3 +302,32 @@ def test_device_distance_maps_match_scipy(B, R):
     want = np.stack([distance_transform_edt(1 - (im > 0.5 * im.max()).astype(np.uint8)) for im in imgs.numpy()])
     got = make_distance_maps(imgs.to(DEV)).cpu().numpy()
     assert np.array_equal(got, want.astype(np.float32))
+
+
+def test_test_time_compute_reduces_dist():
+    """The reference's fine_adjustment_sanity_check.py scenario (:123-162): optimising a small
+    correction of the normals through env.step's image loss ('dist': backward THROUGH the
+    Gaussian footprints) lowers it."""
+    from doodle_amd.env import HelioEnv
+    torch.manual_seed(3)
+    N, B = 4, 32
+    hp = torch.rand(N, 3, device=DEV) * 10 + 80
+    hp[:, 2] = 0
+    env = HelioEnv(hp, torch.tensor([0.0, -5.0, 0.0], device=DEV), (15.0, 15.0), torch.tensor([0.0, 1.0, 0.0], device=DEV),
+                   sigma_scale=0.02, error_scale_mrad=3.0, resolution=64, batch_size=B, device=DEV,
+                   new_errors_every_reset=False)
+    env.reset()
+    base = env.ideal_normals.clone()
+    delta = torch.zeros_like(base).requires_grad_(True)
+    opt = torch.optim.Adam([delta], lr=2e-4)
+    with torch.no_grad():
+        _, before, _ = env.step(torch.nn.functional.normalize(base + delta, dim=2).reshape(B, -1))
+    for _ in range(80):
+        opt.zero_grad()
+        _, losses, _ = env.step(torch.nn.functional.normalize(base + delta, dim=2).reshape(B, -1))
+        losses["dist"].backward()
+        opt.step()
+    with torch.no_grad():
+        _, after, _ = env.step(torch.nn.functional.normalize(base + delta, dim=2).reshape(B, -1))
+    assert after["dist"].item() < 0.7 * before["dist"].item(), (before["dist"].item(), after["dist"].item())
+    assert after["mse"].item() < before["mse"].item()
