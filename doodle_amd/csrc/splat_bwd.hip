@@ -288,6 +288,104 @@ splat_bwd_mfma(int B, int N, int R, const float* __restrict__ rays, const float*
     }
 }
 
+// Small problems: the same two contractions in ONE launch (blockIdx.z = pass) with 64 c × 64
+// rays per 4-wave workgroup (each wave one 32×32 MFMA block), so config 3 (B=25, N=50, R=128)
+// spreads over 100 workgroups instead of 25.  The grad-image slab of a 128-deep k-chunk sits in
+// LDS; the factor operand is computed in registers by the lane that owns (k, ray); the two
+// waves that share a ray block combine their 32-c halves through LDS before writing.
+template <int PASS>
+__device__ __forceinline__ void splat_bwd_small_body(int B, int N, int R, const float* __restrict__ rays,
+                                                     const float* __restrict__ xs, const float* __restrict__ ys,
+                                                     const float* __restrict__ gimg, float* __restrict__ moments,
+                                                     float* smem) {
+    constexpr int KC = 128, T = 64, LD = T + 1;
+    float* __restrict__ sG = smem;                 // [KC][LD]
+    float* __restrict__ sKc = smem + KC * LD;      // [KC]
+    float* __restrict__ sCc = sKc + KC;            // [T]
+    float* __restrict__ sRed = sCc + T;            // [2 ray blocks][32 rays][3]
+
+    const int c_tiles = (R + T - 1) / T;
+    const int b = blockIdx.y;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int c0 = (blockIdx.x % c_tiles) * T, n0 = (blockIdx.x / c_tiles) * T;
+    const int wc = (wave >> 1) * 32, wn = (wave & 1) * 32;
+    const float* __restrict__ ccoord = PASS == 0 ? ys : xs;
+    const float* __restrict__ kcoord = PASS == 0 ? xs : ys;
+    const float* __restrict__ G = gimg + (long)b * R * R;
+
+    if (tid < T) sCc[tid] = ccoord[min(c0 + tid, R - 1)];
+    const int n = n0 + wn + lr;                                    // this lane's ray (B operand and epilogue)
+    float4 q = make_float4(0.f, 0.f, 1.f, 1e30f);
+    if (n < N) q = reinterpret_cast<const float4*>(rays)[(long)b * N + n];
+    const float sk = __builtin_sqrtf(q.z);
+    const float fshift = (PASS == 0 ? q.x : q.y) * sk;
+    const float fcc = PASS == 0 ? q.w * q.z : 0.0f;
+
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+
+    for (int k0 = 0; k0 < R; k0 += KC) {
+        __syncthreads();
+        // slab Gm[k][c]: pass 0 → G[k0+k][c0+c] (lanes ↔ c), pass 1 → G[c0+c][k0+k] (lanes ↔ k)
+        for (int idx = tid; idx < KC * T; idx += 256) {
+            const int k = PASS == 0 ? idx >> 6 : idx & (KC - 1), c = PASS == 0 ? idx & 63 : idx >> 7;
+            const int row = PASS == 0 ? k0 + k : c0 + c, col = PASS == 0 ? c0 + c : k0 + k;
+            sG[k * LD + c] = (row < R && col < R) ? G[(long)row * R + col] : 0.0f;
+        }
+        if (tid < KC) sKc[tid] = kcoord[min(k0 + tid, R - 1)];
+        __syncthreads();
+        const int kmax = min(KC, R - k0);
+#pragma unroll 4
+        for (int kp = 0; 2 * kp < kmax; ++kp) {
+            const int k = 2 * kp + lh;
+            const float g = sG[k * LD + wc + lr];
+            const float t = __builtin_fmaf(sKc[k], sk, fshift);
+            float f = __builtin_amdgcn_exp2f(-__builtin_fmaf(t, t, fcc));
+            if (k >= kmax) f = 0.0f;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(g, f, acc, 0, 0, 0);
+        }
+    }
+
+    // epilogue: lane = ray (column lr), registers = 16 values of c
+    const float hshift = PASS == 0 ? q.y : q.x;
+    const float hcc = PASS == 0 ? 0.0f : q.w;
+    const float hk = n < N ? q.z : 0.0f;
+    float m0 = 0.f, m1 = 0.f, m2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int cl = wc + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        const float s = sCc[cl] + hshift;
+        const float w = __builtin_amdgcn_exp2f(-(__builtin_fmaf(s, s, hcc) * hk)) * acc[e];
+        m0 += w;
+        m1 = __builtin_fmaf(s, w, m1);
+        m2 = __builtin_fmaf(s * s, w, m2);
+    }
+    m0 += __shfl_xor(m0, 32); m1 += __shfl_xor(m1, 32); m2 += __shfl_xor(m2, 32);
+    __syncthreads();
+    if (wave >= 2 && lh == 0) {                                    // c half 1 hands over to c half 0
+        float* r = sRed + ((wave & 1) * 32 + lr) * 3;
+        r[0] = m0; r[1] = m1; r[2] = m2;
+    }
+    __syncthreads();
+    if (wave < 2 && lh == 0 && n < N) {
+        const float* r = sRed + ((wave & 1) * 32 + lr) * 3;
+        const int JB = (R + 63) / 64;
+        float* o = moments + (((long)b * JB + c0 / 64) * N + n) * HELIO_MOMENT_STRIDE;
+        if (PASS == 0) { o[0] = m0 + r[0]; o[2] = m1 + r[1]; o[4] = m2 + r[2]; }
+        else { o[1] = m1 + r[1]; o[3] = m2 + r[2]; }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+splat_bwd_mfma_small(int B, int N, int R, const float* __restrict__ rays, const float* __restrict__ xs,
+                     const float* __restrict__ ys, const float* __restrict__ gimg, float* __restrict__ moments) {
+    __shared__ float smem[128 * 65 + 128 + 64 + 192];
+    if (blockIdx.z == 0) splat_bwd_small_body<0>(B, N, R, rays, xs, ys, gimg, moments, smem);
+    else splat_bwd_small_body<1>(B, N, R, rays, xs, ys, gimg, moments, smem);
+}
+
 template <int PASS>
 static void launch_bwd_mfma(int B, int N, int R, const float* rays, const float* xs, const float* ys,
                             const float* gimg, float* moments, hipStream_t st) {
@@ -304,12 +402,17 @@ static void launch_bwd_mfma(int B, int N, int R, const float* rays, const float*
 
 int splat_bwd_blocks(int R) { return (R + BW_JT - 1) / BW_JT; }
 
-// variant: 0 = by problem size, 1 = VALU kernel, 2 = MFMA kernels
+// variant: 0 = by problem size, 1 = VALU kernel, 2 = MFMA kernels (256-tiles), 3 = MFMA small tiles
 int launch_splat_bwd(int B, int N, int R, const float* rays, const float* xs, const float* ys,
                      const float* gimg, float* moments, int variant, hipStream_t st) {
     if (variant == 0) {
         const long wgs = (long)B * ((R + 255) / 256) * ((N + 255) / 256);
-        variant = (R >= 128 && N >= 96 && wgs >= 128) ? 2 : 1;
+        variant = (R >= 128 && N >= 96 && wgs >= 128) ? 2 : 3;
+    }
+    if (variant == 3) {
+        const int ct = (R + 63) / 64, nt = (N + 63) / 64;
+        hipLaunchKernelGGL(splat_bwd_mfma_small, dim3(ct * nt, B, 2), dim3(256), 0, st, B, N, R, rays, xs, ys, gimg, moments);
+        return HELIO_OK;
     }
     if (variant == 2) {
         launch_bwd_mfma<0>(B, N, R, rays, xs, ys, gimg, moments, st);

@@ -125,7 +125,8 @@ int helio_splat_bwd_blocks(int R);
  * moments_d has shape [B, helio_splat_bwd_blocks(R), N, HELIO_MOMENT_STRIDE]; a block is
  * 64 image columns for (M0, Ms, Mss) and — in the MFMA kernels — 64 image rows for (Mt, Mtt);
  * only the sum over blocks is meaningful.
- * variant: 0 = by problem size, 1 = VALU kernel, 2 = f32 MFMA kernels.
+ * variant: 0 = by problem size, 1 = VALU kernel, 2 = f32 MFMA kernels (256-wide tiles, two
+ * launches), 3 = f32 MFMA small-tile kernel (both passes in one launch).
  */
 int helio_splat_bwd(int B, int N, int R,
                     const float *rays_d, const float *xs_d, const float *ys_d,

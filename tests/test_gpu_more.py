@@ -49,7 +49,7 @@ def test_odd_sizes_against_oracle(N, B, R, normal):
         assert np.array_equal(refl.detach().cpu().numpy(), refl_o.detach().numpy())
         np.testing.assert_allclose(img.detach().cpu().numpy(), img_o.detach().numpy(), rtol=1e-5, atol=1e-8)
     scale = grad_o.abs().max().item()
-    for bwd_variant in (1, 2):
+    for bwd_variant in (1, 2, 3):
         native.get_ops().bwd_variant = bwd_variant
         try:
             (grad,) = torch.autograd.grad((img * G.to(DEV)).sum() + (actual * H.to(DEV)).sum(), a_dev, retain_graph=True)

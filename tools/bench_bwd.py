@@ -32,6 +32,9 @@ def main():
     m2 = ops.splat_bwd(rays, f._xs, f._ys, G, variant=2).sum(1)
     print("   moments valu vs mfma: max|d|/max =", [(m1[..., k] - m2[..., k]).abs().max().item() / m1[..., k].abs().max().item() for k in range(5)])
     print(f"   splat_bwd mfma {t_sm*1e6:9.1f} us ({2*2.0*B*w.N*w.R*w.R/t_sm/1e12:6.1f} TF of 2 FMA/eval)")
+    t_s3 = time_kernel(lambda: ops.splat_bwd(rays, f._xs, f._ys, G, variant=3), iters)
+    m3 = ops.splat_bwd(rays, f._xs, f._ys, G, variant=3).sum(1)
+    print(f"   splat_bwd mfma-small {t_s3*1e6:9.1f} us; vs valu max|d|/max =", max((m1[..., k] - m3[..., k]).abs().max().item() / m1[..., k].abs().max().item() for k in range(5)))
     mom = ops.splat_bwd(rays, f._xs, f._ys, G)
     t_gb = time_kernel(lambda: ops.geometry_bwd(f.heliostat_positions, suns_d, normals, trig, stride, f._plane, mom, H, None), iters)
     fl = 2.0 * B * w.N * w.R * w.R
