@@ -151,6 +151,29 @@ int helio_geometry_bwd(int B, int N, int n_blocks, const float* helios_d, const 
     return after_launch("geometry_bwd");
 }
 
+int helio_render_bwd(int B, int N, int R, const float* helios_d, const float* sun_d, const float* action_d,
+                     const float* trig_d, long trig_b_stride, const helio_plane* plane, const float* rays_d,
+                     const float* xs_d, const float* ys_d, const float* grad_image_d, const float* grad_actual_d,
+                     const float* grad_refl_d, float* moments_d, float* grad_action_d, int variant, void* stream) {
+    if (!sizes_ok(B, N) || R < 1 || R > 16384) return fail(HELIO_E_INVALID, "render_bwd: bad sizes B=%d N=%d R=%d", B, N, R);
+    if (!helios_d || !sun_d || !action_d || !trig_d || !plane || !grad_action_d)
+        return fail(HELIO_E_INVALID, "render_bwd: null pointer");
+    if (trig_b_stride != 0 && trig_b_stride != 4l * N)
+        return fail(HELIO_E_INVALID, "render_bwd: trig_b_stride must be 0 or 4*N");
+    if (!aligned16(trig_d)) return fail(HELIO_E_INVALID, "render_bwd: trig must be 16-byte aligned");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (grad_image_d) {
+        if (!rays_d || !xs_d || !ys_d || !moments_d) return fail(HELIO_E_INVALID, "render_bwd: null pointer");
+        if (!aligned16(rays_d) || !aligned16(grad_image_d))
+            return fail(HELIO_E_INVALID, "render_bwd: rays/grad_image must be 16-byte aligned");
+        if (helio::launch_splat_bwd(B, N, R, rays_d, xs_d, ys_d, grad_image_d, moments_d, variant, st) != HELIO_OK)
+            return fail(HELIO_E_INVALID, "render_bwd: unknown variant %d", variant);
+    }
+    helio::launch_geometry_bwd(B, N, helio::splat_bwd_blocks(R), helios_d, sun_d, action_d, trig_d, trig_b_stride,
+                               plane, grad_image_d ? moments_d : nullptr, grad_actual_d, grad_refl_d, grad_action_d, st);
+    return after_launch("render_bwd");
+}
+
 int helio_ideal_normals(int B, int N, const float* helios_d, const float* sun_d,
                         const float target_position[3], float* out_d, void* stream) {
     if (!sizes_ok(B, N)) return fail(HELIO_E_INVALID, "ideal_normals: bad sizes B=%d N=%d", B, N);

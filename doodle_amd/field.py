@@ -31,19 +31,18 @@ class _Render(torch.autograd.Function):
             field.heliostat_positions, sun, normals, trig, trig_stride, field._plane, field._xs, field._ys)
         ctx.field, ctx.trig_stride = field, trig_stride
         ctx.save_for_backward(normals, sun, trig, rays)
+        ctx.set_materialize_grads(False)          # unused outputs arrive as None, not as zero tensors
         return image, actual, refl
 
     @staticmethod
     def backward(ctx, g_image, g_actual, g_refl):
         normals, sun, trig, rays = ctx.saved_tensors
-        field, ops = ctx.field, _get_ops()
-        moments = None
-        if g_image is not None:
-            moments = ops.splat_bwd(rays, field._xs, field._ys, g_image.contiguous())
-        g = ops.geometry_bwd(field.heliostat_positions, sun, normals, trig, ctx.trig_stride, field._plane,
-                             moments,
-                             g_actual.contiguous() if g_actual is not None else None,
-                             g_refl.contiguous() if g_refl is not None else None)
+        field = ctx.field
+        if g_image is None and g_actual is None and g_refl is None:
+            return None, None, None, None, None
+        c = lambda g: g.contiguous() if g is not None else None  # noqa: E731
+        g = _get_ops().render_bwd(field.heliostat_positions, sun, normals, trig, ctx.trig_stride, field._plane,
+                                  rays, field._xs, field._ys, c(g_image), c(g_actual), c(g_refl))
         return g, None, None, None, None
 
 

@@ -20,7 +20,7 @@ MOMENT_STRIDE = 5
 
 EXPORTS = (
     "helio_abi_version", "helio_last_error_string", "helio_device_arch", "helio_geometry_fwd",
-    "helio_splat_fwd", "helio_render_fwd", "helio_render_fwd_launches", "helio_splat_bwd_blocks", "helio_splat_bwd", "helio_geometry_bwd",
+    "helio_splat_fwd", "helio_render_fwd", "helio_render_bwd", "helio_render_fwd_launches", "helio_splat_bwd_blocks", "helio_splat_bwd", "helio_geometry_bwd",
     "helio_ideal_normals", "helio_step_losses_workspace", "helio_step_losses_fwd", "helio_step_losses_bwd",
     "helio_distance_maps_workspace", "helio_distance_maps",
 )
@@ -56,6 +56,7 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
         "helio_geometry_fwd": (_i, [_i, _i, _vp, _vp, _vp, _vp, _l, pp, _vp, _vp, _vp, _vp]),
         "helio_splat_fwd": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp]),
         "helio_render_fwd": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _l, pp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+        "helio_render_bwd": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _l, pp] + [_vp] * 8 + [_i, _vp]),
         "helio_render_fwd_launches": (_i, [_i, _i, _i]),
         "helio_splat_bwd_blocks": (_i, [_i]),
         "helio_splat_bwd": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
@@ -158,6 +159,22 @@ class HipOps:
             B, N, R, _dev(rays), _dev(xs), _dev(ys), _dev(grad_image), moments.data_ptr(),
             self.bwd_variant if variant is None else variant, _stream()))
         return moments
+
+    def render_bwd(self, helios, sun, normals, trig, trig_b_stride, plane, rays, xs, ys, grad_image, grad_actual,
+                   grad_refl):
+        """splat backward + geometry backward in ONE C call; any cotangent may be None."""
+        B, N, R = normals.shape[0], normals.shape[1], xs.shape[0]
+        grad = torch.empty_like(normals)
+        moments = None
+        if grad_image is not None:
+            moments = torch.empty((B, self.lib.helio_splat_bwd_blocks(R), N, MOMENT_STRIDE), dtype=torch.float32,
+                                  device=normals.device)
+        ptr = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
+        _check(self.lib, self.lib.helio_render_bwd(
+            B, N, R, _dev(helios), _dev(sun), _dev(normals), _dev(trig), trig_b_stride, plane, _dev(rays),
+            _dev(xs), _dev(ys), ptr(grad_image), ptr(grad_actual), ptr(grad_refl), ptr(moments), grad.data_ptr(),
+            self.bwd_variant, _stream()))
+        return grad
 
     def geometry_bwd(self, helios, sun, normals, trig, trig_b_stride, plane, moments, grad_actual, grad_refl):
         B, N = normals.shape[0], normals.shape[1]

@@ -149,6 +149,18 @@ int helio_geometry_bwd(int B, int N, int n_blocks,
                        float *grad_action_d, void *stream);
 
 /*
+ * The whole backward of HelioField.render in one call: helio_splat_bwd (skipped when
+ * grad_image_d is NULL) followed by helio_geometry_bwd on the same stream.  moments_d is the
+ * [B, helio_splat_bwd_blocks(R), N, 5] work buffer; any cotangent may be NULL.
+ */
+int helio_render_bwd(int B, int N, int R,
+                     const float *helios_d, const float *sun_d, const float *action_d,
+                     const float *trig_d, long trig_b_stride, const helio_plane *plane,
+                     const float *rays_d, const float *xs_d, const float *ys_d,
+                     const float *grad_image_d, const float *grad_actual_d, const float *grad_refl_d,
+                     float *moments_d, float *grad_action_d, int variant, void *stream);
+
+/*
  * Replaces calculate_ideal_normals, :256-278:
  *   out[b,n,:] = unit( unit(sun_b - h_n) + unit(target - h_n) ), bit-identical
  *   with the reference's CPU fp32 result.

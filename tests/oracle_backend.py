@@ -74,6 +74,11 @@ class OracleOps:
         m = torch.stack([U(A, E), U(t * A, E), U(A, s * E), U(t * t * A, E), U(A, s * s * E)], dim=-1)
         return m.float().unsqueeze(1).contiguous()       # one column block
 
+    def render_bwd(self, helios, sun, normals, trig, trig_b_stride, plane, rays, xs, ys, grad_image, grad_actual,
+                   grad_refl):
+        moments = self.splat_bwd(rays, xs, ys, grad_image) if grad_image is not None else None
+        return self.geometry_bwd(helios, sun, normals, trig, trig_b_stride, plane, moments, grad_actual, grad_refl)
+
     def geometry_bwd(self, helios, sun, normals, trig, trig_b_stride, plane, moments, grad_actual, grad_refl):
         with torch.enable_grad():     # called from inside an autograd backward
             n = normals.detach().clone().requires_grad_(True)
