@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""The reference's TTT sweep shape (run_experiments.py:31-56): batch_size=500, num_heliostats=1."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from doodle_amd.env import HelioEnv
+dev = "cuda"
+torch.manual_seed(0)
+N, B, R = 1, 500, 128
+hp = torch.rand(N, 3, device=dev) * 10 + 80; hp[:, 2] = 0
+env = HelioEnv(hp, torch.tensor([0., -5., 0.], device=dev), (15., 15.), torch.tensor([0., 1., 0.], device=dev),
+               sigma_scale=0.01, error_scale_mrad=2.0, resolution=R, batch_size=B, device=dev)
+env.reset()
+a = torch.nn.functional.normalize(env.ideal_normals + 0.001 * torch.randn_like(env.ideal_normals), dim=2).reshape(B, -1).requires_grad_(True)
+def timeit(fn, n=200):
+    for _ in range(20): fn()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(n): fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e6
+def fb():
+    _, m, _ = env.step(a); m["dist"].backward(); a.grad = None
+with torch.no_grad():
+    print(f"N=1 B=500 R=128: env.step fwd {timeit(lambda: env.step(a)):.1f} us")
+print(f"                 env.step + dist.backward {timeit(fb):.1f} us")
