@@ -247,6 +247,11 @@ def main():
                     out["roofline_bench_workload"] = small
                 except Exception as e:  # noqa: BLE001  (report, do not hide)
                     out["roofline_large_error"] = repr(e)
+            if not args.no_large:
+                try:
+                    out["extras"] = extras_leg(field, suns_d, action.detach(), w, dev)
+                except Exception as e:  # noqa: BLE001
+                    out["extras"] = {"error": repr(e)}
             if not args.no_cpu:
                 out["cpu_baseline"] = cpu_baseline(w, args.seed)
                 out["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
@@ -255,6 +260,42 @@ def main():
         gather.close()
     if dist is not None:
         dist.destroy_process_group()
+
+
+def extras_leg(field, suns_d, action, w, dev):
+    """Secondary figures SURVEY.md §8(d) asks for, at the bench workload: render forward+backward
+    (config 3) and HelioEnv.step forward, both through the Python surface (wall clock)."""
+    from doodle_amd.env import HelioEnv
+
+    def wall(fn, n):
+        for _ in range(20):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n
+
+    a = action.clone().requires_grad_(True)
+    G = torch.randn((w.B, w.R, w.R), device=dev)
+
+    def fwdbwd():
+        img, actual = field.render(suns_d, a, None)
+        torch.autograd.grad((img * G).sum() + actual.sum(), a)
+
+    t_fb = wall(fwdbwd, 300)
+    env = HelioEnv(field.heliostat_positions, torch.tensor(synthetic.TARGET_POSITION, device=dev), synthetic.TARGET_AREA,
+                   torch.tensor(synthetic.TARGET_NORMAL, device=dev), sigma_scale=w.sigma_scale,
+                   error_scale_mrad=w.error_scale_mrad, resolution=w.R, batch_size=w.B, device=dev)
+    env.set_sun_pos(suns_d)
+    env.reset()
+    with torch.no_grad():
+        t_step = wall(lambda: env.step(action), 300)
+    return {"render_fwd_bwd_frames_per_s": round(w.B / t_fb, 1), "render_fwd_bwd_us": round(t_fb * 1e6, 1),
+            "env_step_fwd_frames_per_s": round(w.B / t_step, 1), "env_step_fwd_us": round(t_step * 1e6, 1),
+            "note": "config 3 = render + autograd.grad of (img*G).sum()+actual.sum(); env.step = 1 render + "
+                    "fused HIP loss block + NaN/Inf check (one host sync)"}
 
 
 def large_leg(dev, seed):
