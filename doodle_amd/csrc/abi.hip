@@ -15,6 +15,7 @@ void launch_geometry_fwd(int, int, const float*, const float*, const float*, con
 void launch_geometry_bwd(int, int, int, const float*, const float*, const float*, const float*, long,
                          const helio_plane*, const float*, const float*, const float*, float*, hipStream_t);
 void launch_ideal_normals(int, int, const float*, const float*, const float*, float*, hipStream_t);
+void launch_error_trig(long, const float*, float*, hipStream_t);
 int launch_splat_fwd(int, int, int, const float*, const float*, const float*, float*, int, hipStream_t);
 int launch_splat_bwd(int, int, int, const float*, const float*, const float*, const float*, float*, int, hipStream_t);
 int splat_bwd_blocks(int);
@@ -172,6 +173,15 @@ int helio_render_bwd(int B, int N, int R, const float* helios_d, const float* su
     helio::launch_geometry_bwd(B, N, helio::splat_bwd_blocks(R), helios_d, sun_d, action_d, trig_d, trig_b_stride,
                                plane, grad_image_d ? moments_d : nullptr, grad_actual_d, grad_refl_d, grad_action_d, st);
     return after_launch("render_bwd");
+}
+
+int helio_error_trig(long M, const float* errs_d, float* trig_d, void* stream) {
+    if (M < 1 || M > (1l << 31) / 4) return fail(HELIO_E_INVALID, "error_trig: bad size M=%ld", M);
+    if (!errs_d || !trig_d) return fail(HELIO_E_INVALID, "error_trig: null pointer");
+    if ((reinterpret_cast<uintptr_t>(errs_d) & 7) || !aligned16(trig_d))
+        return fail(HELIO_E_INVALID, "error_trig: errs must be 8-byte and trig 16-byte aligned");
+    helio::launch_error_trig(M, errs_d, trig_d, static_cast<hipStream_t>(stream));
+    return after_launch("error_trig");
 }
 
 int helio_ideal_normals(int B, int N, const float* helios_d, const float* sun_d,

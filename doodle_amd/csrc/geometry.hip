@@ -120,6 +120,17 @@ ideal_normals_kernel(int B, int N, const float* __restrict__ helios, const float
     }
 }
 
+// (cos_e, sin_e, cos_u, sin_u) of the error angles, :87-91: angle = err_mrad * 1e-3 (fp32), then
+// the precise ocml sinf/cosf — the same device functions torch's own cos/sin kernels call.
+__global__ void __launch_bounds__(256)
+error_trig_kernel(long M, const float* __restrict__ errs, float* __restrict__ trig) {
+    for (long m = (long)blockIdx.x * blockDim.x + threadIdx.x; m < M; m += (long)gridDim.x * blockDim.x) {
+        const float2 e = *reinterpret_cast<const float2*>(errs + 2 * m);
+        const float ae = e.x * 1e-3f, au = e.y * 1e-3f;
+        *reinterpret_cast<float4*>(trig + 4 * m) = make_float4(cosf(ae), sinf(ae), cosf(au), sinf(au));
+    }
+}
+
 static inline int ray_grid(long M) {
     long g = (M + 255) / 256;
     return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
@@ -139,6 +150,10 @@ void launch_geometry_bwd(int B, int N, int n_blocks, const float* helios, const 
     hipLaunchKernelGGL(geometry_bwd_kernel, dim3(ray_grid((long)B * N)), dim3(256), 0, st,
                        B, N, n_blocks, helios, sun, action, trig, trig_b_stride, to_k(plane), moments,
                        g_actual, g_refl, g_action);
+}
+
+void launch_error_trig(long M, const float* errs, float* trig, hipStream_t st) {
+    hipLaunchKernelGGL(error_trig_kernel, dim3(ray_grid(M)), dim3(256), 0, st, M, errs, trig);
 }
 
 void launch_ideal_normals(int B, int N, const float* helios, const float* sun, const float* target,

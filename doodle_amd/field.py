@@ -121,9 +121,12 @@ class HelioField:
         return torch.randn(batch_size, self.num_heliostats, 2, device=self.device) * self.error_scale_mrad
 
     def _trig_of(self, errs: torch.Tensor) -> torch.Tensor:
-        """(cos_e, sin_e, cos_u, sin_u) of errs·1e-3 (:87-91), computed by torch ON THE
-        DEVICE WHERE ``errs`` LIVES (CPU tensors assigned by a script keep torch's CPU
-        trig, i.e. the reference's bits) and moved to the field's device."""
+        """(cos_e, sin_e, cos_u, sin_u) of errs·1e-3 (:87-91), computed ON THE DEVICE WHERE
+        ``errs`` LIVES: the HIP kernel of ``helio_error_trig`` for device tensors (what
+        ``reset_errors`` draws); torch's CPU trig for CPU tensors assigned by a script, i.e. the
+        reference's bits, then moved to the field's device."""
+        if errs.is_cuda:
+            return _get_ops().error_trig(errs).to(self.device)
         ang = errs.detach().to(torch.float32) * 1e-3
         e, u = ang[..., 0], ang[..., 1]
         t = torch.stack([e.cos(), e.sin(), u.cos(), u.sin()], dim=-1)

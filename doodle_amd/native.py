@@ -19,7 +19,7 @@ RAY_STRIDE = 4
 MOMENT_STRIDE = 5
 
 EXPORTS = (
-    "helio_abi_version", "helio_last_error_string", "helio_device_arch", "helio_geometry_fwd",
+    "helio_abi_version", "helio_last_error_string", "helio_device_arch", "helio_error_trig", "helio_geometry_fwd",
     "helio_splat_fwd", "helio_render_fwd", "helio_render_bwd", "helio_render_fwd_launches", "helio_splat_bwd_blocks", "helio_splat_bwd", "helio_geometry_bwd",
     "helio_ideal_normals", "helio_step_losses_workspace", "helio_step_losses_fwd", "helio_step_losses_bwd",
     "helio_distance_maps_workspace", "helio_distance_maps",
@@ -53,6 +53,7 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
         "helio_abi_version": (_i, []),
         "helio_last_error_string": (ctypes.c_char_p, []),
         "helio_device_arch": (_i, [_i, ctypes.c_char_p, _i]),
+        "helio_error_trig": (_i, [_l, _vp, _vp, _vp]),
         "helio_geometry_fwd": (_i, [_i, _i, _vp, _vp, _vp, _vp, _l, pp, _vp, _vp, _vp, _vp]),
         "helio_splat_fwd": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp]),
         "helio_render_fwd": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _l, pp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
@@ -114,6 +115,13 @@ class HipOps:
             raise RuntimeError(f"libhelio.so is built for gfx950 (MI355X); device is {self.arch}")
         self.splat_variant = int(os.environ.get("HELIO_SPLAT_VARIANT", "0"))
         self.bwd_variant = int(os.environ.get("HELIO_BWD_VARIANT", "0"))
+
+    def error_trig(self, errs):
+        """[..., 2] mrad error angles on the device → [..., 4] (cos_e, sin_e, cos_u, sin_u)."""
+        errs = errs.detach().to(torch.float32).contiguous()
+        trig = torch.empty(errs.shape[:-1] + (4,), dtype=torch.float32, device=errs.device)
+        _check(self.lib, self.lib.helio_error_trig(errs.numel() // 2, _dev(errs), trig.data_ptr(), _stream()))
+        return trig
 
     # -- forward ---------------------------------------------------------------------------
     def geometry_fwd(self, helios, sun, normals, trig, trig_b_stride, plane, want_refl=True, want_rays=True):

@@ -63,6 +63,14 @@ const char *helio_last_error_string(void);
 int         helio_device_arch(int device, char *buf, int buflen);
 
 /*
+ * Replaces the trig of rotate_normals_batch, :87-91: for M = B*N error pairs (mrad),
+ *   trig_d[m,:] = (cos(e0*1e-3), sin(e0*1e-3), cos(e1*1e-3), sin(e1*1e-3))
+ * with the precise device sinf/cosf.  The table is an INPUT of the geometry kernels so that a
+ * caller who needs the reference's CPU bits (parity runs) can compute it with CPU torch.
+ */
+int helio_error_trig(long M, const float *errs_d, float *trig_d, void *stream);
+
+/*
  * Replaces the per-ray part of HelioField.render, :356-389 plus the per-ray
  * constants of gaussian_blur_batch :126-127,146: orientation-error rotation
  * (:78-104), leaky-ReLU Z clamp and renormalisation (:369-373), incident

@@ -125,6 +125,10 @@ class OracleOps:
         return (z(gi, img) if want_img else None, z(ga, actual) if want_actual else None,
                 z(gn, action) if want_action else None)
 
+    def error_trig(self, errs):
+        a = errs.detach().float() * 1e-3
+        return torch.stack([a[..., 0].cos(), a[..., 0].sin(), a[..., 1].cos(), a[..., 1].sin()], dim=-1)
+
     def ideal_normals(self, helios, sun, target_xyz):
         return to.ideal_normals(helios, torch.tensor(list(target_xyz)), sun)
 

@@ -331,3 +331,45 @@ def test_test_time_compute_reduces_dist():
         _, after, _ = env.step(torch.nn.functional.normalize(base + delta, dim=2).reshape(B, -1))
     assert after["dist"].item() < 0.7 * before["dist"].item(), (before["dist"].item(), after["dist"].item())
     assert after["mse"].item() < before["mse"].item()
+
+
+def test_error_trig_kernel_and_device_sampled_errors():
+    """helio_error_trig (device-sampled errors, the default path) against torch's trig: equal to
+    the device kernels bit for bit or within 1 ulp, and within 1 ulp of the CPU values the
+    parity runs inject."""
+    from doodle_amd import native
+    errs = torch.randn(7, 130, 2, device=DEV) * 180.0
+    got = native.get_ops().error_trig(errs)
+    a = errs * 1e-3
+    dev_ref = torch.stack([a[..., 0].cos(), a[..., 0].sin(), a[..., 1].cos(), a[..., 1].sin()], dim=-1)
+    ac = errs.cpu() * 1e-3
+    cpu_ref = torch.stack([ac[..., 0].cos(), ac[..., 0].sin(), ac[..., 1].cos(), ac[..., 1].sin()], dim=-1)
+    ulp = 2.0 ** -23
+    assert (got - dev_ref).abs().max().item() <= ulp
+    assert (got.cpu() - cpu_ref).abs().max().item() <= 2 * ulp
+    # a field whose errors were drawn on the device renders, deterministically until reset_errors()
+    f, _, suns, _, act = make_case(N=20, B=3, R=32, seed=2)
+    f.reset_errors()
+    assert f.batch_error_angles_mrad.is_cuda
+    x, _ = f.render(suns, act.to(DEV), None)
+    y, _ = f.render(suns, act.to(DEV), None)
+    assert torch.equal(x, y) and torch.isfinite(x).all()
+
+
+def test_render_is_hip_graph_capturable():
+    """The C ABI never allocates or synchronises, so a render (and its backward kernels) can be
+    captured in a HIP graph on torch's capture stream and replayed."""
+    f, _, suns, _, act = make_case(N=50, B=25, R=128, seed=4)
+    sun_d, a = suns.to(DEV), act.to(DEV)
+    with torch.no_grad():
+        eager, eager_actual = f.render(sun_d, a, None)
+        f.render(sun_d, a, None)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            img, actual = f.render(sun_d, a, None)
+        a.mul_(1.0)                      # same values; replay must recompute from the static inputs
+        img.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+    assert torch.equal(img, eager) and torch.equal(actual, eager_actual)
