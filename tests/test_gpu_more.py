@@ -198,6 +198,19 @@ def test_config5_shard_properties():
     img, actual = f.render(suns, act, None)
     part, _, _ = f.render_rows(suns[3:6], act.detach()[3:6], 3, Bs)
     assert torch.equal(part, img.detach()[3:6])
+    # one sun against the oracle (N=5000: the longest heliostat sum of any config), forcing the
+    # 256x256 one-level-accumulation kernel the full-size per-GPU shard (B=512) would take
+    from doodle_amd import native
+    sc = to.Scene.build(helios, synthetic.TARGET_POSITION, synthetic.TARGET_AREA, synthetic.TARGET_NORMAL, w.R, w.sigma_scale)
+    img_o, _ = to.render_chunked(sc, suns[:1], act.detach().cpu()[:1], errs[:1], b_chunk=1, n_chunk=250)
+    native.get_ops().splat_variant = 5
+    try:
+        with torch.no_grad():
+            img5, _ = f.render(suns, act.detach(), None)
+    finally:
+        native.get_ops().splat_variant = 0
+    np.testing.assert_allclose(img5[:1].cpu().numpy(), img_o.numpy(), rtol=1e-5, atol=1e-8)
+    assert (img5[:1].cpu() - img_o).abs().max().item() <= 1e-5 * img_o.max().item()
     g = torch.Generator(device=DEV).manual_seed(0)
     G1, G2 = (torch.randn(img.shape, device=DEV, generator=g) for _ in range(2))
     (g1,) = torch.autograd.grad((img * G1).sum(), act, retain_graph=True)
