@@ -253,7 +253,10 @@ template <int W, bool TWO_LEVEL>
 __global__ void __launch_bounds__(64 * W * W)
 splat_fwd_mfma_tile(int B, int N, int R, const float* __restrict__ rays, const float* __restrict__ xs,
                     const float* __restrict__ ys, float* __restrict__ image) {
-    constexpr int NC = 64, T = 64 * W, LD = T + 1, NW = W * W;
+    // row pitch: odd for the 4-wave form (ds_write_b32 per factor), T+2 for the 16-wave form, whose
+    // producer stores factor PAIRS with ds_write_b64 (8-byte aligned rows; 16 lanes × 2 dwords
+    // at pitch 258 cover the 32 banks exactly once)
+    constexpr int NC = 64, T = 64 * W, LD = T + (W == 4 ? 2 : 1), NW = W * W;
     constexpr int GROUPS = 2 * T / 32 / NW;          // 32-pixel factor groups per wave (1 or 2)
     static_assert(GROUPS * NW * 32 == 2 * T, "groups must tile the two tables");
     extern __shared__ __attribute__((aligned(16))) float smem[];   // sA[NC][LD] sE[NC][LD] xs[T] ys[T]
@@ -290,11 +293,40 @@ splat_fwd_mfma_tile(int B, int N, int R, const float* __restrict__ rays, const f
     asm volatile("" : "+v"(pa1));
     asm volatile("" : "+v"(pe1));
 
+    // 16-wave form: a wave's 32 pixel coordinates never change and are wave-uniform — keep them
+    // in scalar registers for the whole kernel (s_load; no LDS read in the producer loop)
+    float cs[32];
+    const int uw = __builtin_amdgcn_readfirstlane(wave);
+    if constexpr (GROUPS == 1) {
+        const bool sa = uw < T / 32;
+        const float* __restrict__ cptr = sa ? xs : ys;
+        const int cbase = (sa ? ti0 : tj0) + (sa ? uw : uw - T / 32) * 32;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) cs[j] = cptr[min(cbase + j, R - 1)];
+    }
+
     for (int n0 = 0; n0 < N; n0 += NC) {
         const float4 q = g;
         const float sk = __builtin_sqrtf(q.z);
         __syncthreads();                                     // tables free (and sXY visible)
         if (n0 + NC < N) g = (n0 + NC + lane < N) ? rb[n0 + NC + lane] : pad;   // in flight during the chunk
+        if constexpr (GROUPS == 1) {
+            const bool is_a = uw < T / 32;
+            const int p0 = (is_a ? uw : uw - T / 32) * 32;
+            const float shift = (is_a ? q.x : q.y) * sk;
+            const float cc = is_a ? q.w * q.z : 0.0f;
+            lds_f* wdst = (lds_f*)smem + (is_a ? 0 : NC * LD) + lane * LD + p0;
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            typedef __attribute__((address_space(3))) f32x2 lds_f2;
+#pragma unroll
+            for (int j = 0; j < 32; j += 2) {
+                const float t0 = __builtin_fmaf(cs[j], sk, shift), t1 = __builtin_fmaf(cs[j + 1], sk, shift);
+                f32x2 v;
+                v.x = exp2_fast(-__builtin_fmaf(t0, t0, cc));
+                v.y = exp2_fast(-__builtin_fmaf(t1, t1, cc));
+                *reinterpret_cast<lds_f2*>(wdst + j) = v;
+            }
+        } else
 #pragma unroll
         for (int gi = 0; gi < GROUPS; ++gi) {
             const int grp = wave * GROUPS + gi;              // wave-uniform: [0, T/32) → A, rest → E
@@ -444,7 +476,7 @@ static void launch_tile(int B, int N, int R, const float* rays, const float* xs,
                         float* image, hipStream_t st) {
     constexpr int T = 64 * W;
     const int t = (R + T - 1) / T;
-    const size_t lds = (2 * 64 * (T + 1) + 2 * T) * sizeof(float);
+    const size_t lds = (2 * 64 * (T + (W == 4 ? 2 : 1)) + 2 * T) * sizeof(float);
     static bool configured = false;   // raising the dynamic-LDS cap is idempotent; a race is harmless
     if (!configured) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(splat_fwd_mfma_tile<W, TWO_LEVEL>),
