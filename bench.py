@@ -218,6 +218,15 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
 
+    # secondary weak-scaling point on EVERY rank (collective): a config-5-like shard, where
+    # compute (ms) dominates the all-gather — see DESIGN.md §5
+    shard = None
+    if not args.no_large:
+        try:
+            shard = cfg5_shard_leg(dev, rank, world, gather, dist, args.seed)
+        except Exception as e:  # noqa: BLE001
+            shard = {"error": repr(e)}
+
     if rank == 0:
         frames = world * w.B * args.steps
         out = {
@@ -233,6 +242,8 @@ def main():
                           f"{'side stream' if args.overlap else 'stream-ordered'})"
                           if gather is not None else "")},
         }
+        if shard is not None:
+            out["weak_scaling_config5_shard"] = shard
         iters = 200 if w.B * w.N * w.R * w.R < 1e10 else 10
         small = splat_roofline(field, suns_d, action.detach(), iters)
         small["workload"] = w.name
@@ -296,6 +307,45 @@ def extras_leg(field, suns_d, action, w, dev):
             "env_step_fwd_frames_per_s": round(w.B / t_step, 1), "env_step_fwd_us": round(t_step * 1e6, 1),
             "note": "config 3 = render + autograd.grad of (img*G).sum()+actual.sum(); env.step = 1 render + "
                     "fused HIP loss block + NaN/Inf check (one host sync)"}
+
+
+def cfg5_shard_leg(dev, rank, world, gather, dist, seed, b_local=256, steps=8):
+    """Every rank renders its own ``b_local``-sun shard of BASELINE config 5 (N=5000, R=256) and the
+    ranks all-gather the images; whole-job frames/s.  Compute per step ≈ ms, so this is the
+    regime in which the sun-batch sharding scales; config 2 (the headline) is gather-bound."""
+    w5 = synthetic.CONFIGS["cfg5"]
+    w = synthetic.Workload(w5.name, w5.N, b_local, w5.R, w5.sigma_scale, w5.error_scale_mrad, w5.span)
+    helios, suns, errs, noise = synthetic.make_inputs(w, seed, b_offset=rank * b_local, b_count=b_local)
+    field = build_field(w, helios, errs, dev)
+    suns_d = suns.to(dev)
+    action = make_action(field, suns_d, noise)
+    out = torch.empty((world * b_local, w.R, w.R), dtype=torch.float32, device=dev) if gather is not None else None
+
+    def step():
+        with torch.no_grad():
+            img, _ = field.render(suns_d, action, None)
+        if gather is not None:
+            gather.gather(img, out)
+
+    for _ in range(3):
+        step()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([el], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    return {"workload": f"N={w.N}, R={w.R}, {b_local} suns per GPU", "n_gpus": world,
+            "frames_per_s": round(world * b_local * steps / el, 1), "ms_per_step": round(el / steps * 1e3, 3),
+            "gathered_MB_per_rank_and_step": round(world * b_local * w.R * w.R * 4 / 1e6, 1)}
 
 
 def large_leg(dev, seed):
