@@ -445,8 +445,10 @@ render_fwd_fused_small(int B, int N, int R, const float* __restrict__ helios, co
 
 // true when launch_render_fwd() would take the single-launch path
 bool render_is_fused(int B, int N, int R) {
+    // the fused kernel is the 64²-tile kernel plus in-kernel ray tracing: right wherever that tile
+    // size is (few tiles), and for short heliostat sums where saving a launch beats a better tile
     const long t128 = (long)B * ((R + 127) / 128) * ((R + 127) / 128);
-    return t128 < 512 && N <= 4096;
+    return t128 < 192 || (t128 < 512 && N <= 256);
 }
 
 void launch_render_fused(int B, int N, int R, const float* helios, const float* sun, const float* action,
@@ -489,14 +491,18 @@ static void launch_tile(int B, int N, int R, const float* rays, const float* xs,
 
 // variant: 0/2 = MFMA, kernel chosen by problem size; 1 = VALU; 3/4/5/6 force one MFMA kernel
 // (regs 128², tile 128², tile 256², regs 64²) — used by the tests and tools/bench_splat.py.
+// (tile 128² is never the fastest in the sweep; it stays as a forced variant for A/B runs.)
 int launch_splat_fwd(int B, int N, int R, const float* rays, const float* xs, const float* ys,
                      float* image, int variant, hipStream_t st) {
     const long t128 = (long)B * ((R + 127) / 128) * ((R + 127) / 128);
     const long t256 = (long)B * ((R + 255) / 256) * ((R + 255) / 256);
     if (variant == 0 || variant == 2) {
-        if (N >= 48 && R > 128 && t256 >= 192) variant = 5;
-        else if (N >= 48 && t128 >= 384) variant = 4;
-        else if (t128 >= 512) variant = 3;
+        // measured on MI355X over B ∈ {4..256}, N ∈ {50, 500, 5000}, R ∈ {64..512}
+        // (tools/sweep_variants.py): the 256² LDS-table kernel wins once its tiles fill the 256 CUs
+        // and the heliostat sum is long enough to amortise its 64-ray chunks; the 128²
+        // register-operand kernel once ITS tiles fill the chip; below that, 64² tiles.
+        if (N >= 200 && R > 128 && t256 >= 192) variant = 5;
+        else if (t128 >= 192 && R > 64) variant = 3;
         else variant = 6;
     }
     switch (variant) {
