@@ -407,7 +407,9 @@ int launch_splat_bwd(int B, int N, int R, const float* rays, const float* xs, co
                      const float* gimg, float* moments, int variant, hipStream_t st) {
     if (variant == 0) {
         const long wgs = (long)B * ((R + 255) / 256) * ((N + 255) / 256);
-        variant = (R >= 128 && N >= 96 && wgs >= 128) ? 2 : 3;
+        // tools/sweep_bwd.py: the 256-wide tiles pay off only when the image is wider than 128
+        // pixels (at R = 128 half of every tile is padding) and there are enough of them
+        variant = (R > 128 && N >= 96 && wgs >= 128) ? 2 : 3;
     }
     if (variant == 3) {
         const int ct = (R + 63) / 64, nt = (N + 63) / 64;
