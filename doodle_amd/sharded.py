@@ -11,7 +11,6 @@ consumes the rows of ∂L/∂image it produced.  One process per GPU.
 from __future__ import annotations
 
 import torch
-import torch.distributed as dist
 
 from .comm import ImageGather
 

@@ -253,3 +253,16 @@ def test_env_reset_step_match_reference(tag, monkeypatch):
     env.new_sun_pos_every_reset = True
     with pytest.raises(NotImplementedError):
         env.reset()
+
+
+def test_synthetic_inputs_are_shard_invariant():
+    """A rank that draws only the rows it owns sees exactly the rows of the global batch
+    (bench.py --gpus N relies on it for weak scaling with identical per-sun inputs)."""
+    from doodle_amd import synthetic
+    w = synthetic.Workload("t", N=7, B=10, R=8)
+    helios, suns, errs, noise = synthetic.make_inputs(w, seed=3)
+    h2, s2, e2, n2 = synthetic.make_inputs(w, seed=3, b_offset=4, b_count=3)
+    assert torch.equal(helios, h2) and torch.equal(suns[4:7], s2)
+    assert torch.equal(errs[4:7], e2) and torch.equal(noise[4:7], n2)
+    assert (suns[:, 2] >= 0).all() and torch.allclose(suns.norm(dim=1), torch.full((10,), synthetic.SUN_RADIUS))
+    assert set(synthetic.CONFIGS) == {"cfg1", "cfg2", "cfg4", "cfg5"}
