@@ -59,5 +59,28 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+def hostbind_path():
+    import glob
+    hits = glob.glob(os.path.join(HERE, "_hostbind*.so"))
+    return hits[0] if hits else None
+
+
+def build_hostbind(force: bool = False, verbose: bool = False):
+    """The compiled torch binding of the C ABI (csrc/hostbind.cpp → doodle_amd/_hostbind*.so).
+    Host C++ against the torch headers (≈1 min); links libhelio.so, so build() runs first."""
+    src = os.path.join(CSRC, "hostbind.cpp")
+    so = hostbind_path()
+    if not force and so and os.path.getmtime(so) >= max(os.path.getmtime(src), os.path.getmtime(HEADERS[2])):
+        return so
+    build(force=False, verbose=verbose)
+    cmd = [sys.executable, os.path.join(HERE, "setup_hostbind.py"), "-q", "build_ext", "--inplace",
+           "--build-temp", os.path.join(ROOT, "build", "hostbind")]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd, cwd=ROOT)
+    return hostbind_path()
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    print(build_hostbind(force="--force" in sys.argv, verbose=True))

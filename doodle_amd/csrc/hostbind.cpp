@@ -1,0 +1,144 @@
+// _hostbind — a compiled host-side binding of the C ABI (include/helio.h) for torch tensors.
+//
+// The C ABI stays the boundary (raw pointers, sizes, hipStream_t).  doodle_amd/native.py binds
+// it with ctypes, which is the reference binding; this module binds the SAME
+// entry points from C++ so that the per-call host work of the launch-bound small configurations
+// (output allocation, pointer extraction, stream lookup, argument marshalling) costs ≈2 µs
+// instead of ≈7 µs.  No arithmetic happens here.  Optional: if it is not built, native.py's
+// ctypes path is used.
+#include <torch/extension.h>
+#include <c10/hip/HIPStream.h>
+
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "helio.h"
+
+namespace {
+
+void check(int rc) {
+    if (rc != 0) throw std::runtime_error(std::string("libhelio: ") + helio_last_error_string() + " (code " + std::to_string(rc) + ")");
+}
+
+const float* fp(const at::Tensor& t, const char* what) {
+    TORCH_CHECK(t.is_cuda(), "doodle_amd renders only on a HIP device (MI355X); ", what, " is a CPU tensor — there is no CPU fallback");
+    TORCH_CHECK(t.scalar_type() == at::kFloat && t.is_contiguous(), what, " must be contiguous float32");
+    return t.data_ptr<float>();
+}
+const float* fpo(const c10::optional<at::Tensor>& t, const char* what) { return t.has_value() ? fp(*t, what) : nullptr; }
+
+void* cur_stream(const at::Tensor& t) { return (void*)c10::hip::getCurrentHIPStream(t.get_device()).stream(); }
+
+// helio_plane structs live for the life of the process (a field keeps its handle)
+int64_t make_plane(const std::vector<double>& v) {
+    TORCH_CHECK(v.size() == 16, "plane needs 16 numbers");
+    auto* p = new helio_plane;
+    for (int k = 0; k < 3; ++k) {
+        p->origin[k] = (float)v[k]; p->normal[k] = (float)v[3 + k]; p->u[k] = (float)v[6 + k];
+        p->v[k] = (float)v[9 + k]; p->w[k] = (float)v[12 + k];
+    }
+    p->sigma_scale = (float)v[15];
+    return reinterpret_cast<int64_t>(p);
+}
+
+int64_t current_stream_handle(const at::Tensor& t) { return reinterpret_cast<int64_t>(cur_stream(t)); }
+
+py::tuple render_fwd(int64_t plane, const at::Tensor& helios, const at::Tensor& sun, const at::Tensor& normals,
+                     const at::Tensor& trig, int64_t trig_b_stride, const at::Tensor& xs, const at::Tensor& ys,
+                     c10::optional<at::Tensor> rays_ws, bool want_refl, int64_t variant) {
+    const int64_t B = normals.size(0), N = normals.size(1), R = xs.size(0);
+    const float* pn = fp(normals, "action");
+    at::Tensor actual = at::empty_like(normals);
+    at::Tensor refl = want_refl ? at::empty_like(normals) : at::Tensor();
+    at::Tensor rays = rays_ws.has_value() ? *rays_ws : at::empty({B, N, HELIO_RAY_STRIDE}, normals.options());
+    at::Tensor image = at::empty({B, R, R}, normals.options());
+    check(helio_render_fwd((int)B, (int)N, (int)R, fp(helios, "heliostat_positions"), fp(sun, "sun"), pn,
+                           fp(trig, "trig"), (long)trig_b_stride, reinterpret_cast<const helio_plane*>(plane),
+                           fp(xs, "xs"), fp(ys, "ys"), actual.data_ptr<float>(),
+                           want_refl ? refl.data_ptr<float>() : nullptr, rays.data_ptr<float>(),
+                           image.data_ptr<float>(), (int)variant, cur_stream(normals)));
+    if (want_refl) return py::make_tuple(image, actual, refl, rays);
+    return py::make_tuple(image, actual, py::none(), rays);
+}
+
+at::Tensor render_bwd(int64_t plane, const at::Tensor& helios, const at::Tensor& sun, const at::Tensor& normals,
+                      const at::Tensor& trig, int64_t trig_b_stride, const at::Tensor& rays, const at::Tensor& xs,
+                      const at::Tensor& ys, c10::optional<at::Tensor> g_image, c10::optional<at::Tensor> g_actual,
+                      c10::optional<at::Tensor> g_refl, int64_t variant) {
+    const int64_t B = normals.size(0), N = normals.size(1), R = xs.size(0);
+    at::Tensor grad = at::empty_like(normals);
+    at::Tensor moments;
+    if (g_image.has_value())
+        moments = at::empty({B, (int64_t)helio_splat_bwd_blocks((int)R), N, HELIO_MOMENT_STRIDE}, normals.options());
+    check(helio_render_bwd((int)B, (int)N, (int)R, fp(helios, "heliostat_positions"), fp(sun, "sun"),
+                           fp(normals, "action"), fp(trig, "trig"), (long)trig_b_stride,
+                           reinterpret_cast<const helio_plane*>(plane), fp(rays, "rays"), fp(xs, "xs"), fp(ys, "ys"),
+                           fpo(g_image, "grad_image"), fpo(g_actual, "grad_actual"), fpo(g_refl, "grad_refl"),
+                           g_image.has_value() ? moments.data_ptr<float>() : nullptr, grad.data_ptr<float>(),
+                           (int)variant, cur_stream(normals)));
+    return grad;
+}
+
+py::tuple step_losses_fwd(const at::Tensor& img, const at::Tensor& target, const at::Tensor& tx, const at::Tensor& dmaps,
+                          const at::Tensor& ideal, const at::Tensor& actual, const at::Tensor& action,
+                          const at::Tensor& helios, const std::vector<double>& tp, const std::vector<double>& tn,
+                          double W, double H, bool exp_risk) {
+    const int64_t B = action.size(0), N = action.size(1), R = img.size(-1);
+    const float tpf[3] = {(float)tp[0], (float)tp[1], (float)tp[2]}, tnf[3] = {(float)tn[0], (float)tn[1], (float)tn[2]};
+    auto opt = img.options();
+    at::Tensor ws = at::empty({helio_step_losses_workspace((int)B, (int)N, (int)R)}, opt);
+    at::Tensor out = at::empty({5}, opt), mae = at::empty({B}, opt);
+    at::Tensor align = at::empty({B, N}, opt), allb = at::empty({B, N}, opt);
+    check(helio_step_losses_fwd((int)B, (int)N, (int)R, fp(img, "img"), fp(target, "target"), fp(tx, "tx"),
+                                fp(dmaps, "distance_maps"), fp(ideal, "ideal"), fp(actual, "actual"),
+                                fp(action, "action"), fp(helios, "heliostat_positions"), tpf, tnf, (float)W, (float)H,
+                                exp_risk ? 1 : 0, ws.data_ptr<float>(), out.data_ptr<float>(), mae.data_ptr<float>(),
+                                align.data_ptr<float>(), allb.data_ptr<float>(), cur_stream(img)));
+    return py::make_tuple(out, mae, align, allb);
+}
+
+py::tuple step_losses_bwd(const at::Tensor& img, const at::Tensor& target, const at::Tensor& tx, const at::Tensor& dmaps,
+                          const at::Tensor& ideal, const at::Tensor& actual, const at::Tensor& action,
+                          const at::Tensor& helios, const std::vector<double>& tp, const std::vector<double>& tn,
+                          double W, double H, bool exp_risk, c10::optional<at::Tensor> g_mse,
+                          c10::optional<at::Tensor> g_dist, c10::optional<at::Tensor> g_bound,
+                          c10::optional<at::Tensor> g_align, bool want_img, bool want_actual, bool want_action) {
+    const int64_t B = action.size(0), N = action.size(1), R = img.size(-1);
+    const float tpf[3] = {(float)tp[0], (float)tp[1], (float)tp[2]}, tnf[3] = {(float)tn[0], (float)tn[1], (float)tn[2]};
+    at::Tensor gi = want_img ? at::empty_like(img) : at::Tensor();
+    at::Tensor ga = want_actual ? at::empty_like(actual) : at::Tensor();
+    at::Tensor gn = want_action ? at::empty_like(action) : at::Tensor();
+    check(helio_step_losses_bwd((int)B, (int)N, (int)R, fp(img, "img"), fp(target, "target"), fp(tx, "tx"),
+                                fp(dmaps, "distance_maps"), fp(ideal, "ideal"), fp(actual, "actual"),
+                                fp(action, "action"), fp(helios, "heliostat_positions"), tpf, tnf, (float)W, (float)H,
+                                exp_risk ? 1 : 0, fpo(g_mse, "g_mse"), fpo(g_dist, "g_dist"), fpo(g_bound, "g_bound"),
+                                fpo(g_align, "g_align"), want_img ? gi.data_ptr<float>() : nullptr,
+                                want_actual ? ga.data_ptr<float>() : nullptr,
+                                want_action ? gn.data_ptr<float>() : nullptr, cur_stream(img)));
+    auto o = [](const at::Tensor& t) -> py::object { return t.defined() ? py::cast(t) : py::none(); };
+    return py::make_tuple(o(gi), o(ga), o(gn));
+}
+
+at::Tensor ideal_normals(const at::Tensor& helios, const at::Tensor& sun, const std::vector<double>& target) {
+    const int64_t B = sun.size(0), N = helios.size(0);
+    const float t[3] = {(float)target[0], (float)target[1], (float)target[2]};
+    at::Tensor out = at::empty({B, N, 3}, helios.options());
+    check(helio_ideal_normals((int)B, (int)N, fp(helios, "heliostat_positions"), fp(sun, "sun"), t,
+                              out.data_ptr<float>(), cur_stream(helios)));
+    return out;
+}
+
+}  // namespace
+
+PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
+    m.doc() = "compiled torch binding of libhelio.so's C ABI (same entry points as doodle_amd/native.py)";
+    m.def("abi_version", []() { return helio_abi_version(); });
+    m.def("make_plane", &make_plane);
+    m.def("current_stream_handle", &current_stream_handle);
+    m.def("render_fwd", &render_fwd);
+    m.def("render_bwd", &render_bwd);
+    m.def("step_losses_fwd", &step_losses_fwd);
+    m.def("step_losses_bwd", &step_losses_bwd);
+    m.def("ideal_normals", &ideal_normals);
+}

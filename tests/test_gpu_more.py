@@ -386,3 +386,32 @@ def test_render_is_hip_graph_capturable():
         graph.replay()
         torch.cuda.synchronize()
     assert torch.equal(img, eager) and torch.equal(actual, eager_actual)
+
+
+def test_hostbind_and_ctypes_bindings_agree():
+    """The compiled binding (csrc/hostbind.cpp) and the ctypes binding call the same C ABI on the
+    same stream: identical results, forward and backward."""
+    from doodle_amd import native
+    ops = native.get_ops()
+    if ops.hb is None:
+        pytest.skip("_hostbind not built")
+    f, _, suns, _, act = make_case(N=50, B=25, R=128, seed=8)
+    a = act.to(DEV).requires_grad_(True)
+    x = torch.zeros(1, device=DEV)
+    assert ops.hb.current_stream_handle(x) == torch.cuda.current_stream().cuda_stream
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        assert ops.hb.current_stream_handle(x) == side.cuda_stream
+    G = torch.randn(25, 128, 128, device=DEV)
+    out = {}
+    for name, hb in (("hostbind", ops.hb), ("ctypes", None)):
+        saved, ops.hb = ops.hb, hb
+        try:
+            img, actual, refl = f.render(suns, a, None, monitor=True)
+            (g,) = torch.autograd.grad((img * G).sum() + actual.sum() + refl.sum(), a)
+            ideal = f.calculate_ideal_normals(suns)
+        finally:
+            ops.hb = saved
+        out[name] = (img.detach(), actual.detach(), refl.detach(), g, ideal)
+    for p, q in zip(out["hostbind"], out["ctypes"]):
+        assert torch.equal(p, q)
