@@ -62,6 +62,21 @@ py::tuple render_fwd(int64_t plane, const at::Tensor& helios, const at::Tensor& 
     return py::make_tuple(image, actual, py::none(), rays);
 }
 
+// The no-autograd render of tensors that may still need a dtype/device/shape fix-up
+// (HelioField.render's as_tensor / reshape / contiguous, :326-337), done here instead of in Python.
+py::tuple render_any(int64_t plane, const at::Tensor& helios, const at::Tensor& sun_in, const at::Tensor& action_in,
+                     const at::Tensor& trig, int64_t trig_b_stride, const at::Tensor& xs, const at::Tensor& ys,
+                     c10::optional<at::Tensor> rays_ws, bool want_refl, int64_t variant) {
+    const auto opt = helios.options();
+    at::Tensor sun = sun_in.to(opt, /*non_blocking=*/false, /*copy=*/false);
+    if (sun.dim() == 1) sun = sun.unsqueeze(0);
+    sun = sun.contiguous();
+    const int64_t B = sun.size(0), N = helios.size(0);
+    at::Tensor normals = action_in.to(opt, false, false).reshape({B, N, 3}).contiguous();
+    if (rays_ws.has_value() && (rays_ws->size(0) != B || rays_ws->device() != normals.device())) rays_ws.reset();
+    return render_fwd(plane, helios, sun, normals, trig, trig_b_stride, xs, ys, rays_ws, want_refl, variant);
+}
+
 at::Tensor render_bwd(int64_t plane, const at::Tensor& helios, const at::Tensor& sun, const at::Tensor& normals,
                       const at::Tensor& trig, int64_t trig_b_stride, const at::Tensor& rays, const at::Tensor& xs,
                       const at::Tensor& ys, c10::optional<at::Tensor> g_image, c10::optional<at::Tensor> g_actual,
@@ -137,6 +152,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("make_plane", &make_plane);
     m.def("current_stream_handle", &current_stream_handle);
     m.def("render_fwd", &render_fwd);
+    m.def("render_any", &render_any);
     m.def("render_bwd", &render_bwd);
     m.def("step_losses_fwd", &step_losses_fwd);
     m.def("step_losses_bwd", &step_losses_bwd);

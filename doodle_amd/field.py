@@ -185,6 +185,18 @@ class HelioField:
         ``[B,N,3]`` (``[1,N,3]`` for a 1-D sun), ``refl`` is ``[B·N,3]``.
         ``ideal_normals`` and ``show_spillage`` are accepted and unused, as in the reference.
         """
+        if (type(sun_position) is torch.Tensor and type(action) is torch.Tensor
+                and not (action.requires_grad and torch.is_grad_enabled())):
+            # launch-bound fast path: everything below happens inside the compiled binding
+            ops = _get_ops()
+            fast = getattr(ops, "render_nograd", None)
+            if fast is not None:
+                batched = sun_position.dim() > 1
+                trig, stride = self._select_trig(sun_position.shape[0] if batched else 1)
+                out = fast(self, sun_position, action, trig, stride, monitor)
+                if out is not None:
+                    img = out[0] if batched else out[0][0]
+                    return (img, out[1], out[2].view(-1, 3)) if monitor else (img, out[1])
         sun = torch.as_tensor(sun_position, dtype=torch.float32, device=self.device)
         batched = sun.dim() > 1
         if not batched:

@@ -175,6 +175,17 @@ class HipOps:
             rays.data_ptr(), image.data_ptr(), self.splat_variant, _stream()))
         return image, actual, refl, rays
 
+    def render_nograd(self, field, sun, action, trig, trig_b_stride, want_refl):
+        """Fast path of HelioField.render without autograd for torch.Tensor inputs: dtype /
+        device / shape fix-ups, allocation and the launch all happen in the compiled binding.
+        Returns None when that binding is not built (the caller then takes the general path)."""
+        if self.hb is None:
+            return None
+        out = self.hb.render_any(_plane_handle(self.hb, field._plane), field.heliostat_positions, sun, action, trig,
+                                 trig_b_stride, field._xs, field._ys, field._ray_ws, want_refl, self.splat_variant)
+        field._ray_ws = out[3]
+        return out
+
     def splat_fwd(self, rays, xs, ys, variant=None):
         B, N, R = rays.shape[0], rays.shape[1], xs.shape[0]
         image = torch.empty((B, R, R), dtype=torch.float32, device=rays.device)
