@@ -325,16 +325,25 @@ def cfg5_shard_leg(dev, rank, world, gather, dist, seed, b_local=256, steps=8):
         with torch.no_grad():
             img, _ = field.render(suns_d, action, None)
         if gather is not None:
-            gather.gather(img, out)
+            # side stream: the gather of this step's images (67 MB per rank) overlaps the next render
+            gather.gather(img, out[step.k & 1], overlap=gather.transport == "rccl")
+            step.k += 1
 
+    step.k = 0
+    if gather is not None:
+        out = [out, torch.empty_like(out)]
     for _ in range(3):
         step()
+    if gather is not None:
+        gather.wait()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
+    if gather is not None:
+        gather.wait()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
