@@ -267,6 +267,8 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(w, args.seed)
                 out["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
         print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()                 # rank 0 runs extra single-GPU legs; tear down together
     if gather is not None:
         gather.close()
     if dist is not None:
