@@ -148,6 +148,9 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-large", action="store_true", help="skip the config-4 roofline leg")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the secondary legs (fwd+bwd, env.step, config-5 shard): used for profiling runs "
+                         "so that every kernel in the trace belongs to one workload")
     ap.add_argument("--mode", default="fwd", choices=["fwd", "fwdbwd"])
     ap.add_argument("--overlap", action="store_true",
                     help="run the all-gather on a side stream (overlaps the next render)")
@@ -221,7 +224,7 @@ def main():
     # secondary weak-scaling point on EVERY rank (collective): a config-5-like shard, where
     # compute (ms) dominates the all-gather — see DESIGN.md §5
     shard = None
-    if not args.no_large:
+    if not args.no_large and not args.no_extras:
         try:
             shard = cfg5_shard_leg(dev, rank, world, gather, dist, args.seed)
         except Exception as e:  # noqa: BLE001
@@ -258,7 +261,7 @@ def main():
                     out["roofline_bench_workload"] = small
                 except Exception as e:  # noqa: BLE001  (report, do not hide)
                     out["roofline_large_error"] = repr(e)
-            if not args.no_large:
+            if not args.no_large and not args.no_extras:
                 try:
                     out["extras"] = extras_leg(field, suns_d, action.detach(), w, dev)
                 except Exception as e:  # noqa: BLE001
