@@ -125,6 +125,13 @@ class OracleOps:
         return (z(gi, img) if want_img else None, z(ga, actual) if want_actual else None,
                 z(gn, action) if want_action else None)
 
+    def distance_maps(self, imgs, thr=0.5):
+        """The reference's own implementation (test_environment.py:92-97): scipy on the host."""
+        import numpy as np
+        from scipy.ndimage import distance_transform_edt
+        maps = [distance_transform_edt(1 - (im > thr * im.max()).astype(np.uint8)) for im in imgs.cpu().numpy()]
+        return torch.tensor(np.stack(maps), dtype=torch.float32)
+
     def error_trig(self, errs):
         a = errs.detach().float() * 1e-3
         return torch.stack([a[..., 0].cos(), a[..., 0].sin(), a[..., 1].cos(), a[..., 1].sin()], dim=-1)
