@@ -23,12 +23,14 @@ bool render_is_fused(int, int, int);
 void launch_distance_maps(int, int, const float*, float, int*, float*, int*, float*, hipStream_t);
 int step_losses_chunks(int);
 int step_losses_ray_wgs(int, int);
+int step_losses_max_mask_batch();
 void launch_step_losses_fwd(int, int, int, const float*, const float*, const float*, const float*, const float*,
                             const float*, const float*, const float*, const float*, const float*, float, float, int,
-                            float*, float*, float*, float*, float*, hipStream_t);
+                            float, float*, float*, float*, float*, float*, float*, hipStream_t);
 void launch_step_losses_bwd(int, int, int, const float*, const float*, const float*, const float*, const float*,
                             const float*, const float*, const float*, const float*, const float*, float, float, int,
-                            const float*, const float*, const float*, const float*, float*, float*, float*, hipStream_t);
+                            const float*, const float*, const float*, const float*, const float*, float*, float*,
+                            float*, hipStream_t);
 void launch_render_fused(int, int, int, const float*, const float*, const float*, const float*, long,
                          const helio_plane*, const float*, const float*, float*, float*, float*, float*, hipStream_t);
 }  // namespace helio
@@ -215,17 +217,23 @@ long helio_step_losses_workspace(int B, int N, int R) {
 int helio_step_losses_fwd(int B, int N, int R, const float* img_d, const float* target_d, const float* tx_d,
                           const float* dmaps_d, const float* ideal_d, const float* actual_d, const float* action_d,
                           const float* helios_d, const float target_position[3], const float target_normal[3],
-                          float width, float height, int exponential_risk, float* workspace_d, float* out_d,
-                          float* mae_d, float* align_err_d, float* all_bounds_d, void* stream) {
+                          float width, float height, int exponential_risk, float error_mask_ratio,
+                          float* workspace_d, float* out_d, float* mae_d, float* keep_d, float* align_err_d,
+                          float* all_bounds_d, void* stream) {
     if (!sizes_ok(B, N) || R < 1 || R > 16384) return fail(HELIO_E_INVALID, "step_losses_fwd: bad sizes B=%d N=%d R=%d", B, N, R);
     if (!img_d || !target_d || !tx_d || !dmaps_d || !ideal_d || !actual_d || !action_d || !helios_d ||
-        !target_position || !target_normal || !workspace_d || !out_d || !mae_d || !align_err_d || !all_bounds_d)
+        !target_position || !target_normal || !workspace_d || !out_d || !mae_d || !keep_d || !align_err_d ||
+        !all_bounds_d)
         return fail(HELIO_E_INVALID, "step_losses_fwd: null pointer");
+    if (error_mask_ratio >= 0.0f && (error_mask_ratio > 1.0f || B > helio::step_losses_max_mask_batch()))
+        return fail(HELIO_E_INVALID, "step_losses_fwd: error mask needs ratio in [0,1] and B <= %d",
+                    helio::step_losses_max_mask_batch());
     if (!aligned16(img_d) || !aligned16(target_d) || !aligned16(dmaps_d))
         return fail(HELIO_E_INVALID, "step_losses_fwd: images must be 16-byte aligned");
     helio::launch_step_losses_fwd(B, N, R, img_d, target_d, tx_d, dmaps_d, ideal_d, actual_d, action_d, helios_d,
-                                  target_position, target_normal, width, height, exponential_risk, workspace_d,
-                                  out_d, mae_d, align_err_d, all_bounds_d, static_cast<hipStream_t>(stream));
+                                  target_position, target_normal, width, height, exponential_risk, error_mask_ratio,
+                                  workspace_d, out_d, mae_d, keep_d, align_err_d, all_bounds_d,
+                                  static_cast<hipStream_t>(stream));
     return after_launch("step_losses_fwd");
 }
 
@@ -233,8 +241,8 @@ int helio_step_losses_bwd(int B, int N, int R, const float* img_d, const float* 
                           const float* dmaps_d, const float* ideal_d, const float* actual_d, const float* action_d,
                           const float* helios_d, const float target_position[3], const float target_normal[3],
                           float width, float height, int exponential_risk, const float* g_mse_d,
-                          const float* g_dist_d, const float* g_bound_d, const float* g_align_d, float* grad_img_d,
-                          float* grad_actual_d, float* grad_action_d, void* stream) {
+                          const float* g_dist_d, const float* g_bound_d, const float* g_align_d, const float* keep_d,
+                          float* grad_img_d, float* grad_actual_d, float* grad_action_d, void* stream) {
     if (!sizes_ok(B, N) || R < 1 || R > 16384) return fail(HELIO_E_INVALID, "step_losses_bwd: bad sizes B=%d N=%d R=%d", B, N, R);
     if (!img_d || !target_d || !tx_d || !dmaps_d || !ideal_d || !actual_d || !action_d || !helios_d ||
         !target_position || !target_normal)
@@ -243,7 +251,7 @@ int helio_step_losses_bwd(int B, int N, int R, const float* img_d, const float* 
         return fail(HELIO_E_INVALID, "step_losses_bwd: images must be 16-byte aligned");
     helio::launch_step_losses_bwd(B, N, R, img_d, target_d, tx_d, dmaps_d, ideal_d, actual_d, action_d, helios_d,
                                   target_position, target_normal, width, height, exponential_risk, g_mse_d, g_dist_d,
-                                  g_bound_d, g_align_d, grad_img_d, grad_actual_d, grad_action_d,
+                                  g_bound_d, g_align_d, keep_d, grad_img_d, grad_actual_d, grad_action_d,
                                   static_cast<hipStream_t>(stream));
     return after_launch("step_losses_bwd");
 }

@@ -98,19 +98,20 @@ at::Tensor render_bwd(int64_t plane, const at::Tensor& helios, const at::Tensor&
 py::tuple step_losses_fwd(const at::Tensor& img, const at::Tensor& target, const at::Tensor& tx, const at::Tensor& dmaps,
                           const at::Tensor& ideal, const at::Tensor& actual, const at::Tensor& action,
                           const at::Tensor& helios, const std::vector<double>& tp, const std::vector<double>& tn,
-                          double W, double H, bool exp_risk) {
+                          double W, double H, bool exp_risk, double mask_ratio) {
     const int64_t B = action.size(0), N = action.size(1), R = img.size(-1);
     const float tpf[3] = {(float)tp[0], (float)tp[1], (float)tp[2]}, tnf[3] = {(float)tn[0], (float)tn[1], (float)tn[2]};
     auto opt = img.options();
     at::Tensor ws = at::empty({helio_step_losses_workspace((int)B, (int)N, (int)R)}, opt);
-    at::Tensor out = at::empty({5}, opt), mae = at::empty({B}, opt);
+    at::Tensor out = at::empty({5}, opt), mae = at::empty({B}, opt), keep = at::empty({B}, opt);
     at::Tensor align = at::empty({B, N}, opt), allb = at::empty({B, N}, opt);
     check(helio_step_losses_fwd((int)B, (int)N, (int)R, fp(img, "img"), fp(target, "target"), fp(tx, "tx"),
                                 fp(dmaps, "distance_maps"), fp(ideal, "ideal"), fp(actual, "actual"),
                                 fp(action, "action"), fp(helios, "heliostat_positions"), tpf, tnf, (float)W, (float)H,
-                                exp_risk ? 1 : 0, ws.data_ptr<float>(), out.data_ptr<float>(), mae.data_ptr<float>(),
-                                align.data_ptr<float>(), allb.data_ptr<float>(), cur_stream(img)));
-    return py::make_tuple(out, mae, align, allb);
+                                exp_risk ? 1 : 0, (float)mask_ratio, ws.data_ptr<float>(), out.data_ptr<float>(),
+                                mae.data_ptr<float>(), keep.data_ptr<float>(), align.data_ptr<float>(),
+                                allb.data_ptr<float>(), cur_stream(img)));
+    return py::make_tuple(out, mae, align, allb, keep);
 }
 
 py::tuple step_losses_bwd(const at::Tensor& img, const at::Tensor& target, const at::Tensor& tx, const at::Tensor& dmaps,
@@ -118,7 +119,8 @@ py::tuple step_losses_bwd(const at::Tensor& img, const at::Tensor& target, const
                           const at::Tensor& helios, const std::vector<double>& tp, const std::vector<double>& tn,
                           double W, double H, bool exp_risk, c10::optional<at::Tensor> g_mse,
                           c10::optional<at::Tensor> g_dist, c10::optional<at::Tensor> g_bound,
-                          c10::optional<at::Tensor> g_align, bool want_img, bool want_actual, bool want_action) {
+                          c10::optional<at::Tensor> g_align, c10::optional<at::Tensor> keep, bool want_img,
+                          bool want_actual, bool want_action) {
     const int64_t B = action.size(0), N = action.size(1), R = img.size(-1);
     const float tpf[3] = {(float)tp[0], (float)tp[1], (float)tp[2]}, tnf[3] = {(float)tn[0], (float)tn[1], (float)tn[2]};
     at::Tensor gi = want_img ? at::empty_like(img) : at::Tensor();
@@ -128,7 +130,7 @@ py::tuple step_losses_bwd(const at::Tensor& img, const at::Tensor& target, const
                                 fp(dmaps, "distance_maps"), fp(ideal, "ideal"), fp(actual, "actual"),
                                 fp(action, "action"), fp(helios, "heliostat_positions"), tpf, tnf, (float)W, (float)H,
                                 exp_risk ? 1 : 0, fpo(g_mse, "g_mse"), fpo(g_dist, "g_dist"), fpo(g_bound, "g_bound"),
-                                fpo(g_align, "g_align"), want_img ? gi.data_ptr<float>() : nullptr,
+                                fpo(g_align, "g_align"), fpo(keep, "keep"), want_img ? gi.data_ptr<float>() : nullptr,
                                 want_actual ? ga.data_ptr<float>() : nullptr,
                                 want_action ? gn.data_ptr<float>() : nullptr, cur_stream(img)));
     auto o = [](const at::Tensor& t) -> py::object { return t.defined() ? py::cast(t) : py::none(); };

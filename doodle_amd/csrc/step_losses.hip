@@ -137,22 +137,54 @@ step_losses_partial(int B, int N, int R, int chunks, const float* __restrict__ i
 }
 
 // one workgroup: out[0..3] = mse, dist, bound, alignment_loss; out[4] = 1 if any of the first
-// three is NaN/Inf else 0 (the reference's six asserts, :495-501, in one flag); mae[b]
+// three is NaN/Inf else 0 (the reference's six asserts, :495-501, in one flag); mae[b];
+// keep[b] = 1, or — use_error_mask, :444-447 — 1 only for the images whose mean error exceeds
+// torch.quantile(mae, 1 - ratio) (linear interpolation between order statistics; B <= 4096)
+constexpr int SL_MAX_MASK_B = 4096;
+
 __global__ void __launch_bounds__(SL_THREADS)
-step_losses_final(int B, int N, int R, int chunks, int ray_wgs, const float* __restrict__ part_img,
-                  const float* __restrict__ part_ray, float* __restrict__ out, float* __restrict__ mae) {
+step_losses_final(int B, int N, int R, int chunks, int ray_wgs, float mask_ratio, const float* __restrict__ part_img,
+                  const float* __restrict__ part_ray, float* __restrict__ out, float* __restrict__ mae,
+                  float* __restrict__ keep) {
     __shared__ double red[4][SL_THREADS];
+    __shared__ float smae[SL_MAX_MASK_B];
+    __shared__ float order[2];
     const int tid = threadIdx.x;
-    double sq = 0, ds = 0, sa = 0, sb = 0;
     const double P = (double)R * R;
+    const bool masked = mask_ratio >= 0.0f;
     for (int b = tid; b < B; b += SL_THREADS) {
-        double bsq = 0, bab = 0, bds = 0;
-        for (int c = 0; c < chunks; ++c) {
-            const float* p = part_img + 3l * ((long)b * chunks + c);
-            bsq += p[0]; bab += p[1]; bds += p[2];
+        double bab = 0;
+        for (int c = 0; c < chunks; ++c) bab += part_img[3l * ((long)b * chunks + c) + 1];
+        const float m = (float)(bab / P);
+        mae[b] = m;
+        if (masked) smae[b] = m;
+    }
+    float cutoff = 0.0f;
+    if (masked) {
+        // torch.quantile(mae, q): rank = q (B-1); lerp between the two neighbouring order statistics
+        const float pos = (1.0f - mask_ratio) * (float)(B - 1);
+        const int lo = (int)floorf(pos), hi = (int)ceilf(pos);
+        __syncthreads();
+        for (int b = tid; b < B; b += SL_THREADS) {
+            const float v = smae[b];
+            int rank = 0;
+            for (int j = 0; j < B; ++j) rank += (smae[j] < v) || (smae[j] == v && j < b);
+            if (rank == lo) order[0] = v;
+            if (rank == hi) order[1] = v;
         }
-        mae[b] = (float)(bab / P);
-        sq += bsq; ds += bds;
+        __syncthreads();
+        const float w = pos - (float)lo;
+        cutoff = w < 0.5f ? order[0] + w * (order[1] - order[0]) : order[1] - (order[1] - order[0]) * (1.0f - w);
+    }
+    double sq = 0, ds = 0, sa = 0, sb = 0;
+    for (int b = tid; b < B; b += SL_THREADS) {
+        const float k = (!masked || mae[b] > cutoff) ? 1.0f : 0.0f;
+        keep[b] = k;
+        if (k != 0.0f)
+            for (int c = 0; c < chunks; ++c) {
+                const float* p = part_img + 3l * ((long)b * chunks + c);
+                sq += p[0]; ds += p[2];
+            }
     }
     for (int w = tid; w < ray_wgs; w += SL_THREADS) { sa += part_ray[2l * w]; sb += part_ray[2l * w + 1]; }
     red[0][tid] = sq; red[1][tid] = ds; red[2][tid] = sa; red[3][tid] = sb;
@@ -182,6 +214,7 @@ step_losses_bwd(int B, int N, int R, int chunks, const float* __restrict__ img,
                 const float* __restrict__ helios, LossGeom g,
                 const float* __restrict__ g_mse, const float* __restrict__ g_dist,
                 const float* __restrict__ g_bound, const float* __restrict__ g_align,
+                const float* __restrict__ keep,
                 float* __restrict__ grad_img, float* __restrict__ grad_actual, float* __restrict__ grad_action) {
     const int img_wgs = grad_img ? B * chunks : 0;
     const int tid = threadIdx.x;
@@ -189,8 +222,9 @@ step_losses_bwd(int B, int N, int R, int chunks, const float* __restrict__ img,
         const int b = blockIdx.x / chunks, ch = blockIdx.x % chunks;
         const long P = (long)R * R, base = (long)b * P;
         const float s = tx[b];
-        const float km = (g_mse ? *g_mse : 0.0f) * 2.0f / ((float)B * (float)P);   // d mean(d²)
-        const float kd = (g_dist ? *g_dist : 0.0f) / (float)B;                      // d mean_b Σ e·dm
+        const float kb = keep ? keep[b] : 1.0f;                                     // error mask (0/1, constant)
+        const float km = kb * (g_mse ? *g_mse : 0.0f) * 2.0f / ((float)B * (float)P);   // d mean(d²)
+        const float kd = kb * (g_dist ? *g_dist : 0.0f) / (float)B;                      // d mean_b Σ e·dm
         auto one = [&](float x, float y, float dm) -> float {
             const float d = x / s - y / s;
             const float sg = d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f);
@@ -241,7 +275,9 @@ step_losses_bwd(int B, int N, int R, int chunks, const float* __restrict__ img,
                 const float gt = gxl * v[0] + gyl * v[2];
                 gv[0] = gxl * r.t; gv[2] = gyl * r.t;
                 // t = (tp·v) / den ; den = -(v·tn) (+1e-6)
-                const float gnum = gt / r.den, gden = -gt * r.t / r.den;
+                // torch's div backward associates as grad·((num/den)/den); keep that order: with the
+                // reference's target (position ∥ normal) t is a constant and the two terms below cancel
+                const float gnum = gt / r.den, gden = -(gt * (r.t / r.den));
 #pragma unroll
                 for (int k = 0; k < 3; ++k) gv[k] += gnum * g.tp[k] - gden * g.tn[k];
             }
@@ -259,35 +295,36 @@ static LossGeom make_geom(const float* tp, const float* tn, float W, float H, in
     return g;
 }
 
+int step_losses_max_mask_batch() { return SL_MAX_MASK_B; }
 int step_losses_chunks(int R) { return (int)(((long)R * R + SL_PIX_PER_WG - 1) / SL_PIX_PER_WG); }
 int step_losses_ray_wgs(int B, int N) { return (int)(((long)B * N + SL_RAYS_PER_WG - 1) / SL_RAYS_PER_WG); }
 
 void launch_step_losses_fwd(int B, int N, int R, const float* img, const float* target, const float* tx,
                             const float* dmaps, const float* ideal, const float* actual, const float* action,
                             const float* helios, const float* tp, const float* tn, float W, float H,
-                            int exponential_risk, float* workspace, float* out, float* mae, float* align_err,
-                            float* all_bounds, hipStream_t st) {
+                            int exponential_risk, float mask_ratio, float* workspace, float* out, float* mae,
+                            float* keep, float* align_err, float* all_bounds, hipStream_t st) {
     const int chunks = step_losses_chunks(R), rw = step_losses_ray_wgs(B, N);
     float* part_img = workspace;
     float* part_ray = workspace + 3l * B * chunks;
     hipLaunchKernelGGL(step_losses_partial, dim3(B * chunks + rw), dim3(SL_THREADS), 0, st, B, N, R, chunks, img,
                        target, tx, dmaps, ideal, actual, action, helios, make_geom(tp, tn, W, H, exponential_risk),
                        part_img, part_ray, align_err, all_bounds);
-    hipLaunchKernelGGL(step_losses_final, dim3(1), dim3(SL_THREADS), 0, st, B, N, R, chunks, rw, part_img, part_ray,
-                       out, mae);
+    hipLaunchKernelGGL(step_losses_final, dim3(1), dim3(SL_THREADS), 0, st, B, N, R, chunks, rw, mask_ratio, part_img,
+                       part_ray, out, mae, keep);
 }
 
 void launch_step_losses_bwd(int B, int N, int R, const float* img, const float* target, const float* tx,
                             const float* dmaps, const float* ideal, const float* actual, const float* action,
                             const float* helios, const float* tp, const float* tn, float W, float H,
                             int exponential_risk, const float* g_mse, const float* g_dist, const float* g_bound,
-                            const float* g_align, float* grad_img, float* grad_actual, float* grad_action,
-                            hipStream_t st) {
+                            const float* g_align, const float* keep, float* grad_img, float* grad_actual,
+                            float* grad_action, hipStream_t st) {
     const int chunks = step_losses_chunks(R), rw = step_losses_ray_wgs(B, N);
     const int grid = (grad_img ? B * chunks : 0) + rw;
     hipLaunchKernelGGL(step_losses_bwd, dim3(grid), dim3(SL_THREADS), 0, st, B, N, R, chunks, img, target, tx, dmaps,
                        ideal, actual, action, helios, make_geom(tp, tn, W, H, exponential_risk), g_mse, g_dist,
-                       g_bound, g_align, grad_img, grad_actual, grad_action);
+                       g_bound, g_align, keep, grad_img, grad_actual, grad_action);
 }
 
 }  // namespace helio

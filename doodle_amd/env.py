@@ -235,15 +235,16 @@ class HelioEnv(_EnvBase):
         """
         if isinstance(action, np.ndarray):
             action = torch.tensor(action, dtype=torch.float32, device=self.device)
-        if self.use_error_mask:
-            return self._step_torch(action)
+        if self.use_error_mask and self.batch_size > 4096:
+            return self._step_torch(action)         # the fused quantile handles B <= 4096
         ideal, target, tx = self._reference()
         img, actual, reflected = self.noisy_field.render(self.sun_pos, action, ideal, monitor=True)
         aux = torch.cat([self.sun_pos.detach(), action.flatten(1)], dim=1)
         normals = action.view(self.batch_size, -1, 3)                    # :460
         consts = StepConstants(target, tx, self.distance_maps, ideal, self.noisy_field.heliostat_positions,
                                self._tp3, self._tn3, float(self.targ_area[0]), float(self.targ_area[1]),
-                               bool(self.exponential_risk))
+                               bool(self.exponential_risk),
+                               float(self.error_mask_ratio) if self.use_error_mask else -1.0)
         mse, dist_l, bound, alignment_loss, mae, angles, all_bounds, flag = step_losses(img, actual, normals, consts)
         if self.check_finite and bool(flag):                             # :495-501, one sync instead of six
             raise AssertionError("MSE, distance loss or boundary loss is NaN or Inf")
@@ -260,8 +261,8 @@ class HelioEnv(_EnvBase):
         return obs, metrics, monitor
 
     def _step_torch(self, action):
-        """The ``use_error_mask=True`` branch (:444-452, torch.quantile), kept as torch ops on
-        the device around the two HIP renders."""
+        """The loss block as torch ops on the device (:427-488) around the two HIP renders: only
+        for ``use_error_mask`` with more than 4096 suns, which the fused quantile does not cover."""
         ideal = self.ref_field.calculate_ideal_normals(self.sun_pos)
         img, actual, reflected = self.noisy_field.render(self.sun_pos, action, ideal, monitor=True)
         aux = torch.cat([self.sun_pos.detach(), action.flatten(1)], dim=1)

@@ -29,25 +29,26 @@ class StepConstants:
     W: float
     H: float
     exp_risk: bool
+    mask_ratio: float = -1.0  # use_error_mask: fraction of worst images kept (< 0: no mask)
 
 
 class _StepLosses(torch.autograd.Function):
     @staticmethod
     def forward(ctx, img, actual, action, consts):
-        out, mae, align, allb = _field._get_ops().step_losses_fwd(img, actual, action, consts)
+        out, mae, align, allb, keep = _field._get_ops().step_losses_fwd(img, actual, action, consts)
         ctx.consts = consts
-        ctx.save_for_backward(img, actual, action)
+        ctx.save_for_backward(img, actual, action, keep)
         flag = out[4]
         ctx.mark_non_differentiable(mae, align, allb, flag)
         return out[0], out[1], out[2], out[3], mae, align, allb, flag
 
     @staticmethod
     def backward(ctx, g_mse, g_dist, g_bound, g_align, *_unused):
-        img, actual, action = ctx.saved_tensors
+        img, actual, action, keep = ctx.saved_tensors
         want = ctx.needs_input_grad
         c = lambda g: g.contiguous() if g is not None else None  # noqa: E731
         gi, ga, gn = _field._get_ops().step_losses_bwd(
-            img, actual, action, ctx.consts, c(g_mse), c(g_dist), c(g_bound), c(g_align),
+            img, actual, action, ctx.consts, c(g_mse), c(g_dist), c(g_bound), c(g_align), keep,
             want[0] and (g_mse is not None or g_dist is not None), want[1] and g_align is not None,
             want[2] and g_bound is not None)
         return gi, ga, gn, None
@@ -58,5 +59,5 @@ def step_losses(img, actual, action, consts: StepConstants):
     img, actual, action = img.contiguous(), actual.contiguous(), action.contiguous()
     if torch.is_grad_enabled() and (img.requires_grad or actual.requires_grad or action.requires_grad):
         return _StepLosses.apply(img, actual, action, consts)
-    out, mae, align, allb = _field._get_ops().step_losses_fwd(img, actual, action, consts)
+    out, mae, align, allb, _ = _field._get_ops().step_losses_fwd(img, actual, action, consts)
     return out[0], out[1], out[2], out[3], mae, align, allb, out[4]

@@ -66,8 +66,8 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
         "helio_distance_maps_workspace": (_l, [_i, _i]),
         "helio_distance_maps": (_i, [_i, _i, _vp, _f, _vp, _vp, _vp]),
         "helio_step_losses_workspace": (_l, [_i, _i, _i]),
-        "helio_step_losses_fwd": (_i, [_i, _i, _i] + [_vp] * 8 + [_f3, _f3, _f, _f, _i] + [_vp] * 5 + [_vp]),
-        "helio_step_losses_bwd": (_i, [_i, _i, _i] + [_vp] * 8 + [_f3, _f3, _f, _f, _i] + [_vp] * 4 + [_vp] * 3 + [_vp]),
+        "helio_step_losses_fwd": (_i, [_i, _i, _i] + [_vp] * 8 + [_f3, _f3, _f, _f, _i, _f] + [_vp] * 6 + [_vp]),
+        "helio_step_losses_bwd": (_i, [_i, _i, _i] + [_vp] * 8 + [_f3, _f3, _f, _f, _i] + [_vp] * 5 + [_vp] * 3 + [_vp]),
     }
     for name, (res, args) in protos.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
@@ -257,31 +257,34 @@ class HipOps:
 
     # -- HelioEnv.step loss block --------------------------------------------------------------
     def step_losses_fwd(self, img, actual, action, c):
-        """``c``: the env's per-sun constants (target, tx, dmaps, ideal, helios, tp, tn, W, H, exp_risk).
-        Returns out[5] = (mse, dist, bound, alignment_loss, nonfinite flag), mae [B],
-        alignment errors [B,N] (mrad), boundary terms [B,N]."""
+        """``c``: the env's per-sun constants (target, tx, dmaps, ideal, helios, tp, tn, W, H, exp_risk,
+        mask_ratio).  Returns out[5] = (mse, dist, bound, alignment_loss, nonfinite flag), mae [B],
+        alignment errors [B,N] (mrad), boundary terms [B,N], keep [B] (the 0/1 error mask)."""
         if self.hb is not None:
             return self.hb.step_losses_fwd(img, c.target, c.tx, c.dmaps, c.ideal, actual, action, c.helios,
-                                           list(c.tp), list(c.tn), c.W, c.H, bool(c.exp_risk))
+                                           list(c.tp), list(c.tn), c.W, c.H, bool(c.exp_risk), float(c.mask_ratio))
         B, N, R = action.shape[0], action.shape[1], img.shape[-1]
         dev = img.device
         ws = torch.empty(self.lib.helio_step_losses_workspace(B, N, R), dtype=torch.float32, device=dev)
         out = torch.empty(5, dtype=torch.float32, device=dev)
         mae = torch.empty(B, dtype=torch.float32, device=dev)
+        keep = torch.empty(B, dtype=torch.float32, device=dev)
         align = torch.empty((B, N), dtype=torch.float32, device=dev)
         allb = torch.empty((B, N), dtype=torch.float32, device=dev)
         _check(self.lib, self.lib.helio_step_losses_fwd(
             B, N, R, _dev(img), _dev(c.target), _dev(c.tx), _dev(c.dmaps), _dev(c.ideal), _dev(actual),
-            _dev(action), _dev(c.helios), c.tp, c.tn, c.W, c.H, int(c.exp_risk),
-            ws.data_ptr(), out.data_ptr(), mae.data_ptr(), align.data_ptr(), allb.data_ptr(), _stream()))
-        return out, mae, align, allb
+            _dev(action), _dev(c.helios), c.tp, c.tn, c.W, c.H, int(c.exp_risk), float(c.mask_ratio),
+            ws.data_ptr(), out.data_ptr(), mae.data_ptr(), keep.data_ptr(), align.data_ptr(), allb.data_ptr(),
+            _stream()))
+        return out, mae, align, allb, keep
 
-    def step_losses_bwd(self, img, actual, action, c, g_mse, g_dist, g_bound, g_align, want_img, want_actual,
+    def step_losses_bwd(self, img, actual, action, c, g_mse, g_dist, g_bound, g_align, keep, want_img, want_actual,
                         want_action):
         if self.hb is not None:
             return self.hb.step_losses_bwd(img, c.target, c.tx, c.dmaps, c.ideal, actual, action, c.helios,
                                            list(c.tp), list(c.tn), c.W, c.H, bool(c.exp_risk), g_mse, g_dist,
-                                           g_bound, g_align, bool(want_img), bool(want_actual), bool(want_action))
+                                           g_bound, g_align, keep, bool(want_img), bool(want_actual),
+                                           bool(want_action))
         B, N, R = action.shape[0], action.shape[1], img.shape[-1]
         grad_img = torch.empty_like(img) if want_img else None
         grad_actual = torch.empty_like(actual) if want_actual else None
@@ -290,7 +293,7 @@ class HipOps:
         _check(self.lib, self.lib.helio_step_losses_bwd(
             B, N, R, _dev(img), _dev(c.target), _dev(c.tx), _dev(c.dmaps), _dev(c.ideal), _dev(actual),
             _dev(action), _dev(c.helios), c.tp, c.tn, c.W, c.H, int(c.exp_risk),
-            ptr(g_mse), ptr(g_dist), ptr(g_bound), ptr(g_align), ptr(grad_img), ptr(grad_actual),
+            ptr(g_mse), ptr(g_dist), ptr(g_bound), ptr(g_align), ptr(keep), ptr(grad_img), ptr(grad_actual),
             ptr(grad_action), _stream()))
         return grad_img, grad_actual, grad_action
 

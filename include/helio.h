@@ -180,15 +180,18 @@ int helio_ideal_normals(int B, int N, const float *helios_d, const float *sun_d,
  * ---- HelioEnv.step loss block (SURVEY.md §8 f) -------------------------------------------
  * Replaces test_environment.py :436-457 (peak-normalised MSE, EDT-weighted distance loss,
  * per-image mean error), :101-130 + :460-488 (boundary loss with the axes step() passes:
- * east (1,0,0), up (0,0,1)) and :132-155 + :450-455 (alignment loss) — the
- * use_error_mask=False branch.  Two launches forward, one backward; fixed-order reductions.
+ * east (1,0,0), up (0,0,1)) and :132-155 + :450-455 (alignment loss).  error_mask_ratio < 0:
+ * the use_error_mask=False branch; otherwise (:444-452, B <= 4096) only images whose mean error
+ * exceeds torch.quantile(mean errors, 1 - ratio) enter mse and dist.
+ * Two launches forward, one backward; fixed-order reductions.
  *
  *   img_d, target_d, dmaps_d [B,R,R]   tx_d [B] = clamp_min(amax(target[b]), 1e-6)  (:436)
  *   ideal_d, actual_d, action_d [B,N,3]   helios_d [N,3]
  *   workspace_d: helio_step_losses_workspace(B,N,R) floats
  *   out_d [5] = (mse, dist, bound, alignment_loss, flag) with flag = 1 if mse, dist or bound
  *               is NaN/Inf (the asserts of :495-501)
- *   mae_d [B] (monitor 'mae_image'), align_err_d [B,N] (mrad), all_bounds_d [B,N]
+ *   mae_d [B] (monitor 'mae_image'), keep_d [B] (the 0/1 error mask; all ones without it),
+ *   align_err_d [B,N] (mrad), all_bounds_d [B,N]
  */
 long helio_step_losses_workspace(int B, int N, int R);
 
@@ -204,11 +207,12 @@ int helio_step_losses_fwd(int B, int N, int R,
                           const float *img_d, const float *target_d, const float *tx_d, const float *dmaps_d,
                           const float *ideal_d, const float *actual_d, const float *action_d,
                           const float *helios_d, const float target_position[3], const float target_normal[3],
-                          float width, float height, int exponential_risk,
-                          float *workspace_d, float *out_d, float *mae_d, float *align_err_d, float *all_bounds_d,
-                          void *stream);
+                          float width, float height, int exponential_risk, float error_mask_ratio,
+                          float *workspace_d, float *out_d, float *mae_d, float *keep_d, float *align_err_d,
+                          float *all_bounds_d, void *stream);
 /*
- * Backward: g_*_d are DEVICE scalars (cotangents of the four losses; NULL = none);
+ * Backward: g_*_d are DEVICE scalars (cotangents of the four losses; NULL = none); keep_d is
+ * the mask the forward wrote (NULL = all ones);
  * grad_img_d [B,R,R], grad_actual_d [B,N,3] (through the alignment loss), grad_action_d
  * [B,N,3] (through the boundary loss); any output may be NULL.
  */
@@ -218,6 +222,7 @@ int helio_step_losses_bwd(int B, int N, int R,
                           const float *helios_d, const float target_position[3], const float target_normal[3],
                           float width, float height, int exponential_risk,
                           const float *g_mse_d, const float *g_dist_d, const float *g_bound_d, const float *g_align_d,
+                          const float *keep_d,
                           float *grad_img_d, float *grad_actual_d, float *grad_action_d, void *stream);
 
 #ifdef __cplusplus

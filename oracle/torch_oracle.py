@@ -233,16 +233,24 @@ def boundary_all(vects, heliostat_pos, targ_pos, targ_norm, targ_area):
 
 
 def step_losses(img, target, distance_maps, ideal, actual, action, heliostat_pos, targ_pos, targ_norm,
-                targ_area, exponential_risk: bool = False):
-    """The use_error_mask=False branch of HelioEnv.step, test_environment.py:436-488.
+                targ_area, exponential_risk: bool = False, error_mask_ratio=None):
+    """The loss block of HelioEnv.step, test_environment.py:436-488; ``error_mask_ratio`` selects
+    the use_error_mask=True branch (:444-452: only the worst images, by torch.quantile of their
+    mean error, enter mse and dist).
     Returns (mse, dist, bound, alignment_loss, mae_image [B], all_bounds [B,N], angles [B,N])."""
     tx = target.amax((1, 2), keepdim=True).clamp_min(1e-6)
     pred_n, targ_n = img / tx, target / tx
     err = (pred_n - targ_n).abs()
     mae = err.mean(dim=[-2, -1])
     ang = angles_mrad(ideal, actual)
-    mse = torch.nn.functional.mse_loss(pred_n, targ_n)
-    dist_l = (err * distance_maps).sum((1, 2)).mean()
+    if error_mask_ratio is None:
+        mse = torch.nn.functional.mse_loss(pred_n, targ_n)
+        dist_l = (err * distance_maps).sum((1, 2)).mean()
+    else:
+        cutoff = torch.quantile(mae, 1 - error_mask_ratio)
+        keep = (mae > cutoff).float().unsqueeze(-1).unsqueeze(-1)
+        mse = torch.nn.functional.mse_loss(pred_n * keep, targ_n * keep)
+        dist_l = (keep * (err * distance_maps)).sum((1, 2)).mean()
     normals = action.view(img.shape[0], -1, 3)
     allb = boundary_all(normals, heliostat_pos, targ_pos, targ_norm, targ_area)
     bound = torch.mean(torch.exp(allb + 1e-6)) if exponential_risk else allb.mean()

@@ -275,14 +275,15 @@ def make_env_golden(helios, suns):
     sys.modules["gymnasium"], sys.modules["gymnasium.spaces"] = gym, spaces
     import test_environment as refenv  # noqa: E402
 
-    for tag, sig, err in (("train", 0.01, 90.0), ("readme", 0.1, 180.0)):
+    for tag, sig, err, masked in (("train", 0.01, 90.0, False), ("readme", 0.1, 180.0, False),
+                                  ("mask", 0.02, 60.0, True)):
         torch.manual_seed(21)
         env = refenv.HelioEnv(
             heliostat_pos=helios, targ_pos=torch.tensor([0.0, -5.0, 0.0]),
             targ_area=(15.0, 15.0), targ_norm=torch.tensor([0.0, 1.0, 0.0]),
             sigma_scale=sig, error_scale_mrad=err, initial_action_noise=0.0,
             resolution=64, batch_size=25, device="cpu",
-            new_errors_every_reset=False)
+            new_errors_every_reset=False, use_error_mask=masked, error_mask_ratio=0.2)
         cone_suns = env.sun_pos.clone()
         env.set_sun_pos(suns)
         obs0 = env.reset()

@@ -106,15 +106,16 @@ class OracleOps:
     @staticmethod
     def _losses(img, actual, action, c):
         return to.step_losses(img, c.target, c.dmaps, c.ideal, actual, action, c.helios,
-                              torch.tensor(list(c.tp)), torch.tensor(list(c.tn)), (c.W, c.H), c.exp_risk)
+                              torch.tensor(list(c.tp)), torch.tensor(list(c.tn)), (c.W, c.H), c.exp_risk,
+                              c.mask_ratio if c.mask_ratio >= 0 else None)
 
     def step_losses_fwd(self, img, actual, action, c):
         with torch.no_grad():
             mse, dist, bound, align, mae, allb, ang = self._losses(img, actual, action, c)
         bad = ~torch.isfinite(torch.stack([mse, dist, bound])).all()
-        return torch.stack([mse, dist, bound, align, bad.float()]), mae, ang, allb
+        return torch.stack([mse, dist, bound, align, bad.float()]), mae, ang, allb, torch.ones_like(mae)
 
-    def step_losses_bwd(self, img, actual, action, c, g_mse, g_dist, g_bound, g_align, want_img, want_actual,
+    def step_losses_bwd(self, img, actual, action, c, g_mse, g_dist, g_bound, g_align, keep, want_img, want_actual,
                         want_action):
         with torch.enable_grad():
             i, a, n = (t.detach().clone().requires_grad_(True) for t in (img, actual, action))

@@ -69,14 +69,15 @@ def test_abi_size_limits_fail_cleanly():
         native.get_ops().splat_fwd(torch.zeros(1, 2, 4), f._xs, f._ys)
 
 
-@pytest.mark.parametrize("tag", ["train", "readme"])
+@pytest.mark.parametrize("tag", ["train", "readme", "mask"])
 def test_env_matches_reference_fixture(tag):
     from doodle_amd.env import HelioEnv
     g = golden(f"g6_env_{tag}_n50_b25_r64")
     env = HelioEnv(heliostat_pos=torch.from_numpy(g["helios"]).to(DEV), targ_pos=torch.tensor([0.0, -5.0, 0.0], device=DEV),
                    targ_area=(15.0, 15.0), targ_norm=torch.tensor([0.0, 1.0, 0.0], device=DEV),
                    sigma_scale=float(g["sigma_scale"]), error_scale_mrad=float(g["error_scale_mrad"]),
-                   initial_action_noise=0.0, resolution=64, batch_size=25, device=DEV, new_errors_every_reset=False)
+                   initial_action_noise=0.0, resolution=64, batch_size=25, device=DEV, new_errors_every_reset=False,
+                   use_error_mask=(tag == "mask"), error_mask_ratio=0.2)
     env.noisy_field.error_angles_mrad = torch.from_numpy(g["error_angles_mrad"])
     env.noisy_field.batch_error_angles_mrad = torch.from_numpy(g["batch_error_angles_mrad"])
     env.set_sun_pos(torch.from_numpy(g["suns"]).to(DEV))
@@ -253,8 +254,11 @@ def test_rccl_gather_single_rank_process_group():
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("B,N,R,exp_risk", [(3, 7, 33, False), (25, 50, 128, False), (5, 300, 64, True), (2, 1, 1, False)])
-def test_fused_step_losses_against_oracle(B, N, R, exp_risk):
+@pytest.mark.parametrize("B,N,R,exp_risk,mask", [(3, 7, 33, False, None), (25, 50, 128, False, None),
+                                                  (5, 300, 64, True, None), (2, 1, 1, False, None),
+                                                  (25, 50, 64, False, 0.2), (40, 9, 31, False, 0.35),
+                                                  (300, 3, 16, False, 0.1)])
+def test_fused_step_losses_against_oracle(B, N, R, exp_risk, mask):
     """helio_step_losses_fwd/bwd vs the oracle's restatement of the reference's loss block
     (oracle/torch_oracle.step_losses, itself bit-exact with the reference env on CPU)."""
     import ctypes
@@ -275,13 +279,14 @@ def test_fused_step_losses_against_oracle(B, N, R, exp_risk):
     area = (1.5, 1.2) if exp_risk else (15.0, 12.0)
     # oracle (CPU)
     ci, ca, cn = (t.clone().requires_grad_(True) for t in (img, actual, action))
-    ref = to.step_losses(ci, target, dmaps, ideal, ca, cn, helios, tp, tn, area, exp_risk)
+    ref = to.step_losses(ci, target, dmaps, ideal, ca, cn, helios, tp, tn, area, exp_risk, mask)
     w = [0.7, 1.3, -0.4, 2.1]
     gi_o, ga_o, gn_o = torch.autograd.grad(sum(wi * r for wi, r in zip(w, ref[:4])), (ci, ca, cn))
     # HIP
     f3 = ctypes.c_float * 3
     c = StepConstants(target.to(DEV), target.amax((1, 2)).clamp_min(1e-6).to(DEV), dmaps.to(DEV), ideal.to(DEV),
-                      helios.to(DEV), f3(*tp.tolist()), f3(*tn.tolist()), area[0], area[1], exp_risk)
+                      helios.to(DEV), f3(*tp.tolist()), f3(*tn.tolist()), area[0], area[1], exp_risk,
+                      -1.0 if mask is None else mask)
     di, da, dn = (t.to(DEV).requires_grad_(True) for t in (img, actual, action))
     out = step_losses(di, da, dn, c)
     for k in range(4):
@@ -295,10 +300,12 @@ def test_fused_step_losses_against_oracle(B, N, R, exp_risk):
     for got, want, tol in ((gi, gi_o, 1e-4), (ga, ga_o, 3e-2), (gn, gn_o, 1e-4)):
         scale = max(want.abs().max().item(), 1e-30)
         assert (got.cpu() - want).abs().max().item() <= tol * scale
-    # a NaN in the image raises the flag
-    bad = img.clone()
-    bad[0, 0, 0] = float("nan")
-    assert step_losses(bad.to(DEV), da.detach(), dn.detach(), c)[7].item() == 1.0
+    # a NaN in the image raises the flag (without the error mask: with it a NaN image is masked
+    # out of mse and dist in the reference as well, since NaN > cutoff is false)
+    if mask is None:
+        bad = img.clone()
+        bad[0, 0, 0] = float("nan")
+        assert step_losses(bad.to(DEV), da.detach(), dn.detach(), c)[7].item() == 1.0
 
 
 @pytest.mark.parametrize("B,R", [(3, 17), (25, 128), (2, 300), (1, 1)])

@@ -212,7 +212,7 @@ def test_init_actions(monkeypatch):
 
 
 # ------------------------------------------------------------------ HelioEnv
-@pytest.mark.parametrize("tag", ["train", "readme"])
+@pytest.mark.parametrize("tag", ["train", "readme", "mask"])
 def test_env_reset_step_match_reference(tag, monkeypatch):
     oracle_backend.install(monkeypatch)
     from doodle_amd.env import HelioEnv
@@ -222,7 +222,7 @@ def test_env_reset_step_match_reference(tag, monkeypatch):
                    targ_area=(15.0, 15.0), targ_norm=torch.tensor([0.0, 1.0, 0.0]),
                    sigma_scale=float(g["sigma_scale"]), error_scale_mrad=float(g["error_scale_mrad"]),
                    initial_action_noise=0.0, resolution=64, batch_size=25, device="cpu",
-                   new_errors_every_reset=False)
+                   new_errors_every_reset=False, use_error_mask=(tag == "mask"), error_mask_ratio=0.2)
     # same seed, same RNG call order → same cone suns and the same error tensors
     assert np.array_equal(env.sun_pos.numpy(), g["cone_suns"])
     assert np.array_equal(env.noisy_field.batch_error_angles_mrad.numpy(), g["batch_error_angles_mrad"])

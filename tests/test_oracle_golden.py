@@ -127,7 +127,7 @@ def test_tiny_scene_properties():
 import pytest as _pytest
 
 
-@_pytest.mark.parametrize("tag", ["train", "readme"])
+@_pytest.mark.parametrize("tag", ["train", "readme", "mask"])
 def test_step_loss_oracle_matches_reference_env(tag):
     """oracle.step_losses on the reference's recorded step() inputs reproduces its metrics,
     monitors and gradients bit for bit (same ATen ops in the same order)."""
@@ -143,7 +143,7 @@ def test_step_loss_oracle_matches_reference_env(tag):
     with torch.no_grad():
         target, _ = to.render(sc, suns, ideal.flatten(1), torch.zeros_like(errs))
     out = to.step_losses(img, target, torch.from_numpy(g["distance_maps"]), ideal, actual, act, helios, tp, tn,
-                         (15.0, 15.0))
+                         (15.0, 15.0), error_mask_ratio=0.2 if tag == "mask" else None)
     names = ("mse", "dist", "bound", "alignment_loss")
     for k, v in zip(names, out[:4]):
         assert np.array_equal(v.detach().numpy(), g["metric_" + k]), k
