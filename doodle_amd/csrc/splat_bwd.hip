@@ -156,9 +156,8 @@ __global__ void __launch_bounds__(1024)
 splat_bwd_mfma(int B, int N, int R, const float* __restrict__ rays, const float* __restrict__ xs,
                const float* __restrict__ ys, const float* __restrict__ gimg, float* __restrict__ moments) {
     constexpr int KC = 64, T = 256, LD = T + 1;
-    extern __shared__ __attribute__((aligned(16))) float smem[];   // sG[KC][LD] sF[KC][LD] ccoord[T] kcoord[KC]
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // sG[KC][LD] sF[KC][LD] ccoord[T]
     float* __restrict__ sCc = smem + 2 * KC * LD;
-    float* __restrict__ sKc = sCc + T;
 
     const int c_tiles = (R + T - 1) / T;
     const int b = blockIdx.y;
@@ -223,24 +222,23 @@ splat_bwd_mfma(int B, int N, int R, const float* __restrict__ rays, const float*
     asm volatile("" : "+v"(pg1));
     asm volatile("" : "+v"(pf1));
 
+    // the 16 contraction coordinates a wave needs per chunk are wave-uniform: scalar loads, no
+    // LDS staging (and one barrier fewer per chunk)
+    const int upk0 = __builtin_amdgcn_readfirstlane(pk0);
     load_slab(0);
     for (int k0 = 0; k0 < R; k0 += KC) {
+        float kc[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) kc[j] = kcoord[min(k0 + upk0 + j, R - 1)];
         __syncthreads();                                   // previous chunk consumed
         store_slab();
-        if (tid < KC) sKc[tid] = kcoord[min(k0 + tid, R - 1)];
-        __syncthreads();                                   // coordinates of this chunk visible
         if (k0 + KC < R) load_slab(k0 + KC);               // in flight during the chunk
 #pragma unroll
-        for (int j4 = 0; j4 < 16; j4 += 4) {
-            const float4 cv = *reinterpret_cast<const float4*>(&sKc[pk0 + j4]);
-            const float ca[4] = {cv.x, cv.y, cv.z, cv.w};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float t = __builtin_fmaf(ca[j], sk, fshift);
-                float f = __builtin_amdgcn_exp2f(-__builtin_fmaf(t, t, fcc));
-                if (k0 + pk0 + j4 + j >= R) f = 0.0f;      // rows/cols past the image contract nothing
-                fdst[(j4 + j) * LD] = f;
-            }
+        for (int j = 0; j < 16; ++j) {
+            const float t = __builtin_fmaf(kc[j], sk, fshift);
+            float f = __builtin_amdgcn_exp2f(-__builtin_fmaf(t, t, fcc));
+            if (k0 + upk0 + j >= R) f = 0.0f;              // rows/cols past the image contract nothing
+            fdst[j * LD] = f;
         }
         __syncthreads();
 #pragma unroll
