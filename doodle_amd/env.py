@@ -21,7 +21,7 @@ import torch.nn.functional as F
 import ctypes
 
 from .field import HelioField
-from .losses import StepConstants, step_losses
+from .losses import StepConstants, env_step_fused, step_losses
 
 try:  # pragma: no cover - depends on the image
     import gymnasium as _gym
@@ -238,14 +238,20 @@ class HelioEnv(_EnvBase):
         if self.use_error_mask and self.batch_size > 4096:
             return self._step_torch(action)         # the fused quantile handles B <= 4096
         ideal, target, tx = self._reference()
-        img, actual, reflected = self.noisy_field.render(self.sun_pos, action, ideal, monitor=True)
-        aux = torch.cat([self.sun_pos.detach(), action.flatten(1)], dim=1)
         normals = action.view(self.batch_size, -1, 3)                    # :460
         consts = StepConstants(target, tx, self.distance_maps, ideal, self.noisy_field.heliostat_positions,
                                self._tp3, self._tn3, float(self.targ_area[0]), float(self.targ_area[1]),
                                bool(self.exponential_risk),
                                float(self.error_mask_ratio) if self.use_error_mask else -1.0)
-        mse, dist_l, bound, alignment_loss, mae, angles, all_bounds, flag = step_losses(img, actual, normals, consts)
+        if torch.is_grad_enabled() and action.requires_grad:
+            # render + loss block as one autograd node
+            (img, actual, reflected, mse, dist_l, bound, alignment_loss, mae, angles, all_bounds,
+             flag) = env_step_fused(self.noisy_field, self.sun_pos, normals.contiguous(), consts)
+        else:
+            img, actual, reflected = self.noisy_field.render(self.sun_pos, action, ideal, monitor=True)
+            mse, dist_l, bound, alignment_loss, mae, angles, all_bounds, flag = step_losses(img, actual, normals,
+                                                                                         consts)
+        aux = torch.cat([self.sun_pos.detach(), action.flatten(1)], dim=1)
         if self.check_finite and bool(flag):                             # :495-501, one sync instead of six
             raise AssertionError("MSE, distance loss or boundary loss is NaN or Inf")
         metrics = {"mse": mse, "dist": dist_l, "bound": bound, "alignment_loss": alignment_loss}

@@ -54,6 +54,55 @@ class _StepLosses(torch.autograd.Function):
         return gi, ga, gn, None
 
 
+class _EnvStep(torch.autograd.Function):
+    """render + loss block as ONE autograd node (what HelioEnv.step differentiates): forward =
+    helio_render_fwd + helio_step_losses_fwd, backward = helio_step_losses_bwd + helio_render_bwd.
+    Same kernels as ``_Render`` followed by ``_StepLosses``; it only spares the autograd engine
+    five graph nodes per step (the TTT inner loop of the reference calls step+backward 800 times
+    per optimiser step)."""
+
+    @staticmethod
+    def forward(ctx, normals, field, sun, trig, trig_stride, consts):
+        ops = _field._get_ops()
+        image, actual, refl, rays = ops.render_fwd(field.heliostat_positions, sun, normals, trig, trig_stride,
+                                                   field._plane, field._xs, field._ys)
+        out, mae, align, allb, keep = ops.step_losses_fwd(image, actual, normals, consts)
+        ctx.field, ctx.trig_stride, ctx.consts = field, trig_stride, consts
+        ctx.save_for_backward(normals, sun, trig, rays, image, actual, keep)
+        ctx.set_materialize_grads(False)
+        flag = out[4]
+        ctx.mark_non_differentiable(mae, align, allb, flag)
+        return image, actual, refl, out[0], out[1], out[2], out[3], mae, align, allb, flag
+
+    @staticmethod
+    def backward(ctx, g_image, g_actual, g_refl, g_mse, g_dist, g_bound, g_align, *_unused):
+        normals, sun, trig, rays, image, actual, keep = ctx.saved_tensors
+        field, ops = ctx.field, _field._get_ops()
+        c = lambda g: g.contiguous() if g is not None else None  # noqa: E731
+        need_img = g_mse is not None or g_dist is not None
+        gi = ga = gn = None
+        if need_img or g_align is not None or g_bound is not None:
+            gi, ga, gn = ops.step_losses_bwd(image, actual, normals, ctx.consts, c(g_mse), c(g_dist), c(g_bound),
+                                             c(g_align), keep, need_img, g_align is not None, g_bound is not None)
+        g_image = gi if g_image is None else (g_image if gi is None else g_image + gi)
+        g_actual = ga if g_actual is None else (g_actual if ga is None else g_actual + ga)
+        if g_image is None and g_actual is None and g_refl is None:
+            g = gn
+        else:
+            g = ops.render_bwd(field.heliostat_positions, sun, normals, trig, ctx.trig_stride, field._plane, rays,
+                               field._xs, field._ys, c(g_image), c(g_actual), c(g_refl))
+            if gn is not None:
+                g = g + gn
+        return g, None, None, None, None, None
+
+
+def env_step_fused(field, sun, normals, consts: StepConstants):
+    """One autograd node for HelioEnv.step: → (image, actual, refl [B,N,3], mse, dist, bound,
+    alignment_loss, mae [B], angles [B,N], all_bounds [B,N], flag)."""
+    trig, stride = field._select_trig(sun.shape[0])
+    return _EnvStep.apply(normals, field, sun, trig, stride, consts)
+
+
 def step_losses(img, actual, action, consts: StepConstants):
     """→ (mse, dist, bound, alignment_loss, mae [B], angles [B,N], all_bounds [B,N], flag)."""
     img, actual, action = img.contiguous(), actual.contiguous(), action.contiguous()
