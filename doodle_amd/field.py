@@ -88,15 +88,16 @@ class HelioField:
 
         self.error_scale_mrad = float(error_scale_mrad)
         self.initial_action_noise = float(initial_action_noise)
-        self.sigma_scale = float(sigma_scale)
+        self._sigma_scale = float(sigma_scale)
         self.resolution = int(resolution)
 
         # native-side constants: receiver frame (w = u × v closes the orthonormal
         # frame of the separable footprint) and the pixel coordinates of :129-130
         w = torch.linalg.cross(u.double(), v.double()).float()
         tp = self.target_position.detach().cpu()
-        self._plane = native.Plane(tuple(tp.tolist()), tuple(tn.tolist()), tuple(u.tolist()),
-                                   tuple(v.tolist()), tuple(w.tolist()), self.sigma_scale)
+        self._plane_vectors = (tuple(tp.tolist()), tuple(tn.tolist()), tuple(u.tolist()), tuple(v.tolist()),
+                               tuple(w.tolist()))
+        self._plane = native.Plane(*self._plane_vectors, self._sigma_scale)
         self._target_xyz = tuple(tp.tolist())
         self._xs = torch.linspace(-self.target_width / 2, self.target_width / 2, self.resolution).to(self.device)
         self._ys = torch.linspace(-self.target_height / 2, self.target_height / 2, self.resolution).to(self.device)
@@ -105,6 +106,16 @@ class HelioField:
         self._ray_ws = None
         self.reset_errors()
         self.initial_action = None
+
+    @property
+    def sigma_scale(self) -> float:
+        return self._sigma_scale
+
+    @sigma_scale.setter
+    def sigma_scale(self, value: float) -> None:
+        # a plain attribute in the reference (read at every render, :400): keep assignments effective
+        self._sigma_scale = float(value)
+        self._plane = native.Plane(*self._plane_vectors, self._sigma_scale)
 
     # ------------------------------------------------------------------ errors
     def reset_errors(self) -> None:

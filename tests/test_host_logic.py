@@ -189,6 +189,12 @@ def test_return_conventions_and_error_selection(monkeypatch):
     f3.error_angles_mrad.mul_(0.5)
     q, _ = f3.render(sun1, a1, None)
     assert not torch.equal(p, q)
+    # sigma_scale is a live attribute, as in the reference
+    wide = f3.sigma_scale * 4
+    f3.sigma_scale = wide
+    q2, _ = f3.render(sun1, a1, None)
+    assert f3.sigma_scale == wide and not torch.equal(q2, q)
+    f3.sigma_scale = wide / 4
     # accepts lists / ndarrays / other dtypes like the reference's as_tensor calls
     r, _ = f3.render(sun1.double().numpy(), a1.numpy().tolist(), None)
     assert torch.equal(r, q)
