@@ -398,9 +398,11 @@ render_fwd_fused_small(int B, int N, int R, const float* __restrict__ helios, co
 
     const float xv = xs[min(i0 + lr, R - 1)], yv = ys[min(j0 + lr, R - 1)];
     const vec3 s = ld3(sun + 3l * b);
-    f32x16 tot, acc;
+    // two accumulators (even / odd k-pairs): the two MFMAs of a trip do not depend on each other, so
+    // the latency-bound loop of a single wave per SIMD is one MFMA latency per trip, not two
+    f32x16 tot, acc, acc2;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) { tot[e] = 0.0f; acc[e] = 0.0f; }
+    for (int e = 0; e < 16; ++e) { tot[e] = 0.0f; acc[e] = 0.0f; acc2[e] = 0.0f; }
 
     const float4 pad = make_float4(0.f, 0.f, 1.f, 1e30f);   // A = exp2(-1e30) = 0 exactly
     for (int n0 = 0; n0 < N; n0 += NC) {
@@ -434,11 +436,11 @@ render_fwd_fused_small(int B, int N, int R, const float* __restrict__ helios, co
             const float fe0 = exp2_fast(-((u0 * u0) * p0.z));
             const float fe1 = exp2_fast(-((u1 * u1) * p1.z));
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0, fe0, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1, fe1, acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1, fe1, acc2, 0, 0, 0);
         }
-        tot += acc;
+        tot += acc + acc2;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+        for (int e = 0; e < 16; ++e) { acc[e] = 0.0f; acc2[e] = 0.0f; }
     }
     store_block(image + (long)b * R * R, R, i0, j0, lr, lh, tot);
 }
