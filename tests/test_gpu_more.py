@@ -422,3 +422,19 @@ def test_hostbind_and_ctypes_bindings_agree():
         out[name] = (img.detach(), actual.detach(), refl.detach(), g, ideal)
     for p, q in zip(out["hostbind"], out["ctypes"]):
         assert torch.equal(p, q)
+
+
+@pytest.mark.parametrize("N,B,R", [(50, 25, 128), (300, 40, 256)])
+def test_bitwise_reproducible_run_to_run(N, B, R):
+    """No atomics anywhere on the path: forward, backward and the fused losses give the same bits
+    on every run (the reductions are fixed-order)."""
+    f, _, suns, _, act = make_case(N=N, B=B, R=R, seed=11)
+    G = torch.randn(B, R, R, device=DEV)
+    runs = []
+    for _ in range(3):
+        a = act.to(DEV).requires_grad_(True)
+        img, actual = f.render(suns, a, None)
+        (g,) = torch.autograd.grad((img * G).sum() + actual.sum(), a)
+        runs.append((img.detach().clone(), g.clone()))
+    for img, g in runs[1:]:
+        assert torch.equal(img, runs[0][0]) and torch.equal(g, runs[0][1])
