@@ -438,3 +438,49 @@ def test_bitwise_reproducible_run_to_run(N, B, R):
         runs.append((img.detach().clone(), g.clone()))
     for img, g in runs[1:]:
         assert torch.equal(img, runs[0][0]) and torch.equal(g, runs[0][1])
+
+
+def test_degenerate_rays_follow_the_reference_clamps():
+    """Rays that hit the reference's clamp_min / where() branches (:48, :63-73, :127, :146, :372):
+    zero normals, a heliostat at the sun's position, plane-parallel reflections, normals pointing
+    away (leaky-ReLU side), sub-pixel and huge footprints, large errors.  Forward bit-exact
+    geometry, image within tolerance, finite gradients that match the oracle's autograd."""
+    from doodle_amd import HelioField
+    torch.manual_seed(5)
+    N, B, R = 12, 3, 40
+    helios = torch.rand(N, 3) * 10 + 80
+    helios[:, 2] = 0
+    helios[0] = torch.tensor([0.0, 50.0, 0.0])
+    suns = torch.tensor([[0.0, 50.0, 1000.0], [5000.0, 6000.0, 11000.0], [-3000.0, 9000.0, 4000.0]])
+    suns[2] = suns[2]
+    tp, tn = torch.tensor([0.0, -5.0, 0.0]), torch.tensor([0.0, 1.0, 0.0])
+    for sigma in (1e-5, 0.02, 5.0):
+        sc = to.Scene.build(helios, tp, (15.0, 15.0), tn, R, sigma)
+        ideal = to.ideal_normals(helios, tp, suns)
+        act = ideal.clone()
+        act[0, 1] = 0.0                                            # zero normal → clamp_min(1e-9) path
+        act[0, 0] = torch.tensor([2.0 ** -0.5, 0.0, 2.0 ** -0.5])  # reflects (0,0,1) into (1,0,0): plane-parallel
+        act[1, 2] = -act[1, 2]                                     # pointing away: negative Z → leaky side
+        act[1, 3] = torch.tensor([0.0, 0.0, -1.0])
+        act[2, 4] = act[2, 4] * 1e-12                              # tiny but non-zero
+        helios2 = helios.clone()
+        errs = torch.randn(B, N, 2) * 400.0                        # ±0.4 rad
+        errs[:, 0] = 0.0
+        f = HelioField(helios2, tp, (15.0, 15.0), tn, error_scale_mrad=400.0, sigma_scale=sigma, resolution=R,
+                       device=DEV, max_batch_size=B)
+        f.batch_error_angles_mrad = errs
+        a_cpu = act.reshape(B, -1).clone().requires_grad_(True)
+        img_o, actual_o, refl_o = to.render(sc, suns, a_cpu, errs, monitor=True)
+        g = torch.Generator().manual_seed(2)
+        G, H = torch.randn(img_o.shape, generator=g), torch.randn(actual_o.shape, generator=g)
+        (grad_o,) = torch.autograd.grad((img_o * G).sum() + (actual_o * H).sum(), a_cpu)
+        a_dev = act.reshape(B, -1).to(DEV).requires_grad_(True)
+        img, actual, refl = f.render(suns, a_dev, None, monitor=True)
+        assert np.array_equal(actual.detach().cpu().numpy(), actual_o.detach().numpy()), sigma
+        assert np.array_equal(refl.detach().cpu().numpy(), refl_o.detach().numpy()), sigma
+        np.testing.assert_allclose(img.detach().cpu().numpy(), img_o.detach().numpy(), rtol=1e-5, atol=1e-8)
+        (grad,) = torch.autograd.grad((img * G.to(DEV)).sum() + (actual * H.to(DEV)).sum(), a_dev)
+        assert torch.isfinite(grad).all() == torch.isfinite(grad_o).all()
+        fin = torch.isfinite(grad_o)
+        scale = grad_o[fin].abs().max().item()
+        assert (grad.cpu()[fin] - grad_o[fin]).abs().max().item() <= 5e-4 * scale, sigma
