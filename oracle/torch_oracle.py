@@ -39,14 +39,17 @@ class Scene:
     sigma_scale: float
 
     @staticmethod
-    def build(helios, target_position, target_area, target_normal, resolution, sigma_scale):
-        helios = torch.as_tensor(helios, dtype=torch.float32)
-        tp = torch.as_tensor(target_position, dtype=torch.float32)
-        tn = torch.as_tensor(target_normal, dtype=torch.float32)
+    def build(helios, target_position, target_area, target_normal, resolution, sigma_scale,
+              dtype=torch.float32):
+        """``dtype=torch.float64`` gives the same formulas in double: the "truth" the fp32 results
+        (the reference's and the kernels') are both measured against in the accuracy tests."""
+        helios = torch.as_tensor(helios, dtype=dtype)
+        tp = torch.as_tensor(target_position, dtype=dtype)
+        tn = torch.as_tensor(target_normal, dtype=dtype)
         tn = tn / tn.norm().clamp_min(_TINY)                          # :192
-        u = torch.tensor([1.0, 0.0, 0.0])                              # :206
-        if torch.allclose(tn, torch.tensor([0.0, 1.0, 0.0])):         # :207-210
-            v = torch.tensor([0.0, 0.0, 1.0])
+        u = torch.tensor([1.0, 0.0, 0.0], dtype=dtype)                 # :206
+        if torch.allclose(tn, torch.tensor([0.0, 1.0, 0.0], dtype=dtype)):   # :207-210
+            v = torch.tensor([0.0, 0.0, 1.0], dtype=dtype)
         else:                                                          # :212-213
             v = torch.linalg.cross(tn, u)
             v = v / v.norm().clamp_min(_TINY)
@@ -116,8 +119,8 @@ def footprints(scene: Scene, hit: torch.Tensor, origins: torch.Tensor, mask: tor
     """[M,3] hits → [M,R,R] un-normalised Gaussians, :107-149."""
     M, R = hit.shape[0], scene.resolution
     sigma = (scene.sigma_scale * (hit - origins).norm(dim=1)).clamp_min(_TINY).view(M, 1, 1)
-    xs = torch.linspace(-scene.width / 2, scene.width / 2, R)
-    ys = torch.linspace(-scene.height / 2, scene.height / 2, R)
+    xs = torch.linspace(-scene.width / 2, scene.width / 2, R, dtype=hit.dtype)
+    ys = torch.linspace(-scene.height / 2, scene.height / 2, R, dtype=hit.dtype)
     gx, gy = torch.meshgrid(xs, ys, indexing="ij")
     pts = (scene.target_position.view(1, 1, 1, 3)
            + gx.view(1, R, R, 1) * scene.plane_u.view(1, 1, 1, 3)
@@ -135,10 +138,11 @@ def render(scene: Scene, sun, action, errs, monitor: bool = False):
     The caller applies the single-sun ``images[0]`` convention and the
     error-selection rule (:340-353) — see :func:`pick_errors`.
     """
-    sun = torch.as_tensor(sun, dtype=torch.float32).reshape(-1, 3)
+    dt = scene.helios.dtype
+    sun = torch.as_tensor(sun, dtype=dt).reshape(-1, 3)
     B, N, R = sun.shape[0], scene.helios.shape[0], scene.resolution
-    normals = torch.as_tensor(action, dtype=torch.float32).reshape(B, N, 3)
-    actual, refl, hit, mask, origins = ray_geometry(scene, sun, normals, errs)
+    normals = torch.as_tensor(action, dtype=dt).reshape(B, N, 3)
+    actual, refl, hit, mask, origins = ray_geometry(scene, sun, normals, errs.to(dt))
     g = footprints(scene, hit, origins, mask)
     images = g.view(B, N, R, R).sum(dim=1)                               # :404-406
     return (images, actual, refl) if monitor else (images, actual)

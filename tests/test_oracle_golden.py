@@ -153,3 +153,16 @@ def test_step_loss_oracle_matches_reference_env(tag):
     assert np.array_equal(out[4].detach().numpy().reshape(-1, 1), g["monitor_mae_image"])
     assert np.array_equal(out[5].detach().numpy(), g["monitor_all_bounds"])
     assert np.array_equal(out[6].detach().numpy().reshape(-1), g["monitor_alignment_errors"])
+
+
+def test_reference_fp32_noise_floor_against_fp64():
+    """The size of the reference's own fp32 error (~1.8e-5 of peak at
+    sigma_scale=0.01): the yardstick for the 1e-5 image tolerance.  The same formulas in fp64
+    are the truth."""
+    g = golden("g1_train_n50_b25_r128")
+    sc64 = to.Scene.build(g["helios"], g["target_position"], tuple(g["target_area"]), g["target_normal"],
+                          int(g["resolution"]), float(g["sigma_scale"]), dtype=torch.float64)
+    sun = torch.from_numpy(g["sun"])
+    img64, _ = to.render(sc64, sun, torch.from_numpy(g["action"]), torch.from_numpy(g["batch_error_angles_mrad"]).double())
+    err = (torch.from_numpy(g["image"]).double() - img64).abs().max().item() / img64.max().item()
+    assert 1e-6 < err < 1e-4, err

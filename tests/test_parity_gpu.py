@@ -105,3 +105,25 @@ def test_ideal_normals_bit_exact():
     assert tuple(f.initial_action.shape) == (25, 150)
     f.init_actions(suns[0])
     assert tuple(f.initial_action.shape) == (150,)
+
+
+@pytest.mark.parametrize("name", ["g1_train_n50_b25_r128", "g1_readme_n50_b25_r64", "g3_tilted_n50_b5_r64",
+                                  "g8_ragged_n201_b7_r48"])
+def test_accuracy_against_fp64_truth_is_at_the_reference_level(name):
+    """Accuracy, not only agreement: measured against the same formulas in fp64, the HIP image is
+    as close to the truth as the reference's own fp32 image (it inherits the reference's geometry
+    bits, and its footprint arithmetic adds no error of its own)."""
+    from oracle import torch_oracle as to
+    g = golden(name)
+    sc64 = to.Scene.build(g["helios"], g["target_position"], tuple(g["target_area"]), g["target_normal"],
+                          int(g["resolution"]), float(g["sigma_scale"]), dtype=torch.float64)
+    sun = torch.from_numpy(g["sun"]).reshape(-1, 3)
+    errs = to.pick_errors(torch.from_numpy(g["error_angles_mrad"]), torch.from_numpy(g["batch_error_angles_mrad"]),
+                          sun.shape[0]).double()
+    truth, _ = to.render(sc64, sun, torch.from_numpy(g["action"]), errs)
+    peak = truth.max().item()
+    ref_err = (torch.from_numpy(g["image"]).double().reshape(truth.shape) - truth).abs().max().item() / peak
+    f = field_from(g)
+    img, _ = f.render(torch.from_numpy(g["sun"]), torch.from_numpy(g["action"]), None)
+    our_err = (img.cpu().double().reshape(truth.shape) - truth).abs().max().item() / peak
+    assert our_err <= 1.25 * ref_err + 1e-6, (our_err, ref_err)
