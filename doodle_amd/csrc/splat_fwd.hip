@@ -22,8 +22,8 @@
 //     operands.  Why: measured on MI355X, the f32 MFMA and the VALU do not overlap on
 //     a SIMD (f32 MFMA runs at the f32 VALU rate — same multiply-add lanes), so every
 //     VALU instruction removed per MFMA is time gained.
-// Measured at N=2000, B=512, R=512 (config 4): valu 75, mfma_regs 116, mfma_tile<2> see
-// DESIGN.md, mfma_tile<4> 134 TFLOP/s (f32 peak 157.3).
+// Measured at N=2000, B=512, R=512 (config 4): valu 96, mfma_regs 111, mfma_tile<2> 118,
+// mfma_tile<4> 135 TFLOP/s (f32 peak 157.3).
 // The 4-wave kernels accumulate in two levels (a chunk of rays, then the running total);
 // the 16-wave kernel (128-VGPR budget) in one level: measured 1.5e-6 of peak apart at N=2000.
 #include <hip/hip_runtime.h>
@@ -37,7 +37,7 @@ __device__ __forceinline__ float exp2_fast(float x) { return __builtin_amdgcn_ex
 // ----------------------------------------------------------------------------------------------
 // VALU variant
 // ----------------------------------------------------------------------------------------------
-template <int TILE, int NC>
+template <int TILE, int NC, bool TWO_LEVEL = true>
 __global__ void __launch_bounds__(256)
 splat_fwd_valu(int B, int N, int R, const float* __restrict__ rays, const float* __restrict__ xs,
                const float* __restrict__ ys, float* __restrict__ image) {
@@ -81,10 +81,12 @@ splat_fwd_valu(int B, int N, int R, const float* __restrict__ rays, const float*
             sE[nn][p] = fe;
         }
         __syncthreads();
+        if (TWO_LEVEL || n0 == 0) {
 #pragma unroll
-        for (int r = 0; r < TR; ++r)
+            for (int r = 0; r < TR; ++r)
 #pragma unroll
-            for (int c = 0; c < TC; ++c) acc[r][c] = 0.0f;
+                for (int c = 0; c < TC; ++c) acc[r][c] = 0.0f;
+        }
 #pragma unroll 4
         for (int nn = 0; nn < NC; ++nn) {
             float av[TR], ev[TC];
@@ -103,10 +105,18 @@ splat_fwd_valu(int B, int N, int R, const float* __restrict__ rays, const float*
 #pragma unroll
                 for (int c = 0; c < TC; ++c) acc[r][c] = __builtin_fmaf(av[r], ev[c], acc[r][c]);
         }
+        if (TWO_LEVEL) {
+#pragma unroll
+            for (int r = 0; r < TR; ++r)
+#pragma unroll
+                for (int c = 0; c < TC; ++c) tot[r][c] += acc[r][c];
+        }
+    }
+    if (!TWO_LEVEL) {
 #pragma unroll
         for (int r = 0; r < TR; ++r)
 #pragma unroll
-            for (int c = 0; c < TC; ++c) tot[r][c] += acc[r][c];
+            for (int c = 0; c < TC; ++c) tot[r][c] = acc[r][c];
     }
 
     float* __restrict__ img = image + (long)b * R * R;
@@ -514,7 +524,9 @@ int launch_splat_fwd(int B, int N, int R, const float* rays, const float* xs, co
             hipLaunchKernelGGL((splat_fwd_valu<64, 32>), dim3(t * t, B), dim3(256), 0, st, B, N, R, rays, xs, ys, image);
         } else {
             const int t = (R + 127) / 128;
-            hipLaunchKernelGGL((splat_fwd_valu<128, 32>), dim3(t * t, B), dim3(256), 0, st, B, N, R, rays, xs, ys, image);
+            // one-level sums for the 8×8 register tile: 107 VGPRs instead of 224 (4 waves/SIMD instead
+            // of 2) — 96 vs 76 TFLOP/s at config 4; the summation error stays within the tolerance
+            hipLaunchKernelGGL((splat_fwd_valu<128, 32, false>), dim3(t * t, B), dim3(256), 0, st, B, N, R, rays, xs, ys, image);
         }
         return HELIO_OK;
     case 3: launch_regs<2, 2, 2, 2, 128, true>(B, N, R, rays, xs, ys, image, st); return HELIO_OK;
