@@ -24,8 +24,9 @@
 //     VALU instruction removed per MFMA is time gained.
 // Measured at N=2000, B=512, R=512 (config 4): valu 96, mfma_regs 111, mfma_tile<2> 118,
 // mfma_tile<4> 135 TFLOP/s (f32 peak 157.3).
-// The 4-wave kernels accumulate in two levels (a chunk of rays, then the running total);
-// the 16-wave kernel (128-VGPR budget) in one level: measured 1.5e-6 of peak apart at N=2000.
+// The 64²-tile kernels (small problems, short sums) accumulate in two levels (a chunk of rays,
+// then the running total); the throughput kernels in one level — fewer registers, more waves per
+// SIMD — measured 1.5e-6 of peak apart at N=2000 and inside the tolerance at N=5000.
 #include <hip/hip_runtime.h>
 #include "helio.h"
 #include "ray_trace.h"
@@ -529,8 +530,10 @@ int launch_splat_fwd(int B, int N, int R, const float* rays, const float* xs, co
             hipLaunchKernelGGL((splat_fwd_valu<128, 32, false>), dim3(t * t, B), dim3(256), 0, st, B, N, R, rays, xs, ys, image);
         }
         return HELIO_OK;
-    case 3: launch_regs<2, 2, 2, 2, 128, true>(B, N, R, rays, xs, ys, image, st); return HELIO_OK;
-    case 4: launch_tile<2, true>(B, N, R, rays, xs, ys, image, st); return HELIO_OK;
+    // one-level sums everywhere the heliostat loop is long (fewer registers → more waves per SIMD;
+    // measured +4 %); the summation error at N = 5000 stays inside the tolerance (GPU tests)
+    case 3: launch_regs<2, 2, 2, 2, 128, false>(B, N, R, rays, xs, ys, image, st); return HELIO_OK;
+    case 4: launch_tile<2, false>(B, N, R, rays, xs, ys, image, st); return HELIO_OK;
     case 5: launch_tile<4, false>(B, N, R, rays, xs, ys, image, st); return HELIO_OK;
     case 6: launch_regs<1, 1, 2, 2, 128, true>(B, N, R, rays, xs, ys, image, st); return HELIO_OK;
     default: return HELIO_E_INVALID;
