@@ -192,12 +192,22 @@ splat_fwd_mfma_regs(int B, int N, int R, const float* __restrict__ rays, const f
 #pragma unroll
             for (int e = 0; e < 16; ++e) { tot[mi][mj][e] = 0.0f; acc[mi][mj][e] = 0.0f; }
 
-    // a padded ray: k2 = 1, c2 = 1e30  →  A = exp2(-1e30) = 0 exactly, E finite
-    const float4 pad = make_float4(0.f, 0.f, 1.f, 1e30f);
+    // Rays are staged in LDS pre-scaled, (a·√k2, b·√k2, √k2, c2·k2), so that a factor is
+    //   exp2(-(q² + cc)),  q = fma(coord, √k2, shift)        — 2 VALU + 1 exp per factor.
+    // A padded ray: √k2 = 0, cc = 1e30  →  A = exp2(-1e30) = 0 exactly, E = 1
+    const float4 pad = make_float4(0.f, 0.f, 0.f, 1e30f);
     const float4* __restrict__ rb = reinterpret_cast<const float4*>(rays) + (long)b * N;
     for (int n0 = 0; n0 < N; n0 += NC) {
         __syncthreads();
-        for (int k = tid; k < NC + 4; k += 256) sRay[k] = (k < NC && n0 + k < N) ? rb[n0 + k] : pad;
+        for (int k = tid; k < NC + 4; k += 256) {
+            float4 v = pad;
+            if (k < NC && n0 + k < N) {
+                const float4 r = rb[n0 + k];
+                const float sk = __builtin_sqrtf(r.z);
+                v = make_float4(r.x * sk, r.y * sk, sk, r.w * r.z);
+            }
+            sRay[k] = v;
+        }
         __syncthreads();
         const int cnt = min(NC, N - n0);
         float4 q0 = sRay[lh], q1 = sRay[2 + lh];
@@ -208,15 +218,15 @@ splat_fwd_mfma_regs(int B, int N, int R, const float* __restrict__ rays, const f
             float fa0[MBI], fe0[MBJ], fa1[MBI], fe1[MBJ];
 #pragma unroll
             for (int m = 0; m < MBI; ++m) {
-                const float t0 = xv[m] + p0.x, t1 = xv[m] + p1.x;
-                fa0[m] = exp2_fast(-(__builtin_fmaf(t0, t0, p0.w) * p0.z));
-                fa1[m] = exp2_fast(-(__builtin_fmaf(t1, t1, p1.w) * p1.z));
+                const float t0 = __builtin_fmaf(xv[m], p0.z, p0.x), t1 = __builtin_fmaf(xv[m], p1.z, p1.x);
+                fa0[m] = exp2_fast(-__builtin_fmaf(t0, t0, p0.w));
+                fa1[m] = exp2_fast(-__builtin_fmaf(t1, t1, p1.w));
             }
 #pragma unroll
             for (int m = 0; m < MBJ; ++m) {
-                const float u0 = yv[m] + p0.y, u1 = yv[m] + p1.y;
-                fe0[m] = exp2_fast(-((u0 * u0) * p0.z));
-                fe1[m] = exp2_fast(-((u1 * u1) * p1.z));
+                const float u0 = __builtin_fmaf(yv[m], p0.z, p0.y), u1 = __builtin_fmaf(yv[m], p1.z, p1.y);
+                fe0[m] = exp2_fast(-(u0 * u0));
+                fe1[m] = exp2_fast(-(u1 * u1));
             }
 #pragma unroll
             for (int mi = 0; mi < MBI; ++mi)
@@ -415,7 +425,7 @@ render_fwd_fused_small(int B, int N, int R, const float* __restrict__ helios, co
 #pragma unroll
     for (int e = 0; e < 16; ++e) { tot[e] = 0.0f; acc[e] = 0.0f; acc2[e] = 0.0f; }
 
-    const float4 pad = make_float4(0.f, 0.f, 1.f, 1e30f);   // A = exp2(-1e30) = 0 exactly
+    const float4 pad = make_float4(0.f, 0.f, 0.f, 1e30f);   // pre-scaled form: A = exp2(-1e30) = 0 exactly
     for (int n0 = 0; n0 < N; n0 += NC) {
         __syncthreads();
         if (tid < NC + 4) {
@@ -425,11 +435,12 @@ render_fwd_fused_small(int B, int N, int R, const float* __restrict__ helios, co
                 const long m = (long)b * N + n;
                 const float4 tg = *reinterpret_cast<const float4*>(trig + (long)b * trig_b_stride + 4l * n);
                 const Ray q = trace(ld3(action + 3 * m), tg.x, tg.y, tg.z, tg.w, ld3(helios + 3l * n), s, P);
-                v = make_float4(q.a, q.b, q.k2, q.c2);
+                const float sk = __builtin_sqrtf(q.k2);
+                v = make_float4(q.a * sk, q.b * sk, sk, q.c2 * q.k2);   // LDS copy pre-scaled (2 VALU + exp per factor)
                 if (writer) {
                     st3(actual + 3 * m, q.act);
                     if (refl) st3(refl + 3 * m, q.r);
-                    if (rays) *reinterpret_cast<float4*>(rays + 4 * m) = v;
+                    if (rays) *reinterpret_cast<float4*>(rays + 4 * m) = make_float4(q.a, q.b, q.k2, q.c2);
                 }
             }
             sRay[tid] = v;
@@ -441,11 +452,12 @@ render_fwd_fused_small(int B, int N, int R, const float* __restrict__ helios, co
             const float4 p0 = q0, p1 = q1;
             q0 = sRay[k + 4 + lh];
             q1 = sRay[k + 6 + lh];
-            const float t0 = xv + p0.x, t1 = xv + p1.x, u0 = yv + p0.y, u1 = yv + p1.y;
-            const float fa0 = exp2_fast(-(__builtin_fmaf(t0, t0, p0.w) * p0.z));
-            const float fa1 = exp2_fast(-(__builtin_fmaf(t1, t1, p1.w) * p1.z));
-            const float fe0 = exp2_fast(-((u0 * u0) * p0.z));
-            const float fe1 = exp2_fast(-((u1 * u1) * p1.z));
+            const float t0 = __builtin_fmaf(xv, p0.z, p0.x), t1 = __builtin_fmaf(xv, p1.z, p1.x);
+            const float u0 = __builtin_fmaf(yv, p0.z, p0.y), u1 = __builtin_fmaf(yv, p1.z, p1.y);
+            const float fa0 = exp2_fast(-__builtin_fmaf(t0, t0, p0.w));
+            const float fa1 = exp2_fast(-__builtin_fmaf(t1, t1, p1.w));
+            const float fe0 = exp2_fast(-(u0 * u0));
+            const float fe1 = exp2_fast(-(u1 * u1));
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0, fe0, acc, 0, 0, 0);
             acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1, fe1, acc2, 0, 0, 0);
         }
