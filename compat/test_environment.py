@@ -1,4 +1,3 @@
 """Import shim for DOODLE's `from test_environment import HelioEnv`."""
 from doodle_amd.env import (  # noqa: F401
-    HelioEnv, azimuth_elevation_to_primary_direction, boundary, calculate_angles_mrad,
-    make_distance_maps, sample_cone_directions)
+    HelioEnv, azimuth_elevation_to_primary_direction, make_distance_maps, sample_cone_directions)

@@ -4,21 +4,20 @@ Mirrors ``HelioEnv`` of DOODLE's ``test_environment.py`` (:175-525): constructor
 signature, ``reset()`` / ``step()`` / ``set_sun_pos()`` / ``seed()``, the observation and
 metric dictionaries, and the attributes the training scripts read
 (``train_with_env.py:171-216``).  The two ``HelioField`` renders and the ideal-normal
-computation per step run in libhelio.so; the loss block (:427-457) and the boundary
-loss (:101-130) are plain torch ops on the device ("next" rows).
+computation per step run in libhelio.so, and so do the loss block (:427-457), the boundary
+loss (:101-130), the alignment angle (:132-155) and the distance maps (:92-97) — SURVEY.md §8(f).
 
 ``gymnasium`` is optional: when it is absent the spaces are small records with the
 same fields (the reference only stores them, ``test_environment.py:241-252``).
 """
 from __future__ import annotations
 
+import ctypes
 import math
 
 import numpy as np
 import torch
 import torch.nn.functional as F
-
-import ctypes
 
 from .field import HelioField
 from .losses import StepConstants, env_step_fused, step_losses
@@ -42,7 +41,6 @@ except Exception:  # gymnasium is not installed in this image
             return self
 
 
-BORDER_TOLERANCE = 0.75          # test_environment.py:113
 SUN_RANGE = math.hypot(10000, 10000)   # :324
 
 
@@ -86,37 +84,6 @@ def make_distance_maps(imgs: torch.Tensor, thr: float = 0.5) -> torch.Tensor:
     no host round trip, and no CPU implementation in the product."""
     from . import field as _field
     return _field._get_ops().distance_maps(imgs.detach().to(torch.float32), float(thr))
-
-
-def boundary(vects, heliostat_pos, targ_pos, targ_norm, targ_area, target_east_axis, target_up_axis,
-             return_all: bool = False):
-    """Anti-spill loss of the reference (:101-130), formula kept as is: the normals are
-    treated as ray directions from the heliostats, intersected with the target plane,
-    and penalised by their distance outside 75 % of the 75 %-shrunk receiver."""
-    dots = -(vects * targ_norm).sum(-1)
-    valid = dots.abs() > 1e-6
-    t = (vects * targ_pos).sum(-1) / (dots + (~valid).float() * 1e-6)
-    local = heliostat_pos.unsqueeze(0) + vects * t.unsqueeze(2) - targ_pos
-    xl = (local * target_east_axis).sum(-1)
-    yl = (local * target_up_axis).sum(-1)
-    hw = targ_area[0] * BORDER_TOLERANCE / 2
-    hh = targ_area[1] * BORDER_TOLERANCE / 2
-    dx = F.relu(xl.abs() - hw * BORDER_TOLERANCE)
-    dy = F.relu(yl.abs() - hh * BORDER_TOLERANCE)
-    dist = torch.sqrt(dx * dx + dy * dy + 1e-8)
-    inside = (xl.abs() <= hw) & (yl.abs() <= hh) & valid
-    out = dist * (~inside).float()
-    return out if return_all else out.mean()
-
-
-def calculate_angles_mrad(v1: torch.Tensor, v2: torch.Tensor, epsilon: float = 1e-10) -> torch.Tensor:
-    """Angle between (unit) vectors in mrad, acos of the clamped dot product (:132-155)."""
-    v1 = v1.unsqueeze(0) if v1.dim() == 1 else v1
-    v2 = v2.unsqueeze(0) if v2.dim() == 1 else v2
-    cosang = torch.sum(v1 * v2, dim=-1)
-    one = torch.tensor(1.0, dtype=cosang.dtype)
-    hi = torch.nextafter(one, torch.tensor(0.0, dtype=cosang.dtype)).item()
-    return torch.acos(torch.clamp(cosang, min=-hi + epsilon, max=hi - epsilon)) * 1000
 
 
 class HelioEnv(_EnvBase):
@@ -236,7 +203,7 @@ class HelioEnv(_EnvBase):
         if isinstance(action, np.ndarray):
             action = torch.tensor(action, dtype=torch.float32, device=self.device)
         if self.use_error_mask and self.batch_size > 4096:
-            return self._step_torch(action)         # the fused quantile handles B <= 4096
+            raise NotImplementedError("use_error_mask: the fused quantile covers batch_size <= 4096")
         ideal, target, tx = self._reference()
         normals = action.view(self.batch_size, -1, 3)                    # :460
         consts = StepConstants(target, tx, self.distance_maps, ideal, self.noisy_field.heliostat_positions,
@@ -263,54 +230,6 @@ class HelioEnv(_EnvBase):
             "all_bounds": all_bounds,
             "mae_image": mae.view([-1, 1]),
             "alignment_errors": angles.view([-1]),
-        }
-        return obs, metrics, monitor
-
-    def _step_torch(self, action):
-        """The loss block as torch ops on the device (:427-488) around the two HIP renders: only
-        for ``use_error_mask`` with more than 4096 suns, which the fused quantile does not cover."""
-        ideal = self.ref_field.calculate_ideal_normals(self.sun_pos)
-        img, actual, reflected = self.noisy_field.render(self.sun_pos, action, ideal, monitor=True)
-        aux = torch.cat([self.sun_pos.detach(), action.flatten(1)], dim=1)
-
-        with torch.no_grad():
-            target, _ = self.ref_field.render(self.sun_pos, ideal.flatten(1), ideal)
-        scale = target.amax((1, 2), keepdim=True).clamp_min(1e-6)       # :436
-        pred_n, targ_n = img / scale, target / scale
-        err = (pred_n - targ_n).abs()
-        per_image = err.mean(dim=[-2, -1])
-        angles = calculate_angles_mrad(ideal, actual)
-        alignment_loss = torch.mean(angles)
-        if self.use_error_mask:                                          # :445-452
-            cutoff = torch.quantile(per_image, 1 - self.error_mask_ratio)
-            keep = (per_image > cutoff).float().unsqueeze(-1).unsqueeze(-1)
-            mse = F.mse_loss(pred_n * keep, targ_n * keep)
-            dist_l = (keep * (err * self.distance_maps)).sum((1, 2)).mean()
-        else:                                                            # :455-457
-            mse = F.mse_loss(pred_n, targ_n)
-            dist_l = (err * self.distance_maps).sum((1, 2)).mean()
-
-        normals = action.view(self.batch_size, -1, 3)                    # :460
-        east = torch.tensor([1.0, 0.0, 0.0], device=self.device)
-        up = torch.tensor([0.0, 0.0, 1.0], device=self.device)
-        all_bounds = boundary(normals, self.heliostat_pos, self.targ_pos, self.targ_norm, self.targ_area,
-                              east, up, return_all=True)
-        bound = torch.mean(torch.exp(all_bounds + 1e-6)) if self.exponential_risk else all_bounds.mean()
-
-        finite = torch.isfinite(torch.stack([mse.detach(), dist_l.detach(), bound.detach()]))
-        if not bool(finite.all()):                                       # :495-501, one sync instead of six
-            names = ("MSE", "Distance loss", "Boundary loss")
-            raise AssertionError(f"{names[int((~finite).nonzero()[0])]} is NaN or Inf")
-
-        metrics = {"mse": mse, "dist": dist_l, "bound": bound, "alignment_loss": alignment_loss}
-        obs = {"img": img, "aux": aux}
-        monitor = {
-            "normals": normals,
-            "reflected_rays": reflected.view([-1, 3]),
-            "ideal_normals": ideal.view([-1, 3]),
-            "all_bounds": all_bounds,
-            "mae_image": per_image.view([-1, 1]),
-            "alignment_errors": angles.detach().view([-1]),
         }
         return obs, metrics, monitor
 
