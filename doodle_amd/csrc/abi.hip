@@ -26,7 +26,7 @@ int step_losses_ray_wgs(int, int);
 int step_losses_max_mask_batch();
 void launch_step_losses_fwd(int, int, int, const float*, const float*, const float*, const float*, const float*,
                             const float*, const float*, const float*, const float*, const float*, float, float, int,
-                            float, float*, float*, float*, float*, float*, float*, hipStream_t);
+                            float, float*, float*, float*, float*, float*, float*, const float*, float*, hipStream_t);
 void launch_step_losses_bwd(int, int, int, const float*, const float*, const float*, const float*, const float*,
                             const float*, const float*, const float*, const float*, const float*, float, float, int,
                             const float*, const float*, const float*, const float*, const float*, float*, float*,
@@ -219,12 +219,13 @@ int helio_step_losses_fwd(int B, int N, int R, const float* img_d, const float* 
                           const float* helios_d, const float target_position[3], const float target_normal[3],
                           float width, float height, int exponential_risk, float error_mask_ratio,
                           float* workspace_d, float* out_d, float* mae_d, float* keep_d, float* align_err_d,
-                          float* all_bounds_d, void* stream) {
+                          float* all_bounds_d, const float* sun_d, float* aux_d, void* stream) {
     if (!sizes_ok(B, N) || R < 1 || R > 16384) return fail(HELIO_E_INVALID, "step_losses_fwd: bad sizes B=%d N=%d R=%d", B, N, R);
     if (!img_d || !target_d || !tx_d || !dmaps_d || !ideal_d || !actual_d || !action_d || !helios_d ||
         !target_position || !target_normal || !workspace_d || !out_d || !mae_d || !keep_d || !align_err_d ||
         !all_bounds_d)
         return fail(HELIO_E_INVALID, "step_losses_fwd: null pointer");
+    if (aux_d && !sun_d) return fail(HELIO_E_INVALID, "step_losses_fwd: aux needs the sun positions");
     if (error_mask_ratio >= 0.0f && (error_mask_ratio > 1.0f || B > helio::step_losses_max_mask_batch()))
         return fail(HELIO_E_INVALID, "step_losses_fwd: error mask needs ratio in [0,1] and B <= %d",
                     helio::step_losses_max_mask_batch());
@@ -232,7 +233,7 @@ int helio_step_losses_fwd(int B, int N, int R, const float* img_d, const float* 
         return fail(HELIO_E_INVALID, "step_losses_fwd: images must be 16-byte aligned");
     helio::launch_step_losses_fwd(B, N, R, img_d, target_d, tx_d, dmaps_d, ideal_d, actual_d, action_d, helios_d,
                                   target_position, target_normal, width, height, exponential_risk, error_mask_ratio,
-                                  workspace_d, out_d, mae_d, keep_d, align_err_d, all_bounds_d,
+                                  workspace_d, out_d, mae_d, keep_d, align_err_d, all_bounds_d, sun_d, aux_d,
                                   static_cast<hipStream_t>(stream));
     return after_launch("step_losses_fwd");
 }

@@ -98,7 +98,8 @@ at::Tensor render_bwd(int64_t plane, const at::Tensor& helios, const at::Tensor&
 py::tuple step_losses_fwd(const at::Tensor& img, const at::Tensor& target, const at::Tensor& tx, const at::Tensor& dmaps,
                           const at::Tensor& ideal, const at::Tensor& actual, const at::Tensor& action,
                           const at::Tensor& helios, const std::vector<double>& tp, const std::vector<double>& tn,
-                          double W, double H, bool exp_risk, double mask_ratio) {
+                          double W, double H, bool exp_risk, double mask_ratio,
+                          c10::optional<at::Tensor> sun = c10::nullopt, c10::optional<at::Tensor> aux = c10::nullopt) {
     const int64_t B = action.size(0), N = action.size(1), R = img.size(-1);
     const float tpf[3] = {(float)tp[0], (float)tp[1], (float)tp[2]}, tnf[3] = {(float)tn[0], (float)tn[1], (float)tn[2]};
     auto opt = img.options();
@@ -110,7 +111,8 @@ py::tuple step_losses_fwd(const at::Tensor& img, const at::Tensor& target, const
                                 fp(action, "action"), fp(helios, "heliostat_positions"), tpf, tnf, (float)W, (float)H,
                                 exp_risk ? 1 : 0, (float)mask_ratio, ws.data_ptr<float>(), out.data_ptr<float>(),
                                 mae.data_ptr<float>(), keep.data_ptr<float>(), align.data_ptr<float>(),
-                                allb.data_ptr<float>(), cur_stream(img)));
+                                allb.data_ptr<float>(), fpo(sun, "sun"),
+                                aux.has_value() ? aux->data_ptr<float>() : nullptr, cur_stream(img)));
     return py::make_tuple(out, mae, align, allb, keep);
 }
 
@@ -137,6 +139,27 @@ py::tuple step_losses_bwd(const at::Tensor& img, const at::Tensor& target, const
     return py::make_tuple(o(gi), o(ga), o(gn));
 }
 
+// HelioEnv.step without autograd in ONE binding call: render (with its dtype/shape fix-ups),
+// loss block and the `aux` observation (test_environment.py:416-457, :424).  Same C ABI calls as
+// the separate paths; it only removes Python between them.
+py::tuple env_step_fwd(int64_t plane, const at::Tensor& helios, const at::Tensor& sun, const at::Tensor& action_in,
+                       const at::Tensor& trig, int64_t trig_b_stride, const at::Tensor& xs, const at::Tensor& ys,
+                       c10::optional<at::Tensor> rays_ws, int64_t variant, const at::Tensor& target,
+                       const at::Tensor& tx, const at::Tensor& dmaps, const at::Tensor& ideal,
+                       const std::vector<double>& tp, const std::vector<double>& tn, double W, double H,
+                       bool exp_risk, double mask_ratio) {
+    const int64_t B = sun.size(0), N = helios.size(0);
+    at::Tensor action = action_in.to(helios.options(), false, false);
+    at::Tensor normals = action.reshape({B, N, 3}).contiguous();
+    if (rays_ws.has_value() && (rays_ws->size(0) != B || rays_ws->device() != normals.device())) rays_ws.reset();
+    py::tuple r = render_fwd(plane, helios, sun, normals, trig, trig_b_stride, xs, ys, rays_ws, true, variant);
+    at::Tensor image = r[0].cast<at::Tensor>(), actual = r[1].cast<at::Tensor>();
+    at::Tensor aux = at::empty({B, 3 + 3 * N}, normals.options());       // filled by the loss launch
+    py::tuple l = step_losses_fwd(image, target, tx, dmaps, ideal, actual, normals, helios, tp, tn, W, H, exp_risk,
+                                  mask_ratio, sun, aux);
+    return py::make_tuple(image, actual, r[2], r[3], l[0], l[1], l[2], l[3], l[4], aux, normals);
+}
+
 at::Tensor ideal_normals(const at::Tensor& helios, const at::Tensor& sun, const std::vector<double>& target) {
     const int64_t B = sun.size(0), N = helios.size(0);
     const float t[3] = {(float)target[0], (float)target[1], (float)target[2]};
@@ -156,7 +179,11 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("render_fwd", &render_fwd);
     m.def("render_any", &render_any);
     m.def("render_bwd", &render_bwd);
-    m.def("step_losses_fwd", &step_losses_fwd);
+    m.def("step_losses_fwd", &step_losses_fwd, py::arg("img"), py::arg("target"), py::arg("tx"), py::arg("dmaps"),
+          py::arg("ideal"), py::arg("actual"), py::arg("action"), py::arg("helios"), py::arg("tp"), py::arg("tn"),
+          py::arg("W"), py::arg("H"), py::arg("exp_risk"), py::arg("mask_ratio"), py::arg("sun") = py::none(),
+          py::arg("aux") = py::none());
     m.def("step_losses_bwd", &step_losses_bwd);
+    m.def("env_step_fwd", &env_step_fwd);
     m.def("ideal_normals", &ideal_normals);
 }

@@ -76,7 +76,8 @@ step_losses_partial(int B, int N, int R, int chunks, const float* __restrict__ i
                     const float* __restrict__ helios, LossGeom g,
                     float* __restrict__ part_img,      // [B, chunks, 3]
                     float* __restrict__ part_ray,      // [ray_wgs, 2]
-                    float* __restrict__ align_err, float* __restrict__ all_bounds) {
+                    float* __restrict__ align_err, float* __restrict__ all_bounds,
+                    const float* __restrict__ sun, float* __restrict__ aux) {
     __shared__ float scratch[4];
     const int img_wgs = B * chunks;
     const int tid = threadIdx.x;
@@ -127,6 +128,12 @@ step_losses_partial(int B, int N, int R, int chunks, const float* __restrict__ i
             const RayLoss r = ray_loss(ideal + 3 * m, actual + 3 * m, action + 3 * m, helios + 3l * n, g);
             align_err[m] = r.ang;
             all_bounds[m] = r.out;
+            if (aux) {      // the observation's `aux` row: [sun_b, action_b] (test_environment.py:424)
+                const int b = (int)(m / N);
+                float* a = aux + (long)b * (3 + 3l * N);
+                a[3 + 3 * n] = action[3 * m]; a[4 + 3 * n] = action[3 * m + 1]; a[5 + 3 * n] = action[3 * m + 2];
+                if (n == 0) { a[0] = sun[3 * b]; a[1] = sun[3 * b + 1]; a[2] = sun[3 * b + 2]; }
+            }
             sa = r.ang;
             sb = g.exponential_risk ? expf(r.out + 1e-6f) : r.out;
         }
@@ -303,13 +310,14 @@ void launch_step_losses_fwd(int B, int N, int R, const float* img, const float* 
                             const float* dmaps, const float* ideal, const float* actual, const float* action,
                             const float* helios, const float* tp, const float* tn, float W, float H,
                             int exponential_risk, float mask_ratio, float* workspace, float* out, float* mae,
-                            float* keep, float* align_err, float* all_bounds, hipStream_t st) {
+                            float* keep, float* align_err, float* all_bounds, const float* sun, float* aux,
+                            hipStream_t st) {
     const int chunks = step_losses_chunks(R), rw = step_losses_ray_wgs(B, N);
     float* part_img = workspace;
     float* part_ray = workspace + 3l * B * chunks;
     hipLaunchKernelGGL(step_losses_partial, dim3(B * chunks + rw), dim3(SL_THREADS), 0, st, B, N, R, chunks, img,
                        target, tx, dmaps, ideal, actual, action, helios, make_geom(tp, tn, W, H, exponential_risk),
-                       part_img, part_ray, align_err, all_bounds);
+                       part_img, part_ray, align_err, all_bounds, sun, aux);
     hipLaunchKernelGGL(step_losses_final, dim3(1), dim3(SL_THREADS), 0, st, B, N, R, chunks, rw, mask_ratio, part_img,
                        part_ray, out, mae, keep);
 }

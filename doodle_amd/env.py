@@ -210,15 +210,26 @@ class HelioEnv(_EnvBase):
                                self._tp3, self._tn3, float(self.targ_area[0]), float(self.targ_area[1]),
                                bool(self.exponential_risk),
                                float(self.error_mask_ratio) if self.use_error_mask else -1.0)
+        fast = None
         if torch.is_grad_enabled() and action.requires_grad:
             # render + loss block as one autograd node
             (img, actual, reflected, mse, dist_l, bound, alignment_loss, mae, angles, all_bounds,
              flag) = env_step_fused(self.noisy_field, self.sun_pos, normals.contiguous(), consts)
         else:
-            img, actual, reflected = self.noisy_field.render(self.sun_pos, action, ideal, monitor=True)
-            mse, dist_l, bound, alignment_loss, mae, angles, all_bounds, flag = step_losses(img, actual, normals,
-                                                                                         consts)
-        aux = torch.cat([self.sun_pos.detach(), action.flatten(1)], dim=1)
+            from . import field as _field
+            step_fn = getattr(_field._get_ops(), "env_step_nograd", None)
+            if step_fn is not None and type(action) is torch.Tensor:
+                trig, stride = self.noisy_field._select_trig(self.batch_size)
+                fast = step_fn(self.noisy_field, self.sun_pos, action, trig, stride, consts)
+            if fast is not None:     # everything in one call of the compiled binding
+                img, actual, reflected, out, mae, angles, all_bounds, aux, normals = fast
+                mse, dist_l, bound, alignment_loss, flag = out[0], out[1], out[2], out[3], out[4]
+            else:
+                img, actual, reflected = self.noisy_field.render(self.sun_pos, action, ideal, monitor=True)
+                mse, dist_l, bound, alignment_loss, mae, angles, all_bounds, flag = step_losses(img, actual, normals,
+                                                                                             consts)
+        if fast is None:
+            aux = torch.cat([self.sun_pos.detach(), action.flatten(1)], dim=1)
         if self.check_finite and bool(flag):                             # :495-501, one sync instead of six
             raise AssertionError("MSE, distance loss or boundary loss is NaN or Inf")
         metrics = {"mse": mse, "dist": dist_l, "bound": bound, "alignment_loss": alignment_loss}

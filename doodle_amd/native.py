@@ -66,7 +66,7 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
         "helio_distance_maps_workspace": (_l, [_i, _i]),
         "helio_distance_maps": (_i, [_i, _i, _vp, _f, _vp, _vp, _vp]),
         "helio_step_losses_workspace": (_l, [_i, _i, _i]),
-        "helio_step_losses_fwd": (_i, [_i, _i, _i] + [_vp] * 8 + [_f3, _f3, _f, _f, _i, _f] + [_vp] * 6 + [_vp]),
+        "helio_step_losses_fwd": (_i, [_i, _i, _i] + [_vp] * 8 + [_f3, _f3, _f, _f, _i, _f] + [_vp] * 8 + [_vp]),
         "helio_step_losses_bwd": (_i, [_i, _i, _i] + [_vp] * 8 + [_f3, _f3, _f, _f, _i] + [_vp] * 5 + [_vp] * 3 + [_vp]),
     }
     for name, (res, args) in protos.items():
@@ -186,6 +186,19 @@ class HipOps:
         field._ray_ws = out[3]
         return out
 
+    def env_step_nograd(self, field, sun, action, trig, trig_b_stride, c):
+        """HelioEnv.step without autograd in one call of the compiled binding (render + loss block +
+        aux).  Returns None when that binding is not built.  → (image, actual, refl [B,N,3], out[5],
+        mae, angles, all_bounds, aux, normals)."""
+        if self.hb is None:
+            return None
+        r = self.hb.env_step_fwd(_plane_handle(self.hb, field._plane), field.heliostat_positions, sun, action, trig,
+                                 trig_b_stride, field._xs, field._ys, field._ray_ws, self.splat_variant, c.target,
+                                 c.tx, c.dmaps, c.ideal, list(c.tp), list(c.tn), c.W, c.H, bool(c.exp_risk),
+                                 float(c.mask_ratio))
+        field._ray_ws = r[3]
+        return r[0], r[1], r[2], r[4], r[5], r[6], r[7], r[9], r[10]
+
     def splat_fwd(self, rays, xs, ys, variant=None):
         B, N, R = rays.shape[0], rays.shape[1], xs.shape[0]
         image = torch.empty((B, R, R), dtype=torch.float32, device=rays.device)
@@ -275,7 +288,7 @@ class HipOps:
             B, N, R, _dev(img), _dev(c.target), _dev(c.tx), _dev(c.dmaps), _dev(c.ideal), _dev(actual),
             _dev(action), _dev(c.helios), c.tp, c.tn, c.W, c.H, int(c.exp_risk), float(c.mask_ratio),
             ws.data_ptr(), out.data_ptr(), mae.data_ptr(), keep.data_ptr(), align.data_ptr(), allb.data_ptr(),
-            _stream()))
+            None, None, _stream()))
         return out, mae, align, allb, keep
 
     def step_losses_bwd(self, img, actual, action, c, g_mse, g_dist, g_bound, g_align, keep, want_img, want_actual,

@@ -192,6 +192,8 @@ int helio_ideal_normals(int B, int N, const float *helios_d, const float *sun_d,
  *               is NaN/Inf (the asserts of :495-501)
  *   mae_d [B] (monitor 'mae_image'), keep_d [B] (the 0/1 error mask; all ones without it),
  *   align_err_d [B,N] (mrad), all_bounds_d [B,N]
+ *   aux_d [B, 3+3N], optional (NULL to skip): the observation row cat(sun_b, action_b) of :424,
+ *   written from sun_d [B,3] and action_d by the same launch
  */
 long helio_step_losses_workspace(int B, int N, int R);
 
@@ -209,7 +211,7 @@ int helio_step_losses_fwd(int B, int N, int R,
                           const float *helios_d, const float target_position[3], const float target_normal[3],
                           float width, float height, int exponential_risk, float error_mask_ratio,
                           float *workspace_d, float *out_d, float *mae_d, float *keep_d, float *align_err_d,
-                          float *all_bounds_d, void *stream);
+                          float *all_bounds_d, const float *sun_d, float *aux_d, void *stream);
 /*
  * Backward: g_*_d are DEVICE scalars (cotangents of the four losses; NULL = none); keep_d is
  * the mask the forward wrote (NULL = all ones);

@@ -94,6 +94,16 @@ def test_env_matches_reference_fixture(tag):
     act = torch.from_numpy(g["action"]).to(DEV).requires_grad_(True)
     obs, metrics, monitor = env.step(act)
     np.testing.assert_allclose(obs["img"].detach().cpu().numpy(), g["step_img"], rtol=1e-5, atol=1e-8)
+    assert np.array_equal(obs["aux"].detach().cpu().numpy(), g["step_aux"])
+    # the no-autograd path (one call of the compiled binding, aux written by the loss launch) agrees
+    # with the autograd path bit for bit
+    with torch.no_grad():
+        obs_ng, metrics_ng, monitor_ng = env.step(act.detach())
+    assert torch.equal(obs_ng["img"], obs["img"].detach()) and torch.equal(obs_ng["aux"], obs["aux"].detach())
+    for k in metrics:
+        assert torch.equal(metrics_ng[k], metrics[k].detach()), k
+    for k in monitor:
+        assert torch.equal(monitor_ng[k], monitor[k].detach()), k
     for k in metrics:
         np.testing.assert_allclose(metrics[k].item(), float(g["metric_" + k]), rtol=5e-5, atol=1e-6, err_msg=k)
         (ga,) = torch.autograd.grad(metrics[k], act, retain_graph=True, allow_unused=True)
