@@ -494,3 +494,37 @@ def test_degenerate_rays_follow_the_reference_clamps():
         fin = torch.isfinite(grad_o)
         scale = grad_o[fin].abs().max().item()
         assert (grad.cpu()[fin] - grad_o[fin]).abs().max().item() <= 5e-4 * scale, sigma
+
+
+def test_kernel_variants_agree_on_random_shapes():
+    """Fuzz over shapes around every tile/chunk boundary (N ≈ 1, 2, 63…65, 127…129, 255…257; R ≈ 1,
+    31…33, 63…65, 127…129, 255…257): all forward kernels give the same image and all backward
+    kernels the same moments.  Catches out-of-tile indexing that the fixed fixtures would miss."""
+    from doodle_amd import native
+    ops = native.get_ops()
+    rng = np.random.default_rng(7)
+    edge_n = [1, 2, 3, 63, 64, 65, 127, 128, 129, 255, 256, 257, 300]
+    edge_r = [1, 2, 31, 32, 33, 63, 64, 65, 127, 128, 129, 255, 256, 257, 300]
+    for it in range(36):
+        N, R = int(rng.choice(edge_n)), int(rng.choice(edge_r))
+        B = int(rng.integers(1, 6))
+        g = torch.Generator(device=DEV).manual_seed(it)
+        rays = torch.rand(B, N, 4, device=DEV, generator=g)
+        rays[..., 0:2] = rays[..., 0:2] * 12 - 6            # a, b within ±6 m of the 15 m target
+        rays[..., 2] = rays[..., 2] * 2.0 + 0.01            # k2
+        rays[..., 3] = rays[..., 3] * 1e-3                  # c2
+        rays[0, 0, 2] = 0.0                                 # an invalid ray: adds 1 to every pixel
+        xs = torch.linspace(-7.5, 7.5, R, device=DEV)
+        ys = torch.linspace(-7.5, 7.5, R, device=DEV)
+        ref = ops.splat_fwd(rays, xs, ys, variant=1)
+        assert torch.isfinite(ref).all() and ref[0].min().item() >= 1.0 - 1e-6, (B, N, R)
+        peak = ref.max().item()
+        for v in (3, 4, 5, 6, 0):
+            img = ops.splat_fwd(rays, xs, ys, variant=v)
+            assert (img - ref).abs().max().item() <= 3e-6 * peak, (B, N, R, v)
+        G = torch.randn(B, R, R, device=DEV, generator=g)
+        m1 = ops.splat_bwd(rays, xs, ys, G, variant=1).sum(1)
+        scale = m1.abs().amax(dim=(0, 1)).clamp_min(1e-20)
+        for v in (2, 3, 0):
+            mv = ops.splat_bwd(rays, xs, ys, G, variant=v).sum(1)
+            assert ((mv - m1).abs().amax(dim=(0, 1)) / scale).max().item() <= 2e-5, (B, N, R, v)
