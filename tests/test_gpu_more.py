@@ -528,3 +528,28 @@ def test_kernel_variants_agree_on_random_shapes():
         for v in (2, 3, 0):
             mv = ops.splat_bwd(rays, xs, ys, G, variant=v).sum(1)
             assert ((mv - m1).abs().amax(dim=(0, 1)) / scale).max().item() <= 2e-5, (B, N, R, v)
+
+
+def test_rollout_like_the_training_loop_on_gpu():
+    """The same rollout pattern as tests/test_host_logic.py::test_env_surface_the_training_loop_uses,
+    on the HIP path: [B,N,3] actions from a differentiable head, three steps, one backward through
+    all of them (every loss), finite gradients; then a no-grad step with a numpy action."""
+    from doodle_amd.env import HelioEnv
+    torch.manual_seed(0)
+    N, B, R = 50, 25, 128
+    hp = torch.rand(N, 3, device=DEV) * 10 + 80
+    hp[:, 2] = 0
+    env = HelioEnv(hp, torch.tensor([0.0, -5.0, 0.0], device=DEV), (15.0, 15.0), torch.tensor([0.0, 1.0, 0.0], device=DEV),
+                   sigma_scale=0.01, error_scale_mrad=90.0, resolution=R, batch_size=B, device=DEV)
+    with torch.no_grad():
+        obs = env.reset()
+    w = torch.zeros(N * 3, N * 3, device=DEV, requires_grad=True)
+    total = 0.0
+    for _ in range(3):
+        normals = torch.nn.functional.normalize(env.ideal_normals + (obs["aux"][:, 3:] @ w).view(B, N, 3), dim=2)
+        obs, losses, monitor = env.step(normals)
+        total = total + losses["alignment_loss"] + 1e-3 * losses["dist"] + losses["mse"] + 1e-3 * losses["bound"]
+    total.backward()
+    assert torch.isfinite(w.grad).all() and w.grad.abs().max().item() > 0
+    o, l, m = env.step(env.ideal_normals.reshape(B, -1).cpu().numpy())
+    assert o["img"].shape == (B, R, R) and torch.isfinite(l["dist"])

@@ -272,3 +272,46 @@ def test_synthetic_inputs_are_shard_invariant():
     assert torch.equal(errs[4:7], e2) and torch.equal(noise[4:7], n2)
     assert (suns[:, 2] >= 0).all() and torch.allclose(suns.norm(dim=1), torch.full((10,), synthetic.SUN_RADIUS))
     assert set(synthetic.CONFIGS) == {"cfg1", "cfg2", "cfg4", "cfg5"}
+
+
+def test_env_surface_the_training_loop_uses(monkeypatch):
+    """What train_with_env.py's rollout() touches (:171-216, :235-275): attributes, a [B,N,3] action
+    straight from a policy head, observation shapes, history rolling."""
+    oracle_backend.install(monkeypatch)
+    from doodle_amd.env import HelioEnv
+    torch.manual_seed(0)
+    N, B, R, k = 6, 4, 16, 3
+    hp = torch.rand(N, 3) * 10 + 80
+    hp[:, 2] = 0
+    env = HelioEnv(heliostat_pos=hp, targ_pos=torch.tensor([0.0, -5.0, 0.0]), targ_area=(15.0, 15.0),
+                   targ_norm=torch.tensor([0.0, 1.0, 0.0]), sigma_scale=0.05, error_scale_mrad=5.0,
+                   initial_action_noise=0.0, resolution=R, batch_size=B, device="cpu",
+                   new_sun_pos_every_reset=False, new_errors_every_reset=True, use_error_mask=False,
+                   error_mask_ratio=0.2, exponential_risk=False)
+    env.seed(3)
+    for attr in ("batch_size", "resolution", "sun_pos", "ref_min", "ref_max", "distance_maps", "num_heliostats",
+                 "ref_field", "noisy_field", "action_space", "observation_space", "heliostat_pos", "targ_pos",
+                 "targ_area", "targ_norm", "sigma_scale", "error_scale_mrad", "device"):
+        assert hasattr(env, attr), attr
+    with torch.no_grad():
+        obs = env.reset()
+    assert env.ideal_normals.shape == (B, N, 3)
+    hist = obs["img"].unsqueeze(1).repeat(1, k, 1, 1)                 # rollout(): hist [B,k,R,R]
+    w = torch.zeros(N * 3, N * 3, requires_grad=True)                    # a stand-in policy head
+    total = 0.0
+    for _ in range(3):
+        normals = torch.nn.functional.normalize(env.ideal_normals + (obs["aux"][:, 3:] @ w).view(B, N, 3), dim=2)
+        obs, losses, monitor = env.step(normals)                         # [B,N,3] action
+        assert obs["img"].shape == (B, R, R) and obs["aux"].shape == (B, 3 + 3 * N)
+        assert monitor["normals"].shape == (B, N, 3) and monitor["reflected_rays"].shape == (B * N, 3)
+        assert monitor["all_bounds"].shape == (B, N) and monitor["mae_image"].shape == (B, 1)
+        hist = torch.roll(hist, -1, dims=1)
+        hist[:, -1] = obs["img"].detach()
+        total = total + losses["alignment_loss"] + 1e-3 * losses["dist"] + losses["mse"] + 1e-3 * losses["bound"]
+    total.backward()
+    assert w.grad is not None and torch.isfinite(w.grad).all()
+    # set_sun_pos with the suns of another env (:255, :275) and numpy actions (:411-412)
+    env.set_sun_pos(env.sun_pos * 1.0)
+    env.reset()
+    o, l, m = env.step(env.ideal_normals.reshape(B, -1).numpy())
+    assert float(l["alignment_loss"]) >= 0.0 and o["img"].shape == (B, R, R)
