@@ -50,7 +50,7 @@ __device__ __forceinline__ RayLoss ray_loss(const float* __restrict__ ideal, con
     const float c0 = (ideal[0] * actual[0] + ideal[1] * actual[1]) + ideal[2] * actual[2];
     const float hi = 0.99999994f;        // nextafter(1,0) - 1e-10, rounded to fp32
     r.clamped = !(c0 > -hi && c0 < hi);
-    r.c = fminf(fmaxf(c0, -hi), hi);
+    r.c = c0 != c0 ? c0 : fminf(fmaxf(c0, -hi), hi);          // torch.clamp keeps a NaN
     r.ang = acosf(r.c) * 1000.0f;
     // :115-130  boundary()
     const float dots = -((v[0] * g.tn[0] + v[1] * g.tn[1]) + v[2] * g.tn[2]);
@@ -59,8 +59,11 @@ __device__ __forceinline__ RayLoss ray_loss(const float* __restrict__ ideal, con
     r.t = ((g.tp[0] * v[0] + g.tp[1] * v[1]) + g.tp[2] * v[2]) / r.den;
     r.xl = (h[0] + v[0] * r.t) - g.tp[0];            // local·(1,0,0)
     r.yl = (h[2] + v[2] * r.t) - g.tp[2];            // local·(0,0,1)
-    r.dx = fmaxf(fabsf(r.xl) - g.hwt, 0.0f);
-    r.dy = fmaxf(fabsf(r.yl) - g.hht, 0.0f);
+    // F.relu keeps a NaN (fmaxf would drop it): a NaN normal must poison the boundary loss, which
+    // the reference's asserts then report (:497, :501)
+    const float ex = fabsf(r.xl) - g.hwt, ey = fabsf(r.yl) - g.hht;
+    r.dx = (ex > 0.0f || ex != ex) ? ex : 0.0f;
+    r.dy = (ey > 0.0f || ey != ey) ? ey : 0.0f;
     r.dist = sqrtf((r.dx * r.dx + r.dy * r.dy) + 1e-8f);
     r.inside = fabsf(r.xl) <= g.hw && fabsf(r.yl) <= g.hh && valid;
     r.out = r.inside ? 0.0f : r.dist;

@@ -112,7 +112,9 @@ class HelioEnv(_EnvBase):
         self.single_sun = single_sun
         self.use_error_mask, self.error_mask_ratio = use_error_mask, error_mask_ratio
         self.exponential_risk = exponential_risk
-        self.check_finite = True        # the NaN/Inf asserts of :495-501 (one host sync per step)
+        # the NaN/Inf asserts of :495-501, one host sync per step (False skips it; measured: the step
+        # is then bound by its three-kernel GPU chain, 34 µs instead of 48 µs at config 2)
+        self.check_finite = True
         self._ref_cache = None
         f3 = ctypes.c_float * 3
         self._tp3 = f3(*[float(x) for x in targ_pos.detach().cpu().tolist()])
@@ -230,7 +232,7 @@ class HelioEnv(_EnvBase):
                                                                                              consts)
         if fast is None:
             aux = torch.cat([self.sun_pos.detach(), action.flatten(1)], dim=1)
-        if self.check_finite and bool(flag):                             # :495-501, one sync instead of six
+        if self.check_finite and bool(flag):                           # :495-501, one sync instead of six
             raise AssertionError("MSE, distance loss or boundary loss is NaN or Inf")
         metrics = {"mse": mse, "dist": dist_l, "bound": bound, "alignment_loss": alignment_loss}
         obs = {"img": img, "aux": aux}

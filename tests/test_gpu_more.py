@@ -553,3 +553,23 @@ def test_rollout_like_the_training_loop_on_gpu():
     assert torch.isfinite(w.grad).all() and w.grad.abs().max().item() > 0
     o, l, m = env.step(env.ideal_normals.reshape(B, -1).cpu().numpy())
     assert o["img"].shape == (B, R, R) and torch.isfinite(l["dist"])
+
+
+def test_nan_action_trips_the_finite_check():
+    """A NaN normal: the reference's ray/plane test marks the ray invalid (image stays finite) but
+    relu/clamp propagate the NaN into the boundary loss, which its asserts report (:497)."""
+    from doodle_amd.env import HelioEnv
+    torch.manual_seed(0)
+    hp = torch.rand(5, 3, device=DEV) * 10 + 80
+    hp[:, 2] = 0
+    env = HelioEnv(hp, torch.tensor([0.0, -5.0, 0.0], device=DEV), (15.0, 15.0), torch.tensor([0.0, 1.0, 0.0], device=DEV),
+                   sigma_scale=0.05, error_scale_mrad=5.0, resolution=32, batch_size=4, device=DEV)
+    env.reset()
+    bad = env.ideal_normals.reshape(4, -1).clone()
+    bad[0, 0] = float("nan")
+    with torch.no_grad():
+        with pytest.raises(AssertionError):
+            env.step(bad)
+        env.check_finite = False
+        obs, losses, _ = env.step(bad)
+        assert torch.isnan(losses["bound"]) and torch.isnan(losses["alignment_loss"])
