@@ -30,9 +30,12 @@ __device__ __forceinline__ float dot3(vec3 a, vec3 b) {
 __device__ __forceinline__ vec3 sub3(vec3 a, vec3 b) { return {__fsub_rn(a.x, b.x), __fsub_rn(a.y, b.y), __fsub_rn(a.z, b.z)}; }
 __device__ __forceinline__ vec3 add3(vec3 a, vec3 b) { return {__fadd_rn(a.x, b.x), __fadd_rn(a.y, b.y), __fadd_rn(a.z, b.z)}; }
 __device__ __forceinline__ vec3 scale3(float s, vec3 a) { return {__fmul_rn(s, a.x), __fmul_rn(s, a.y), __fmul_rn(s, a.z)}; }
+// torch's clamp_min keeps a NaN (fmaxf would replace it by the bound)
+__device__ __forceinline__ float clamp_min_t(float x, float lo) { return x != x ? x : fmaxf(x, lo); }
+
 // x / max(|x|, 1e-9); also hands back the clamped norm
 __device__ __forceinline__ vec3 unit3(vec3 v, float& nclamped) {
-    float n = fmaxf(norm3(v), 1e-9f);
+    float n = clamp_min_t(norm3(v), 1e-9f);
     nclamped = n;
     return {__fdiv_rn(v.x, n), __fdiv_rn(v.y, n), __fdiv_rn(v.z, n)};
 }

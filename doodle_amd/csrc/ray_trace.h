@@ -66,9 +66,9 @@ __device__ __forceinline__ Ray trace(vec3 nin, float ce, float se, float cu, flo
     q.dh = sub3(q.x, h);
     q.dist = norm3(q.dh);
     q.sraw = __fmul_rn(P.sigma_scale, q.dist);
-    q.sigma = fmaxf(q.sraw, 1e-9f);
+    q.sigma = clamp_min_t(q.sraw, 1e-9f);
     q.two_raw = __fmul_rn(2.0f, __fmul_rn(q.sigma, q.sigma));
-    q.two_s2 = fmaxf(q.two_raw, 1e-12f);
+    q.two_s2 = clamp_min_t(q.two_raw, 1e-12f);
     // separable restatement of :134-148: with d0 = o - x and the
     // orthonormal frame (u, v, w = u×v),  |P_ij - x|² = (xs_i+a)² + (ys_j+b)² + c²
     q.d0 = sub3(P.o, q.x);

@@ -573,3 +573,37 @@ def test_nan_action_trips_the_finite_check():
         env.check_finite = False
         obs, losses, _ = env.step(bad)
         assert torch.isnan(losses["bound"]) and torch.isnan(losses["alignment_loss"])
+
+
+def test_nan_and_inf_inputs_propagate_like_the_reference():
+    """Garbage in: NaN / Inf components in the action, as torch's clamp_min / where / relu treat
+    them.  `actual`, `refl` and the image match the oracle with NaNs in the same places."""
+    from doodle_amd import HelioField
+    torch.manual_seed(1)
+    N, B, R = 6, 2, 24
+    helios = torch.rand(N, 3) * 10 + 80
+    helios[:, 2] = 0
+    suns = torch.tensor([[5000.0, 6000.0, 11000.0], [-3000.0, 9000.0, 4000.0]])
+    tp, tn = torch.tensor([0.0, -5.0, 0.0]), torch.tensor([0.0, 1.0, 0.0])
+    sc = to.Scene.build(helios, tp, (15.0, 15.0), tn, R, 0.05)
+    act = to.ideal_normals(helios, tp, suns).clone()
+    act[0, 0, 0] = float("nan")
+    act[0, 1, 2] = float("inf")
+    act[1, 2] = float("nan")
+    act[1, 3, 1] = -float("inf")
+    errs = torch.randn(B, N, 2) * 5.0
+    img_o, actual_o, refl_o = to.render(sc, suns, act.reshape(B, -1), errs, monitor=True)
+    f = HelioField(helios, tp, (15.0, 15.0), tn, error_scale_mrad=5.0, sigma_scale=0.05, resolution=R, device=DEV,
+                   max_batch_size=B)
+    f.batch_error_angles_mrad = errs
+    for variant in (0, 3):          # fused single launch, and geometry + splat
+        from doodle_amd import native
+        native.get_ops().splat_variant = variant
+        try:
+            img, actual, refl = f.render(suns, act.reshape(B, -1).to(DEV), None, monitor=True)
+        finally:
+            native.get_ops().splat_variant = 0
+        assert np.array_equal(actual.cpu().numpy(), actual_o.numpy(), equal_nan=True)
+        assert np.array_equal(refl.cpu().numpy(), refl_o.numpy(), equal_nan=True)
+        assert np.array_equal(np.isnan(img.cpu().numpy()), np.isnan(img_o.numpy()))
+        np.testing.assert_allclose(img.cpu().numpy(), img_o.numpy(), rtol=1e-5, atol=1e-8, equal_nan=True)
