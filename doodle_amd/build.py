@@ -17,7 +17,7 @@ LIB = os.path.join(HERE, "libhelio.so")
 COMM_LIB = os.path.join(HERE, "libhelio_comm.so")      # RCCL wrapper, separate so that the
 COMM_SOURCES = ["comm.hip"]                             # kernels library has no RCCL dependency
 SOURCES = ["abi.hip", "geometry.hip", "splat_fwd.hip", "splat_bwd.hip", "step_losses.hip", "edt.hip"]
-HEADERS = [os.path.join(CSRC, "helio_math.h"), os.path.join(CSRC, "ray_trace.h"),
+HEADERS = [os.path.join(CSRC, "helio_math.h"), os.path.join(CSRC, "ray_trace.h"), os.path.join(CSRC, "step_loss_math.h"),
            os.path.join(ROOT, "include", "helio.h"), os.path.join(ROOT, "include", "helio_comm.h")]
 # -ffp-contract=off: the geometry stage is bit-faithful to the reference's fp32 CPU
 # arithmetic; FMAs appear only where written (helio_math.h).  Division and sqrt stay
@@ -70,7 +70,7 @@ def build_hostbind(force: bool = False, verbose: bool = False):
     Host C++ against the torch headers (≈1 min); links libhelio.so, so build() runs first."""
     src = os.path.join(CSRC, "hostbind.cpp")
     so = hostbind_path()
-    if not force and so and os.path.getmtime(so) >= max(os.path.getmtime(src), os.path.getmtime(HEADERS[2])):
+    if not force and so and os.path.getmtime(so) >= max(os.path.getmtime(src), os.path.getmtime(os.path.join(ROOT, "include", "helio.h"))):
         return so
     build(force=False, verbose=verbose)
     cmd = [sys.executable, os.path.join(HERE, "setup_hostbind.py"), "-q", "build_ext", "--inplace",

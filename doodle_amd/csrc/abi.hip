@@ -4,6 +4,7 @@
 // allocates.  No exception crosses the boundary: errors are negative return codes plus
 // a thread-local message.
 #include <hip/hip_runtime.h>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -26,13 +27,20 @@ int step_losses_ray_wgs(int, int);
 int step_losses_max_mask_batch();
 void launch_step_losses_fwd(int, int, int, const float*, const float*, const float*, const float*, const float*,
                             const float*, const float*, const float*, const float*, const float*, float, float, int,
-                            float, float*, float*, float*, float*, float*, float*, const float*, float*, hipStream_t);
+                            float, float*, float*, float*, float*, float*, float*, const float*, float*, int*, int,
+                            hipStream_t);
 void launch_step_losses_bwd(int, int, int, const float*, const float*, const float*, const float*, const float*,
                             const float*, const float*, const float*, const float*, const float*, float, float, int,
                             const float*, const float*, const float*, const float*, const float*, float*, float*,
                             float*, hipStream_t);
 void launch_render_fused(int, int, int, const float*, const float*, const float*, const float*, long,
                          const helio_plane*, const float*, const float*, float*, float*, float*, float*, hipStream_t);
+long env_step_fused_workspace(int, int);
+void launch_env_step_fused(int, int, int, const float*, const float*, const float*, const float*, long,
+                           const helio_plane*, const float*, const float*, float*, float*, float*, float*,
+                           const float*, const float*, const float*, const float*, const float*, const float*, float,
+                           float, int, float, float*, float*, float*, float*, float*, float*, float*, int*, int,
+                           hipStream_t);
 }  // namespace helio
 
 namespace {
@@ -234,7 +242,7 @@ int helio_step_losses_fwd(int B, int N, int R, const float* img_d, const float* 
     helio::launch_step_losses_fwd(B, N, R, img_d, target_d, tx_d, dmaps_d, ideal_d, actual_d, action_d, helios_d,
                                   target_position, target_normal, width, height, exponential_risk, error_mask_ratio,
                                   workspace_d, out_d, mae_d, keep_d, align_err_d, all_bounds_d, sun_d, aux_d,
-                                  static_cast<hipStream_t>(stream));
+                                  nullptr, 0, static_cast<hipStream_t>(stream));
     return after_launch("step_losses_fwd");
 }
 
@@ -255,6 +263,96 @@ int helio_step_losses_bwd(int B, int N, int R, const float* img_d, const float* 
                                   g_bound_d, g_align_d, keep_d, grad_img_d, grad_actual_d, grad_action_d,
                                   static_cast<hipStream_t>(stream));
     return after_launch("step_losses_bwd");
+}
+
+long helio_env_step_workspace(int B, int N, int R) {
+    const long a = helio_step_losses_workspace(B, N, R);
+    if (a == 0) return 0;
+    const long f = helio::env_step_fused_workspace(B, R);
+    return a > f ? a : f;
+}
+
+int helio_env_step_launches(int B, int N, int R) {
+    return (sizes_ok(B, N) && R >= 1 && helio::render_is_fused(B, N, R)) ? 2 : 4;
+}
+
+int helio_env_step_fwd(int B, int N, int R, const float* helios_d, const float* sun_d, const float* action_d,
+                       const float* trig_d, long trig_b_stride, const helio_plane* plane, const float* xs_d,
+                       const float* ys_d, float* actual_d, float* refl_d, float* rays_d, float* image_d, int variant,
+                       const float* target_d, const float* tx_d, const float* dmaps_d, const float* ideal_d,
+                       const float target_position[3], const float target_normal[3], float width, float height,
+                       int exponential_risk, float error_mask_ratio, float* workspace_d, float* out_d, float* mae_d,
+                       float* keep_d, float* align_err_d, float* all_bounds_d, float* aux_d, int* notify, int ticket,
+                       void* stream) {
+    if (notify && ticket == 0) return fail(HELIO_E_INVALID, "env_step_fwd: ticket 0 is reserved");
+    if ((variant == 0 || variant == 2) && sizes_ok(B, N) && R >= 1 && R <= 16384 && helio::render_is_fused(B, N, R)) {
+        if (!helios_d || !sun_d || !action_d || !trig_d || !plane || !xs_d || !ys_d || !actual_d || !image_d ||
+            !target_d || !tx_d || !dmaps_d || !ideal_d || !target_position || !target_normal || !workspace_d ||
+            !out_d || !mae_d || !keep_d || !align_err_d || !all_bounds_d)
+            return fail(HELIO_E_INVALID, "env_step_fwd: null pointer");
+        if (trig_b_stride != 0 && trig_b_stride != 4l * N)
+            return fail(HELIO_E_INVALID, "env_step_fwd: trig_b_stride must be 0 or 4*N");
+        if (!aligned16(trig_d) || (rays_d && !aligned16(rays_d)))
+            return fail(HELIO_E_INVALID, "env_step_fwd: trig/rays must be 16-byte aligned");
+        if (error_mask_ratio >= 0.0f && (error_mask_ratio > 1.0f || B > helio::step_losses_max_mask_batch()))
+            return fail(HELIO_E_INVALID, "env_step_fwd: error mask needs ratio in [0,1] and B <= %d",
+                        helio::step_losses_max_mask_batch());
+        helio::launch_env_step_fused(B, N, R, helios_d, sun_d, action_d, trig_d, trig_b_stride, plane, xs_d, ys_d,
+                                     actual_d, refl_d, rays_d, image_d, target_d, tx_d, dmaps_d, ideal_d,
+                                     target_position, target_normal, width, height, exponential_risk,
+                                     error_mask_ratio, workspace_d, out_d, mae_d, keep_d, align_err_d, all_bounds_d,
+                                     aux_d, notify, ticket, static_cast<hipStream_t>(stream));
+        return after_launch("env_step_fwd(fused)");
+    }
+    const int rc = helio_render_fwd(B, N, R, helios_d, sun_d, action_d, trig_d, trig_b_stride, plane, xs_d, ys_d,
+                                    actual_d, refl_d, rays_d, image_d, variant, stream);
+    if (rc != HELIO_OK) return rc;
+    // the two-call form, with the same checks as helio_step_losses_fwd
+    if (!target_d || !tx_d || !dmaps_d || !ideal_d || !target_position || !target_normal || !workspace_d || !out_d ||
+        !mae_d || !keep_d || !align_err_d || !all_bounds_d)
+        return fail(HELIO_E_INVALID, "env_step_fwd: null pointer");
+    if (error_mask_ratio >= 0.0f && (error_mask_ratio > 1.0f || B > helio::step_losses_max_mask_batch()))
+        return fail(HELIO_E_INVALID, "env_step_fwd: error mask needs ratio in [0,1] and B <= %d",
+                    helio::step_losses_max_mask_batch());
+    if (!aligned16(target_d) || !aligned16(dmaps_d))
+        return fail(HELIO_E_INVALID, "env_step_fwd: images must be 16-byte aligned");
+    helio::launch_step_losses_fwd(B, N, R, image_d, target_d, tx_d, dmaps_d, ideal_d, actual_d, action_d, helios_d,
+                                  target_position, target_normal, width, height, exponential_risk, error_mask_ratio,
+                                  workspace_d, out_d, mae_d, keep_d, align_err_d, all_bounds_d, sun_d, aux_d, notify,
+                                  ticket, static_cast<hipStream_t>(stream));
+    return after_launch("env_step_fwd");
+}
+
+int helio_notify_create(int** record) {
+    if (!record) return fail(HELIO_E_INVALID, "notify_create: null pointer");
+    void* p = nullptr;
+    if (hipHostMalloc(&p, 2 * HELIO_NOTIFY_SLOTS * sizeof(int), hipHostMallocMapped | hipHostMallocCoherent | hipHostMallocPortable) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(HELIO_E_NODEVICE, "notify_create: hipHostMalloc failed");
+    }
+    memset(p, 0, 2 * HELIO_NOTIFY_SLOTS * sizeof(int));
+    *record = static_cast<int*>(p);
+    return HELIO_OK;
+}
+
+int helio_notify_destroy(int* record) {
+    if (record && hipHostFree(record) != hipSuccess) { (void)hipGetLastError(); return fail(HELIO_E_INVALID, "notify_destroy: not a record"); }
+    return HELIO_OK;
+}
+
+int helio_notify_wait(const int* record, int ticket, double timeout_seconds) {
+    if (!record || ticket == 0) return fail(HELIO_E_INVALID, "notify_wait: null record or ticket 0");
+    const int* slot = record + 2 * (ticket & (HELIO_NOTIFY_SLOTS - 1));
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spin = 1;; ++spin) {
+        const int seen = __atomic_load_n(slot + 1, __ATOMIC_ACQUIRE);
+        if (seen == ticket) return __atomic_load_n(slot, __ATOMIC_RELAXED) ? 1 : 0;
+        if (seen != 0 && (int)((unsigned)seen - (unsigned)ticket) > 0)
+            return fail(HELIO_E_STALE, "notify_wait: slot reused by ticket %d while waiting for %d", seen, ticket);
+        if ((spin & 1023) == 0 &&
+            std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_seconds)
+            return fail(HELIO_E_TIMEOUT, "notify_wait: ticket %d not published within %.3f s", ticket, timeout_seconds);
+    }
 }
 
 }  // extern "C"

@@ -139,25 +139,60 @@ py::tuple step_losses_bwd(const at::Tensor& img, const at::Tensor& target, const
     return py::make_tuple(o(gi), o(ga), o(gn));
 }
 
-// HelioEnv.step without autograd in ONE binding call: render (with its dtype/shape fix-ups),
-// loss block and the `aux` observation (test_environment.py:416-457, :424).  Same C ABI calls as
-// the separate paths; it only removes Python between them.
+// HelioEnv.step forward (render + loss block + optional `aux` row) through helio_env_step_fwd:
+// → (image, actual, refl, rays, out[5], mae, angles, all_bounds, keep, aux|None)
+py::tuple env_step_core(int64_t plane, const at::Tensor& helios, const at::Tensor& sun, const at::Tensor& normals,
+                        const at::Tensor& trig, int64_t trig_b_stride, const at::Tensor& xs, const at::Tensor& ys,
+                        c10::optional<at::Tensor> rays_ws, int64_t variant, const at::Tensor& target,
+                        const at::Tensor& tx, const at::Tensor& dmaps, const at::Tensor& ideal,
+                        const std::vector<double>& tp, const std::vector<double>& tn, double W, double H,
+                        bool exp_risk, double mask_ratio, bool want_aux, int64_t notify, int64_t ticket) {
+    const int64_t B = normals.size(0), N = normals.size(1), R = xs.size(0);
+    const float tpf[3] = {(float)tp[0], (float)tp[1], (float)tp[2]}, tnf[3] = {(float)tn[0], (float)tn[1], (float)tn[2]};
+    const auto opt = normals.options();
+    const float* pn = fp(normals, "action");
+    at::Tensor actual = at::empty_like(normals), refl = at::empty_like(normals);
+    at::Tensor rays = rays_ws.has_value() ? *rays_ws : at::empty({B, N, HELIO_RAY_STRIDE}, opt);
+    at::Tensor image = at::empty({B, R, R}, opt);
+    at::Tensor ws = at::empty({helio_env_step_workspace((int)B, (int)N, (int)R)}, opt);
+    at::Tensor out = at::empty({5}, opt), mae = at::empty({B}, opt), keep = at::empty({B}, opt);
+    at::Tensor align = at::empty({B, N}, opt), allb = at::empty({B, N}, opt);
+    at::Tensor aux = want_aux ? at::empty({B, 3 + 3 * N}, opt) : at::Tensor();
+    check(helio_env_step_fwd((int)B, (int)N, (int)R, fp(helios, "heliostat_positions"), fp(sun, "sun"), pn,
+                             fp(trig, "trig"), (long)trig_b_stride, reinterpret_cast<const helio_plane*>(plane),
+                             fp(xs, "xs"), fp(ys, "ys"), actual.data_ptr<float>(), refl.data_ptr<float>(),
+                             rays.data_ptr<float>(), image.data_ptr<float>(), (int)variant, fp(target, "target"),
+                             fp(tx, "tx"), fp(dmaps, "distance_maps"), fp(ideal, "ideal"), tpf, tnf, (float)W,
+                             (float)H, exp_risk ? 1 : 0, (float)mask_ratio, ws.data_ptr<float>(),
+                             out.data_ptr<float>(), mae.data_ptr<float>(), keep.data_ptr<float>(),
+                             align.data_ptr<float>(), allb.data_ptr<float>(),
+                             want_aux ? aux.data_ptr<float>() : nullptr, reinterpret_cast<int*>(notify), (int)ticket,
+                             cur_stream(normals)));
+    py::object aux_o = want_aux ? py::cast(aux) : py::none();
+    return py::make_tuple(image, actual, refl, rays, out, mae, align, allb, keep, aux_o);
+}
+
+// HelioEnv.step without autograd in ONE binding call: the dtype/shape fix-ups of the action
+// (test_environment.py:416-424) plus env_step_core.  It only removes Python between them.
 py::tuple env_step_fwd(int64_t plane, const at::Tensor& helios, const at::Tensor& sun, const at::Tensor& action_in,
                        const at::Tensor& trig, int64_t trig_b_stride, const at::Tensor& xs, const at::Tensor& ys,
                        c10::optional<at::Tensor> rays_ws, int64_t variant, const at::Tensor& target,
                        const at::Tensor& tx, const at::Tensor& dmaps, const at::Tensor& ideal,
                        const std::vector<double>& tp, const std::vector<double>& tn, double W, double H,
-                       bool exp_risk, double mask_ratio) {
+                       bool exp_risk, double mask_ratio, int64_t notify, int64_t ticket) {
     const int64_t B = sun.size(0), N = helios.size(0);
     at::Tensor action = action_in.to(helios.options(), false, false);
     at::Tensor normals = action.reshape({B, N, 3}).contiguous();
     if (rays_ws.has_value() && (rays_ws->size(0) != B || rays_ws->device() != normals.device())) rays_ws.reset();
-    py::tuple r = render_fwd(plane, helios, sun, normals, trig, trig_b_stride, xs, ys, rays_ws, true, variant);
-    at::Tensor image = r[0].cast<at::Tensor>(), actual = r[1].cast<at::Tensor>();
-    at::Tensor aux = at::empty({B, 3 + 3 * N}, normals.options());       // filled by the loss launch
-    py::tuple l = step_losses_fwd(image, target, tx, dmaps, ideal, actual, normals, helios, tp, tn, W, H, exp_risk,
-                                  mask_ratio, sun, aux);
-    return py::make_tuple(image, actual, r[2], r[3], l[0], l[1], l[2], l[3], l[4], aux, normals);
+    py::tuple r = env_step_core(plane, helios, sun, normals, trig, trig_b_stride, xs, ys, rays_ws, variant, target, tx,
+                                dmaps, ideal, tp, tn, W, H, exp_risk, mask_ratio, true, notify, ticket);
+    return py::make_tuple(r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7], r[8], r[9], normals);
+}
+
+// helio_notify_wait with the GIL released: → 0/1 flag, or a negative HELIO_E_* code
+int64_t notify_wait(int64_t record, int64_t ticket, double timeout_seconds) {
+    py::gil_scoped_release nogil;
+    return helio_notify_wait(reinterpret_cast<const int*>(record), (int)ticket, timeout_seconds);
 }
 
 at::Tensor ideal_normals(const at::Tensor& helios, const at::Tensor& sun, const std::vector<double>& target) {
@@ -185,5 +220,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
           py::arg("aux") = py::none());
     m.def("step_losses_bwd", &step_losses_bwd);
     m.def("env_step_fwd", &env_step_fwd);
+    m.def("env_step_core", &env_step_core);
+    m.def("notify_wait", &notify_wait);
     m.def("ideal_normals", &ideal_normals);
 }

@@ -30,6 +30,7 @@
 #include <hip/hip_runtime.h>
 #include "helio.h"
 #include "ray_trace.h"
+#include "step_loss_math.h"
 
 namespace helio {
 
@@ -400,14 +401,24 @@ splat_fwd_mfma_tile(int B, int N, int R, const float* __restrict__ rays, const f
 // trace() of ray_trace.h straight into the LDS ray table — and the workgroup of tile 0 also
 // writes `actual`, `refl` and the `rays` work buffer.  The redundant geometry (once per tile
 // of an image) is a few hundred flops per ray.
+//
+// LOSS = true is HelioEnv.step's small-problem forward in the same launch (test_environment.py
+// :416-457): the tile's share of the three image sums is taken from the accumulator registers
+// (the image is still written — it is an output of step() — but never re-read), and the writer
+// workgroup of an image evaluates the two ray losses and the `aux` row on the rays it has just
+// traced.  Partials go to the same [B, chunks, 3] / [ray_wgs, 2] layout step_losses_final reduces
+// (chunks = tiles per image, ray_wgs = B); fixed order, no atomics.
+template <bool LOSS>
 __global__ void __launch_bounds__(256)
 render_fwd_fused_small(int B, int N, int R, const float* __restrict__ helios, const float* __restrict__ sun,
                        const float* __restrict__ action, const float* __restrict__ trig, long trig_b_stride,
                        PlaneK P, const float* __restrict__ xs, const float* __restrict__ ys,
                        float* __restrict__ actual, float* __restrict__ refl, float* __restrict__ rays,
-                       float* __restrict__ image) {
+                       float* __restrict__ image, StepLossArgs L) {
     constexpr int NC = 128;
     __shared__ float4 sRay[NC + 4];
+    __shared__ float scratch[4];
+    float ray_sa = 0.0f, ray_sb = 0.0f;
 
     const int tiles_j = (R + 63) / 64;
     const int b = blockIdx.y;
@@ -441,6 +452,19 @@ render_fwd_fused_small(int B, int N, int R, const float* __restrict__ helios, co
                     st3(actual + 3 * m, q.act);
                     if (refl) st3(refl + 3 * m, q.r);
                     if (rays) *reinterpret_cast<float4*>(rays + 4 * m) = make_float4(q.a, q.b, q.k2, q.c2);
+                    if constexpr (LOSS) {
+                        const float act[3] = {q.act.x, q.act.y, q.act.z};
+                        const RayLoss r = ray_loss(L.ideal + 3 * m, act, action + 3 * m, helios + 3l * n, L.g);
+                        L.align_err[m] = r.ang;
+                        L.all_bounds[m] = r.out;
+                        if (L.aux) {     // observation row [sun_b, action_b] (test_environment.py:424)
+                            float* a = L.aux + (long)b * (3 + 3l * N);
+                            a[3 + 3 * n] = action[3 * m]; a[4 + 3 * n] = action[3 * m + 1]; a[5 + 3 * n] = action[3 * m + 2];
+                            if (n == 0) { a[0] = s.x; a[1] = s.y; a[2] = s.z; }
+                        }
+                        ray_sa += r.ang;
+                        ray_sb += L.g.exponential_risk ? expf(r.out + 1e-6f) : r.out;
+                    }
                 }
             }
             sRay[tid] = v;
@@ -466,6 +490,36 @@ render_fwd_fused_small(int B, int N, int R, const float* __restrict__ helios, co
         for (int e = 0; e < 16; ++e) { acc[e] = 0.0f; acc2[e] = 0.0f; }
     }
     store_block(image + (long)b * R * R, R, i0, j0, lr, lh, tot);
+    if constexpr (LOSS) {
+        const long base = (long)b * R * R;
+        const float sc = L.tx[b];
+        const int j = j0 + lr;
+        float sq = 0.f, ab = 0.f, ds = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int i = i0 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+            if (i < R && j < R) {
+                const long p = base + (long)i * R + j;
+                const float d = tot[e] / sc - L.target[p] / sc;      // as the reference divides (:438-441)
+                const float ad = fabsf(d);
+                sq = __builtin_fmaf(d, d, sq);
+                ab += ad;
+                ds = __builtin_fmaf(ad, L.dmaps[p], ds);
+            }
+        }
+        sq = block_sum(sq, scratch);
+        ab = block_sum(ab, scratch);
+        ds = block_sum(ds, scratch);
+        if (tid == 0) {
+            float* o = L.part_img + 3l * ((long)b * gridDim.x + blockIdx.x);
+            o[0] = sq; o[1] = ab; o[2] = ds;
+        }
+        if (writer) {            // block-uniform
+            ray_sa = block_sum(ray_sa, scratch);
+            ray_sb = block_sum(ray_sb, scratch);
+            if (tid == 0) { L.part_ray[2l * b] = ray_sa; L.part_ray[2l * b + 1] = ray_sb; }
+        }
+    }
 }
 
 // true when launch_render_fwd() would take the single-launch path
@@ -480,8 +534,38 @@ void launch_render_fused(int B, int N, int R, const float* helios, const float* 
                          const float* trig, long trig_b_stride, const helio_plane* plane, const float* xs,
                          const float* ys, float* actual, float* refl, float* rays, float* image, hipStream_t st) {
     const int t = (R + 63) / 64;
-    hipLaunchKernelGGL(render_fwd_fused_small, dim3(t * t, B), dim3(256), 0, st, B, N, R, helios, sun, action,
-                       trig, trig_b_stride, to_k(plane), xs, ys, actual, refl, rays, image);
+    hipLaunchKernelGGL(render_fwd_fused_small<false>, dim3(t * t, B), dim3(256), 0, st, B, N, R, helios, sun, action,
+                       trig, trig_b_stride, to_k(plane), xs, ys, actual, refl, rays, image, StepLossArgs{});
+}
+
+void launch_step_losses_final(int, int, int, int, int, float, const float*, const float*, float*, float*, float*,
+                              int*, int, hipStream_t);
+
+// workspace floats of the fused env step: [B, tiles, 3] image partials + [B, 2] ray partials
+long env_step_fused_workspace(int B, int R) {
+    const long t = (R + 63) / 64;
+    return 3l * B * t * t + 2l * B;
+}
+
+// HelioEnv.step forward for the problems render_is_fused() selects: render + loss partials in one
+// launch, then the finishing workgroup of step_losses.hip — 2 launches for the whole step
+void launch_env_step_fused(int B, int N, int R, const float* helios, const float* sun, const float* action,
+                           const float* trig, long trig_b_stride, const helio_plane* plane, const float* xs,
+                           const float* ys, float* actual, float* refl, float* rays, float* image,
+                           const float* target, const float* tx, const float* dmaps, const float* ideal,
+                           const float* tp, const float* tn, float W, float H, int exponential_risk,
+                           float mask_ratio, float* workspace, float* out, float* mae, float* keep,
+                           float* align_err, float* all_bounds, float* aux, int* notify, int ticket,
+                           hipStream_t st) {
+    const int t = (R + 63) / 64;
+    StepLossArgs L;
+    L.target = target; L.tx = tx; L.dmaps = dmaps; L.ideal = ideal;
+    L.part_img = workspace; L.part_ray = workspace + 3l * B * t * t;
+    L.align_err = align_err; L.all_bounds = all_bounds; L.aux = aux;
+    L.g = make_geom(tp, tn, W, H, exponential_risk);
+    hipLaunchKernelGGL(render_fwd_fused_small<true>, dim3(t * t, B), dim3(256), 0, st, B, N, R, helios, sun, action,
+                       trig, trig_b_stride, to_k(plane), xs, ys, actual, refl, rays, image, L);
+    launch_step_losses_final(B, N, R, t * t, B, mask_ratio, L.part_img, L.part_ray, out, mae, keep, notify, ticket, st);
 }
 
 // (A double-buffered form — 32-ray chunks, two LDS buffers, one barrier per chunk, producers

@@ -9,66 +9,13 @@
 // Reductions are two-stage in a fixed order (no atomics): bit-reproducible run to run.
 #include <hip/hip_runtime.h>
 #include "helio.h"
+#include "step_loss_math.h"
 
 namespace helio {
 
 constexpr int SL_THREADS = 256;
 constexpr int SL_PIX_PER_WG = 4096;     // 16 pixels per thread
 constexpr int SL_RAYS_PER_WG = 256;
-
-struct LossGeom {                        // host constants of boundary(), by value
-    float tp[3], tn[3];                  // target position / normal (as the env stores them)
-    float hw, hh;                        // 0.75·W/2, 0.75·H/2   (test_environment.py:123)
-    float hwt, hht;                      // hw·0.75, hh·0.75     (:124)
-    int exponential_risk;
-};
-
-__device__ __forceinline__ float block_sum(float v, float* scratch) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
-    __syncthreads();
-    return (scratch[0] + scratch[1]) + (scratch[2] + scratch[3]);
-}
-
-// per-ray forward of the two ray losses; shared by forward and backward
-struct RayLoss {
-    float c, ang;            // clamped cosine, angle [mrad]
-    bool clamped;
-    float out;               // boundary term
-    // intermediates for the adjoint
-    float t, den, xl, yl, dx, dy, dist;
-    bool inside;
-};
-
-__device__ __forceinline__ RayLoss ray_loss(const float* __restrict__ ideal, const float* __restrict__ actual,
-                                            const float* __restrict__ v, const float* __restrict__ h,
-                                            const LossGeom& g) {
-    RayLoss r;
-    // :144-155  acos(clamp(<ideal,actual>)) · 1000
-    const float c0 = (ideal[0] * actual[0] + ideal[1] * actual[1]) + ideal[2] * actual[2];
-    const float hi = 0.99999994f;        // nextafter(1,0) - 1e-10, rounded to fp32
-    r.clamped = !(c0 > -hi && c0 < hi);
-    r.c = c0 != c0 ? c0 : fminf(fmaxf(c0, -hi), hi);          // torch.clamp keeps a NaN
-    r.ang = acosf(r.c) * 1000.0f;
-    // :115-130  boundary()
-    const float dots = -((v[0] * g.tn[0] + v[1] * g.tn[1]) + v[2] * g.tn[2]);
-    const bool valid = fabsf(dots) > 1e-6f;
-    r.den = dots + (valid ? 0.0f : 1e-6f);
-    r.t = ((g.tp[0] * v[0] + g.tp[1] * v[1]) + g.tp[2] * v[2]) / r.den;
-    r.xl = (h[0] + v[0] * r.t) - g.tp[0];            // local·(1,0,0)
-    r.yl = (h[2] + v[2] * r.t) - g.tp[2];            // local·(0,0,1)
-    // F.relu keeps a NaN (fmaxf would drop it): a NaN normal must poison the boundary loss, which
-    // the reference's asserts then report (:497, :501)
-    const float ex = fabsf(r.xl) - g.hwt, ey = fabsf(r.yl) - g.hht;
-    r.dx = (ex > 0.0f || ex != ex) ? ex : 0.0f;
-    r.dy = (ey > 0.0f || ey != ey) ? ey : 0.0f;
-    r.dist = sqrtf((r.dx * r.dx + r.dy * r.dy) + 1e-8f);
-    r.inside = fabsf(r.xl) <= g.hw && fabsf(r.yl) <= g.hh && valid;
-    r.out = r.inside ? 0.0f : r.dist;
-    return r;
-}
 
 // grid.x = image workgroups (B·chunks) followed by ray workgroups
 __global__ void __launch_bounds__(SL_THREADS)
@@ -155,7 +102,7 @@ constexpr int SL_MAX_MASK_B = 4096;
 __global__ void __launch_bounds__(SL_THREADS)
 step_losses_final(int B, int N, int R, int chunks, int ray_wgs, float mask_ratio, const float* __restrict__ part_img,
                   const float* __restrict__ part_ray, float* __restrict__ out, float* __restrict__ mae,
-                  float* __restrict__ keep) {
+                  float* __restrict__ keep, int* notify, int ticket) {
     __shared__ double red[4][SL_THREADS];
     __shared__ float smae[SL_MAX_MASK_B];
     __shared__ float order[2];
@@ -210,7 +157,13 @@ step_losses_final(int B, int N, int R, int chunks, int ray_wgs, float mask_ratio
         const float mse = (float)(red[0][0] / (B * P)), dist = (float)(red[1][0] / B);
         const float bound = (float)(red[3][0] / M), align = (float)(red[2][0] / M);
         out[0] = mse; out[1] = dist; out[2] = bound; out[3] = align;
-        out[4] = (isfinite(mse) && isfinite(dist) && isfinite(bound)) ? 0.0f : 1.0f;
+        const bool bad = !(isfinite(mse) && isfinite(dist) && isfinite(bound));
+        out[4] = bad ? 1.0f : 0.0f;
+        if (notify) {       // coherent pinned host memory: (flag, ticket), ticket released last
+            int* slot = notify + 2 * (ticket & (HELIO_NOTIFY_SLOTS - 1));
+            slot[0] = bad ? 1 : 0;
+            __hip_atomic_store(slot + 1, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 
@@ -296,33 +249,30 @@ step_losses_bwd(int B, int N, int R, int chunks, const float* __restrict__ img,
     }
 }
 
-static LossGeom make_geom(const float* tp, const float* tn, float W, float H, int exponential_risk) {
-    LossGeom g;
-    for (int k = 0; k < 3; ++k) { g.tp[k] = tp[k]; g.tn[k] = tn[k]; }
-    g.hw = (W * 0.75f) / 2.0f; g.hh = (H * 0.75f) / 2.0f;
-    g.hwt = g.hw * 0.75f; g.hht = g.hh * 0.75f;
-    g.exponential_risk = exponential_risk;
-    return g;
-}
-
 int step_losses_max_mask_batch() { return SL_MAX_MASK_B; }
 int step_losses_chunks(int R) { return (int)(((long)R * R + SL_PIX_PER_WG - 1) / SL_PIX_PER_WG); }
 int step_losses_ray_wgs(int B, int N) { return (int)(((long)B * N + SL_RAYS_PER_WG - 1) / SL_RAYS_PER_WG); }
+
+void launch_step_losses_final(int B, int N, int R, int chunks, int ray_wgs, float mask_ratio, const float* part_img,
+                              const float* part_ray, float* out, float* mae, float* keep, int* notify, int ticket,
+                              hipStream_t st) {
+    hipLaunchKernelGGL(step_losses_final, dim3(1), dim3(SL_THREADS), 0, st, B, N, R, chunks, ray_wgs, mask_ratio,
+                       part_img, part_ray, out, mae, keep, notify, ticket);
+}
 
 void launch_step_losses_fwd(int B, int N, int R, const float* img, const float* target, const float* tx,
                             const float* dmaps, const float* ideal, const float* actual, const float* action,
                             const float* helios, const float* tp, const float* tn, float W, float H,
                             int exponential_risk, float mask_ratio, float* workspace, float* out, float* mae,
                             float* keep, float* align_err, float* all_bounds, const float* sun, float* aux,
-                            hipStream_t st) {
+                            int* notify, int ticket, hipStream_t st) {
     const int chunks = step_losses_chunks(R), rw = step_losses_ray_wgs(B, N);
     float* part_img = workspace;
     float* part_ray = workspace + 3l * B * chunks;
     hipLaunchKernelGGL(step_losses_partial, dim3(B * chunks + rw), dim3(SL_THREADS), 0, st, B, N, R, chunks, img,
                        target, tx, dmaps, ideal, actual, action, helios, make_geom(tp, tn, W, H, exponential_risk),
                        part_img, part_ray, align_err, all_bounds, sun, aux);
-    hipLaunchKernelGGL(step_losses_final, dim3(1), dim3(SL_THREADS), 0, st, B, N, R, chunks, rw, mask_ratio, part_img,
-                       part_ray, out, mae, keep);
+    launch_step_losses_final(B, N, R, chunks, rw, mask_ratio, part_img, part_ray, out, mae, keep, notify, ticket, st);
 }
 
 void launch_step_losses_bwd(int B, int N, int R, const float* img, const float* target, const float* tx,

@@ -19,6 +19,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
+from . import field as _field
 from .field import HelioField
 from .losses import StepConstants, env_step_fused, step_losses
 
@@ -212,19 +213,21 @@ class HelioEnv(_EnvBase):
                                self._tp3, self._tn3, float(self.targ_area[0]), float(self.targ_area[1]),
                                bool(self.exponential_risk),
                                float(self.error_mask_ratio) if self.use_error_mask else -1.0)
-        fast = None
+        fast, ticket = None, 0
         if torch.is_grad_enabled() and action.requires_grad:
             # render + loss block as one autograd node
             (img, actual, reflected, mse, dist_l, bound, alignment_loss, mae, angles, all_bounds,
-             flag) = env_step_fused(self.noisy_field, self.sun_pos, normals.contiguous(), consts)
+             flag) = env_step_fused(self.noisy_field, self.sun_pos, normals.contiguous(), consts,
+                                    notify=self.check_finite)
+            ticket = consts.ticket
         else:
-            from . import field as _field
             step_fn = getattr(_field._get_ops(), "env_step_nograd", None)
             if step_fn is not None and type(action) is torch.Tensor:
                 trig, stride = self.noisy_field._select_trig(self.batch_size)
-                fast = step_fn(self.noisy_field, self.sun_pos, action, trig, stride, consts)
+                fast = step_fn(self.noisy_field, self.sun_pos, action, trig, stride, consts,
+                               notify=self.check_finite)
             if fast is not None:     # everything in one call of the compiled binding
-                img, actual, reflected, out, mae, angles, all_bounds, aux, normals = fast
+                img, actual, reflected, out, mae, angles, all_bounds, aux, normals, ticket = fast
                 mse, dist_l, bound, alignment_loss, flag = out[0], out[1], out[2], out[3], out[4]
             else:
                 img, actual, reflected = self.noisy_field.render(self.sun_pos, action, ideal, monitor=True)
@@ -232,8 +235,11 @@ class HelioEnv(_EnvBase):
                                                                                              consts)
         if fast is None:
             aux = torch.cat([self.sun_pos.detach(), action.flatten(1)], dim=1)
-        if self.check_finite and bool(flag):                           # :495-501, one sync instead of six
-            raise AssertionError("MSE, distance loss or boundary loss is NaN or Inf")
+        if self.check_finite:                                          # :495-501, one wait instead of six syncs
+            # the finishing workgroup publishes the flag to pinned host memory (helio_notify_*)
+            bad = _field._get_ops().notify_wait(ticket) if ticket else None
+            if bool(flag) if bad is None else bad:
+                raise AssertionError("MSE, distance loss or boundary loss is NaN or Inf")
         metrics = {"mse": mse, "dist": dist_l, "bound": bound, "alignment_loss": alignment_loss}
         obs = {"img": img, "aux": aux}
         monitor = {

@@ -30,6 +30,7 @@ class StepConstants:
     H: float
     exp_risk: bool
     mask_ratio: float = -1.0  # use_error_mask: fraction of worst images kept (< 0: no mask)
+    ticket: int = 0           # out: completion ticket of the last env_step_fused(notify=True)
 
 
 class _StepLosses(torch.autograd.Function):
@@ -56,17 +57,18 @@ class _StepLosses(torch.autograd.Function):
 
 class _EnvStep(torch.autograd.Function):
     """render + loss block as ONE autograd node (what HelioEnv.step differentiates): forward =
-    helio_render_fwd + helio_step_losses_fwd, backward = helio_step_losses_bwd + helio_render_bwd.
+    helio_env_step_fwd (render + loss block; 2 launches for small problems), backward = helio_step_losses_bwd + helio_render_bwd.
     Same kernels as ``_Render`` followed by ``_StepLosses``; it only spares the autograd engine
     five graph nodes per step (the TTT inner loop of the reference calls step+backward 800 times
     per optimiser step)."""
 
     @staticmethod
-    def forward(ctx, normals, field, sun, trig, trig_stride, consts):
+    def forward(ctx, normals, field, sun, trig, trig_stride, consts, notify):
         ops = _field._get_ops()
-        image, actual, refl, rays = ops.render_fwd(field.heliostat_positions, sun, normals, trig, trig_stride,
-                                                   field._plane, field._xs, field._ys)
-        out, mae, align, allb, keep = ops.step_losses_fwd(image, actual, normals, consts)
+        image, actual, refl, rays, out, mae, align, allb, keep, _, ticket = ops.env_step_fwd(
+            field.heliostat_positions, sun, normals, trig, trig_stride, field._plane, field._xs, field._ys, consts,
+            notify=notify)
+        consts.ticket = ticket
         ctx.field, ctx.trig_stride, ctx.consts = field, trig_stride, consts
         ctx.save_for_backward(normals, sun, trig, rays, image, actual, keep)
         ctx.set_materialize_grads(False)
@@ -93,14 +95,15 @@ class _EnvStep(torch.autograd.Function):
                                field._xs, field._ys, c(g_image), c(g_actual), c(g_refl))
             if gn is not None:
                 g = g + gn
-        return g, None, None, None, None, None
+        return g, None, None, None, None, None, None
 
 
-def env_step_fused(field, sun, normals, consts: StepConstants):
+def env_step_fused(field, sun, normals, consts: StepConstants, notify: bool = False):
     """One autograd node for HelioEnv.step: → (image, actual, refl [B,N,3], mse, dist, bound,
-    alignment_loss, mae [B], angles [B,N], all_bounds [B,N], flag)."""
+    alignment_loss, mae [B], angles [B,N], all_bounds [B,N], flag).  With ``notify`` the step's
+    completion ticket (for ``ops.notify_wait``) is left in ``consts.ticket``."""
     trig, stride = field._select_trig(sun.shape[0])
-    return _EnvStep.apply(normals, field, sun, trig, stride, consts)
+    return _EnvStep.apply(normals, field, sun, trig, stride, consts, notify)
 
 
 def step_losses(img, actual, action, consts: StepConstants):

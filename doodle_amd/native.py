@@ -23,6 +23,8 @@ EXPORTS = (
     "helio_splat_fwd", "helio_render_fwd", "helio_render_bwd", "helio_render_fwd_launches", "helio_splat_bwd_blocks", "helio_splat_bwd", "helio_geometry_bwd",
     "helio_ideal_normals", "helio_step_losses_workspace", "helio_step_losses_fwd", "helio_step_losses_bwd",
     "helio_distance_maps_workspace", "helio_distance_maps",
+    "helio_env_step_workspace", "helio_env_step_launches", "helio_env_step_fwd",
+    "helio_notify_create", "helio_notify_destroy", "helio_notify_wait",
 )
 
 
@@ -68,6 +70,13 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
         "helio_step_losses_workspace": (_l, [_i, _i, _i]),
         "helio_step_losses_fwd": (_i, [_i, _i, _i] + [_vp] * 8 + [_f3, _f3, _f, _f, _i, _f] + [_vp] * 8 + [_vp]),
         "helio_step_losses_bwd": (_i, [_i, _i, _i] + [_vp] * 8 + [_f3, _f3, _f, _f, _i] + [_vp] * 5 + [_vp] * 3 + [_vp]),
+        "helio_env_step_workspace": (_l, [_i, _i, _i]),
+        "helio_env_step_launches": (_i, [_i, _i, _i]),
+        "helio_env_step_fwd": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _l, pp, _vp, _vp, _vp, _vp, _vp, _vp, _i]
+                               + [_vp] * 4 + [_f3, _f3, _f, _f, _i, _f] + [_vp] * 7 + [_vp, _i, _vp]),
+        "helio_notify_create": (_i, [ctypes.POINTER(_vp)]),
+        "helio_notify_destroy": (_i, [_vp]),
+        "helio_notify_wait": (_i, [_vp, _i, ctypes.c_double]),
     }
     for name, (res, args) in protos.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
@@ -137,6 +146,7 @@ class HipOps:
         self.splat_variant = int(os.environ.get("HELIO_SPLAT_VARIANT", "0"))
         self.bwd_variant = int(os.environ.get("HELIO_BWD_VARIANT", "0"))
         self.hb = _load_hostbind()
+        self._notify, self._ticket = None, 0      # completion record (helio_notify_create), lazily
 
     def error_trig(self, errs):
         """[..., 2] mrad error angles on the device → [..., 4] (cos_e, sin_e, cos_u, sin_u)."""
@@ -186,18 +196,68 @@ class HipOps:
         field._ray_ws = out[3]
         return out
 
-    def env_step_nograd(self, field, sun, action, trig, trig_b_stride, c):
+    # -- completion record of the env step (include/helio.h, helio_notify_*) --------------------
+    def _next_ticket(self):
+        """→ (record pointer, ticket) for one helio_env_step_fwd call."""
+        if self._notify is None:
+            rec = _vp()
+            _check(self.lib, self.lib.helio_notify_create(ctypes.byref(rec)))
+            self._notify = rec.value
+        self._ticket = self._ticket % 0x7FFFFFFF + 1          # never 0
+        return self._notify, self._ticket
+
+    def notify_wait(self, ticket, timeout=30.0):
+        """The NaN/Inf flag of the env step issued with ``ticket``, polled from pinned host memory
+        (no hipMemcpy, no stream synchronise).  None when the slot is no longer available or the
+        step has not finished in ``timeout`` seconds: read the device flag instead."""
+        if self.hb is not None:
+            rc = self.hb.notify_wait(self._notify, ticket, timeout)
+        else:
+            rc = self.lib.helio_notify_wait(self._notify, ticket, timeout)
+        return bool(rc) if rc >= 0 else None
+
+    def env_step_fwd(self, helios, sun, normals, trig, trig_b_stride, plane, xs, ys, c, rays=None, want_aux=False,
+                     notify=False):
+        """HelioEnv.step forward — render + loss block (+ the `aux` observation row) in ONE C call
+        (``helio_env_step_fwd``: 2 launches for small problems, the loss partials taken from the
+        image tile in registers).  → (image, actual, refl, rays, out[5], mae, angles, all_bounds,
+        keep, aux | None, ticket) — ``ticket`` (0 without ``notify``) is for ``notify_wait``."""
+        rec, ticket = self._next_ticket() if notify else (0, 0)
+        if self.hb is not None:
+            return (*self.hb.env_step_core(_plane_handle(self.hb, plane), helios, sun, normals, trig, trig_b_stride,
+                                           xs, ys, rays, self.splat_variant, c.target, c.tx, c.dmaps, c.ideal,
+                                           list(c.tp), list(c.tn), c.W, c.H, bool(c.exp_risk), float(c.mask_ratio),
+                                           bool(want_aux), rec, ticket), ticket)
+        B, N, R = normals.shape[0], normals.shape[1], xs.shape[0]
+        dev = normals.device
+        new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)  # noqa: E731
+        actual, refl, image = torch.empty_like(normals), torch.empty_like(normals), new(B, R, R)
+        if rays is None:
+            rays = new(B, N, RAY_STRIDE)
+        ws = new(self.lib.helio_env_step_workspace(B, N, R))
+        out, mae, keep, align, allb = new(5), new(B), new(B), new(B, N), new(B, N)
+        aux = new(B, 3 + 3 * N) if want_aux else None
+        _check(self.lib, self.lib.helio_env_step_fwd(
+            B, N, R, _dev(helios), _dev(sun), _dev(normals), _dev(trig), trig_b_stride, plane, _dev(xs), _dev(ys),
+            actual.data_ptr(), refl.data_ptr(), rays.data_ptr(), image.data_ptr(), self.splat_variant,
+            _dev(c.target), _dev(c.tx), _dev(c.dmaps), _dev(c.ideal), c.tp, c.tn, c.W, c.H, int(c.exp_risk),
+            float(c.mask_ratio), ws.data_ptr(), out.data_ptr(), mae.data_ptr(), keep.data_ptr(), align.data_ptr(),
+            allb.data_ptr(), aux.data_ptr() if want_aux else None, rec or None, ticket, _stream()))
+        return image, actual, refl, rays, out, mae, align, allb, keep, aux, ticket
+
+    def env_step_nograd(self, field, sun, action, trig, trig_b_stride, c, notify=False):
         """HelioEnv.step without autograd in one call of the compiled binding (render + loss block +
         aux).  Returns None when that binding is not built.  → (image, actual, refl [B,N,3], out[5],
-        mae, angles, all_bounds, aux, normals)."""
+        mae, angles, all_bounds, aux, normals, ticket)."""
         if self.hb is None:
             return None
+        rec, ticket = self._next_ticket() if notify else (0, 0)
         r = self.hb.env_step_fwd(_plane_handle(self.hb, field._plane), field.heliostat_positions, sun, action, trig,
                                  trig_b_stride, field._xs, field._ys, field._ray_ws, self.splat_variant, c.target,
                                  c.tx, c.dmaps, c.ideal, list(c.tp), list(c.tn), c.W, c.H, bool(c.exp_risk),
-                                 float(c.mask_ratio))
+                                 float(c.mask_ratio), rec, ticket)
         field._ray_ws = r[3]
-        return r[0], r[1], r[2], r[4], r[5], r[6], r[7], r[9], r[10]
+        return r[0], r[1], r[2], r[4], r[5], r[6], r[7], r[9], r[10], ticket
 
     def splat_fwd(self, rays, xs, ys, variant=None):
         B, N, R = rays.shape[0], rays.shape[1], xs.shape[0]

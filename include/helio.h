@@ -33,6 +33,8 @@ extern "C" {
 #define HELIO_E_INVALID    -1   /* bad size / null pointer                       */
 #define HELIO_E_LAUNCH     -2   /* hipGetLastError() after a launch was not ok   */
 #define HELIO_E_NODEVICE   -3   /* no HIP device / wrong architecture            */
+#define HELIO_E_TIMEOUT    -4   /* helio_notify_wait: the record was not written in time */
+#define HELIO_E_STALE      -5   /* helio_notify_wait: the slot was reused by a later ticket */
 
 /* Receiver plane, HOST memory (passed by value to the kernels).
  * origin = target_position, normal = unit target normal (ctor :184-192),
@@ -226,6 +228,39 @@ int helio_step_losses_bwd(int B, int N, int R,
                           const float *g_mse_d, const float *g_dist_d, const float *g_bound_d, const float *g_align_d,
                           const float *keep_d,
                           float *grad_img_d, float *grad_actual_d, float *grad_action_d, void *stream);
+
+/*
+ * HelioEnv.step forward in one call (test_environment.py:416-457): helio_render_fwd followed by
+ * helio_step_losses_fwd on the image and normals it produced, arguments as in those two.  For
+ * the problem sizes helio_render_fwd runs as one launch, the loss partial sums are taken in
+ * that same launch from the image tile in registers (2 launches for the whole step, the image
+ * is written once and never re-read); otherwise it is exactly the two calls (4 launches).
+ * workspace_d: helio_env_step_workspace(B,N,R) floats.  helio_env_step_launches → 2 or 4.
+ *
+ * The reference asserts after every step that mse, dist and bound are finite (:495-501): six
+ * device→host reads.  out_d[4] is that test as one flag; with notify != NULL (a record from
+ * helio_notify_create) and ticket != 0 the finishing workgroup also publishes (flag, ticket) to
+ * slot ticket % HELIO_NOTIFY_SLOTS of the record, which lives in coherent pinned host memory:
+ * helio_notify_wait(record, ticket, timeout) polls it and returns the flag (0/1) without a
+ * hipMemcpy or a stream synchronise (≈12 µs on an idle MI355X).  HELIO_E_STALE: more than
+ * HELIO_NOTIFY_SLOTS later tickets were issued before this wait — read out_d[4] instead.
+ */
+#define HELIO_NOTIFY_SLOTS 64
+int helio_notify_create(int **record);      /* host pointer, valid on every device */
+int helio_notify_destroy(int *record);
+int helio_notify_wait(const int *record, int ticket, double timeout_seconds);
+long helio_env_step_workspace(int B, int N, int R);
+int helio_env_step_launches(int B, int N, int R);
+int helio_env_step_fwd(int B, int N, int R,
+                       const float *helios_d, const float *sun_d, const float *action_d,
+                       const float *trig_d, long trig_b_stride, const helio_plane *plane,
+                       const float *xs_d, const float *ys_d,
+                       float *actual_d, float *refl_d, float *rays_d, float *image_d, int variant,
+                       const float *target_d, const float *tx_d, const float *dmaps_d, const float *ideal_d,
+                       const float target_position[3], const float target_normal[3],
+                       float width, float height, int exponential_risk, float error_mask_ratio,
+                       float *workspace_d, float *out_d, float *mae_d, float *keep_d, float *align_err_d,
+                       float *all_bounds_d, float *aux_d, int *notify, int ticket, void *stream);
 
 #ifdef __cplusplus
 }

@@ -115,6 +115,13 @@ class OracleOps:
         bad = ~torch.isfinite(torch.stack([mse, dist, bound])).all()
         return torch.stack([mse, dist, bound, align, bad.float()]), mae, ang, allb, torch.ones_like(mae)
 
+    def env_step_fwd(self, helios, sun, normals, trig, trig_b_stride, plane, xs, ys, c, rays=None, want_aux=False,
+                     notify=False):
+        image, actual, refl, r = self.render_fwd(helios, sun, normals, trig, trig_b_stride, plane, xs, ys)
+        out, mae, ang, allb, keep = self.step_losses_fwd(image, actual, normals, c)
+        aux = torch.cat([sun, normals.reshape(sun.shape[0], -1)], dim=1) if want_aux else None
+        return image, actual, refl, r, out, mae, ang, allb, keep, aux, 0
+
     def step_losses_bwd(self, img, actual, action, c, g_mse, g_dist, g_bound, g_align, keep, want_img, want_actual,
                         want_action):
         with torch.enable_grad():

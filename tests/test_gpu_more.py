@@ -607,3 +607,106 @@ def test_nan_and_inf_inputs_propagate_like_the_reference():
         assert np.array_equal(refl.cpu().numpy(), refl_o.numpy(), equal_nan=True)
         assert np.array_equal(np.isnan(img.cpu().numpy()), np.isnan(img_o.numpy()))
         np.testing.assert_allclose(img.cpu().numpy(), img_o.numpy(), rtol=1e-5, atol=1e-8, equal_nan=True)
+
+
+@pytest.mark.parametrize("N,B,R,exp_risk,mask", [(50, 25, 128, False, None), (7, 3, 33, False, None),
+                                                  (130, 4, 100, False, None), (300, 2, 64, False, 0.5),
+                                                  (1, 1, 1, False, None), (50, 25, 64, False, 0.2),
+                                                  (2000, 6, 512, False, None)])   # last: the 4-launch form
+def test_env_step_abi_call_matches_the_two_calls(N, B, R, exp_risk, mask):
+    """helio_env_step_fwd (render + loss partial sums in one launch for small problems) against
+    helio_render_fwd followed by helio_step_losses_fwd, and against the oracle's loss block on
+    the rendered image: image / normals / per-ray terms bit-identical, the reduced scalars to
+    the summation-order tolerance; on both bindings."""
+    import ctypes
+    from doodle_amd import native
+    from doodle_amd.losses import StepConstants
+    ops = native.get_ops()
+    f, _, suns, _, act = make_case(N=N, B=B, R=R, seed=N + B)
+    g = torch.Generator().manual_seed(N * 7 + R)
+    target = torch.rand(B, R, R, generator=g) * 3
+    dmaps = torch.rand(B, R, R, generator=g) * 40
+    ideal = f.calculate_ideal_normals(suns)
+    tp, tn = f.target_position.cpu(), f.target_normal.cpu()
+    f3 = ctypes.c_float * 3
+    c = StepConstants(target.to(DEV), target.amax((1, 2)).clamp_min(1e-6).to(DEV), dmaps.to(DEV), ideal,
+                      f.heliostat_positions, f3(*tp.tolist()), f3(*tn.tolist()), 15.0, 12.0, exp_risk,
+                      -1.0 if mask is None else mask)
+    normals = act.to(DEV).reshape(B, N, 3).contiguous()
+    sun = suns.to(DEV)
+    trig, stride = f._select_trig(B)
+    assert ops.lib.helio_env_step_launches(B, N, R) == (2 if ops.lib.helio_render_fwd_launches(B, N, R) == 1 else 4)
+    got = {}
+    for name, hb in (("hostbind", ops.hb), ("ctypes", None)):
+        if name == "hostbind" and hb is None:
+            continue
+        saved, ops.hb = ops.hb, hb
+        try:
+            fused = ops.env_step_fwd(f.heliostat_positions, sun, normals, trig, stride, f._plane, f._xs, f._ys, c,
+                                     want_aux=True)
+            image, actual, refl, rays = ops.render_fwd(f.heliostat_positions, sun, normals, trig, stride, f._plane,
+                                                       f._xs, f._ys)
+            out, mae, align, allb, keep = ops.step_losses_fwd(image, actual, normals, c)
+        finally:
+            ops.hb = saved
+        got[name] = fused = fused[:10]
+        for p, q in zip(fused[:4], (image, actual, refl, rays)):
+            assert torch.equal(p, q)
+        assert torch.equal(fused[6], align) and torch.equal(fused[7], allb) and torch.equal(fused[8], keep)
+        np.testing.assert_allclose(fused[4].cpu().numpy(), out.cpu().numpy(), rtol=2e-5, atol=1e-7)
+        np.testing.assert_allclose(fused[5].cpu().numpy(), mae.cpu().numpy(), rtol=2e-5, atol=1e-7)
+        assert torch.equal(fused[9], torch.cat([sun, normals.reshape(B, -1)], dim=1))
+    if len(got) == 2:
+        for p, q in zip(got["hostbind"], got["ctypes"]):
+            assert torch.equal(p, q)
+    # the oracle's loss block on the image the kernel rendered
+    fused = next(iter(got.values()))
+    ref = to.step_losses(fused[0].cpu(), target, dmaps, ideal.cpu(), fused[1].cpu(), normals.cpu(),
+                         f.heliostat_positions.cpu(), tp, tn, (15.0, 12.0), exp_risk, mask)
+    for k in range(4):
+        np.testing.assert_allclose(fused[4][k].item(), ref[k].item(), rtol=2e-5, atol=1e-7)
+    np.testing.assert_allclose(fused[5].cpu().numpy(), ref[4].numpy(), rtol=2e-5, atol=1e-7)
+
+
+def test_completion_record_of_the_env_step():
+    """helio_notify_*: the finishing workgroup publishes (flag, ticket) to pinned host memory;
+    helio_notify_wait returns that flag without a device read, reports a reused slot as stale,
+    and agrees with out[4] for finite and non-finite steps — on both bindings."""
+    import ctypes
+    from doodle_amd import native
+    from doodle_amd.losses import StepConstants
+    ops = native.get_ops()
+    N, B, R = 20, 4, 64
+    f, _, suns, _, act = make_case(N=N, B=B, R=R, seed=5)
+    ideal = f.calculate_ideal_normals(suns)
+    g = torch.Generator().manual_seed(1)
+    target = torch.rand(B, R, R, generator=g).to(DEV)
+    f3 = ctypes.c_float * 3
+    c = StepConstants(target, target.amax((1, 2)), torch.rand(B, R, R, generator=g).to(DEV), ideal,
+                      f.heliostat_positions, f3(*f.target_position.tolist()), f3(*f.target_normal.tolist()),
+                      15.0, 12.0, False)
+    sun = suns.to(DEV)
+    good = act.to(DEV).reshape(B, N, 3).contiguous()
+    bad = good.clone()
+    bad[1, 3, 0] = float("nan")
+    trig, stride = f._select_trig(B)
+    step = lambda n: ops.env_step_fwd(f.heliostat_positions, sun, n, trig, stride, f._plane, f._xs, f._ys, c,  # noqa: E731
+                                      notify=True)
+    for hb in (ops.hb, None):
+        saved, ops.hb = ops.hb, hb
+        try:
+            r_good, r_bad = step(good), step(bad)
+            assert r_bad[10] == r_good[10] + 1 and r_good[10] > 0
+            assert ops.notify_wait(r_bad[10]) is True and r_bad[4][4].item() == 1.0
+            assert ops.notify_wait(r_good[10]) is False and r_good[4][4].item() == 0.0
+            first = step(bad)[10]
+            for _ in range(native.ctypes.c_int(64).value):      # HELIO_NOTIFY_SLOTS later tickets reuse the slot
+                last = step(good)[10]
+            torch.cuda.synchronize()
+            assert ops.notify_wait(first) is None               # stale → the caller reads out[4]
+            assert ops.notify_wait(last) is False
+        finally:
+            ops.hb = saved
+    assert ops.lib.helio_notify_wait(None, 1, 0.0) < 0 and ops.lib.helio_notify_wait(ops._notify, 0, 0.0) < 0
+    # a ticket that was never issued times out instead of hanging
+    assert ops.lib.helio_notify_wait(ops._notify, ops._ticket + 1000, 0.01) == -4
