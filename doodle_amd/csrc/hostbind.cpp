@@ -186,7 +186,11 @@ py::tuple env_step_fwd(int64_t plane, const at::Tensor& helios, const at::Tensor
     if (rays_ws.has_value() && (rays_ws->size(0) != B || rays_ws->device() != normals.device())) rays_ws.reset();
     py::tuple r = env_step_core(plane, helios, sun, normals, trig, trig_b_stride, xs, ys, rays_ws, variant, target, tx,
                                 dmaps, ideal, tp, tn, W, H, exp_risk, mask_ratio, true, notify, ticket);
-    return py::make_tuple(r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7], r[8], r[9], normals);
+    // the shapes step() hands out (:503-514), made here: a view costs ≈0.3 µs in C++, ≈1.5 µs in Python
+    const std::vector<at::Tensor> o = r[4].cast<at::Tensor>().unbind(0);
+    return py::make_tuple(r[0], r[1], r[2].cast<at::Tensor>().view({B * N, 3}), r[3], o[0], o[1], o[2], o[3], o[4],
+                          r[5].cast<at::Tensor>().view({B, 1}), r[6].cast<at::Tensor>().view({B * N}), r[7], r[9],
+                          normals);
 }
 
 // helio_notify_wait with the GIL released: → 0/1 flag, or a negative HELIO_E_* code

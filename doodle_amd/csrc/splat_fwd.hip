@@ -404,10 +404,12 @@ splat_fwd_mfma_tile(int B, int N, int R, const float* __restrict__ rays, const f
 //
 // LOSS = true is HelioEnv.step's small-problem forward in the same launch (test_environment.py
 // :416-457): the tile's share of the three image sums is taken from the accumulator registers
-// (the image is still written — it is an output of step() — but never re-read), and the writer
-// workgroup of an image evaluates the two ray losses and the `aux` row on the rays it has just
-// traced.  Partials go to the same [B, chunks, 3] / [ray_wgs, 2] layout step_losses_final reduces
-// (chunks = tiles per image, ray_wgs = B); fixed order, no atomics.
+// (the image is still written — it is an output of step() — but never re-read; the target and
+// distance-map pixels are fetched before the heliostat loop), and ONE EXTRA workgroup per image
+// (blockIdx.x == tiles) takes the per-ray side work off the tiles' critical path: it writes
+// `actual` / `refl` / `rays`, evaluates the two ray losses and fills the `aux` row.  Partials go
+// to the [B, chunks, 3] / [ray_wgs, 2] layout step_losses_final reduces (chunks = tiles per
+// image, ray_wgs = B); fixed order, no atomics.
 template <bool LOSS>
 __global__ void __launch_bounds__(256)
 render_fwd_fused_small(int B, int N, int R, const float* __restrict__ helios, const float* __restrict__ sun,
@@ -417,19 +419,67 @@ render_fwd_fused_small(int B, int N, int R, const float* __restrict__ helios, co
                        float* __restrict__ image, StepLossArgs L) {
     constexpr int NC = 128;
     __shared__ float4 sRay[NC + 4];
-    __shared__ float scratch[4];
-    float ray_sa = 0.0f, ray_sb = 0.0f;
+    __shared__ float scratch[12];
 
     const int tiles_j = (R + 63) / 64;
     const int b = blockIdx.y;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const vec3 s = ld3(sun + 3l * b);
+
+    if constexpr (LOSS) {
+        if ((int)blockIdx.x == tiles_j * tiles_j) {          // the per-ray workgroup of image b
+            float sa = 0.0f, sb = 0.0f;
+            for (int n = tid; n < N; n += 256) {
+                const long m = (long)b * N + n;
+                const float4 tg = *reinterpret_cast<const float4*>(trig + (long)b * trig_b_stride + 4l * n);
+                const vec3 v = ld3(action + 3 * m);
+                const Ray q = trace(v, tg.x, tg.y, tg.z, tg.w, ld3(helios + 3l * n), s, P);
+                st3(actual + 3 * m, q.act);
+                if (refl) st3(refl + 3 * m, q.r);
+                if (rays) *reinterpret_cast<float4*>(rays + 4 * m) = make_float4(q.a, q.b, q.k2, q.c2);
+                const float act[3] = {q.act.x, q.act.y, q.act.z};
+                const RayLoss r = ray_loss(L.ideal + 3 * m, act, action + 3 * m, helios + 3l * n, L.g);
+                L.align_err[m] = r.ang;
+                L.all_bounds[m] = r.out;
+                if (L.aux) {     // observation row [sun_b, action_b] (test_environment.py:424)
+                    float* a = L.aux + (long)b * (3 + 3l * N);
+                    a[3 + 3 * n] = v.x; a[4 + 3 * n] = v.y; a[5 + 3 * n] = v.z;
+                    if (n == 0) { a[0] = s.x; a[1] = s.y; a[2] = s.z; }
+                }
+                sa += r.ang;
+                sb += L.g.exponential_risk ? expf(r.out + 1e-6f) : r.out;
+            }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) { sa += __shfl_xor(sa, d); sb += __shfl_xor(sb, d); }
+            if (lane == 0) { scratch[2 * wave] = sa; scratch[2 * wave + 1] = sb; }
+            __syncthreads();
+            if (tid == 0) {
+                L.part_ray[2l * b] = (scratch[0] + scratch[2]) + (scratch[4] + scratch[6]);
+                L.part_ray[2l * b + 1] = (scratch[1] + scratch[3]) + (scratch[5] + scratch[7]);
+            }
+            return;
+        }
+    }
+
     const int lr = lane & 31, lh = lane >> 5;
     const int i0 = (blockIdx.x / tiles_j) * 64 + (wave >> 1) * 32;
     const int j0 = (blockIdx.x % tiles_j) * 64 + (wave & 1) * 32;
-    const bool writer = blockIdx.x == 0;
+    const bool writer = !LOSS && blockIdx.x == 0;
 
     const float xv = xs[min(i0 + lr, R - 1)], yv = ys[min(j0 + lr, R - 1)];
-    const vec3 s = ld3(sun + 3l * b);
+    // LOSS: this lane's 16 target / distance-map pixels, in flight during the heliostat loop
+    float tgt[16], dmp[16];
+    if constexpr (LOSS) {
+        const long base = (long)b * R * R;
+        const int j = j0 + lr;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int i = i0 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+            const bool in = i < R && j < R;
+            tgt[e] = in ? L.target[base + (long)i * R + j] : 0.0f;
+            dmp[e] = in ? L.dmaps[base + (long)i * R + j] : 0.0f;
+        }
+    }
     // two accumulators (even / odd k-pairs): the two MFMAs of a trip do not depend on each other, so
     // the latency-bound loop of a single wave per SIMD is one MFMA latency per trip, not two
     f32x16 tot, acc, acc2;
@@ -452,19 +502,6 @@ render_fwd_fused_small(int B, int N, int R, const float* __restrict__ helios, co
                     st3(actual + 3 * m, q.act);
                     if (refl) st3(refl + 3 * m, q.r);
                     if (rays) *reinterpret_cast<float4*>(rays + 4 * m) = make_float4(q.a, q.b, q.k2, q.c2);
-                    if constexpr (LOSS) {
-                        const float act[3] = {q.act.x, q.act.y, q.act.z};
-                        const RayLoss r = ray_loss(L.ideal + 3 * m, act, action + 3 * m, helios + 3l * n, L.g);
-                        L.align_err[m] = r.ang;
-                        L.all_bounds[m] = r.out;
-                        if (L.aux) {     // observation row [sun_b, action_b] (test_environment.py:424)
-                            float* a = L.aux + (long)b * (3 + 3l * N);
-                            a[3 + 3 * n] = action[3 * m]; a[4 + 3 * n] = action[3 * m + 1]; a[5 + 3 * n] = action[3 * m + 2];
-                            if (n == 0) { a[0] = s.x; a[1] = s.y; a[2] = s.z; }
-                        }
-                        ray_sa += r.ang;
-                        ray_sb += L.g.exponential_risk ? expf(r.out + 1e-6f) : r.out;
-                    }
                 }
             }
             sRay[tid] = v;
@@ -491,7 +528,6 @@ render_fwd_fused_small(int B, int N, int R, const float* __restrict__ helios, co
     }
     store_block(image + (long)b * R * R, R, i0, j0, lr, lh, tot);
     if constexpr (LOSS) {
-        const long base = (long)b * R * R;
         const float sc = L.tx[b];
         const int j = j0 + lr;
         float sq = 0.f, ab = 0.f, ds = 0.f;
@@ -499,25 +535,20 @@ render_fwd_fused_small(int B, int N, int R, const float* __restrict__ helios, co
         for (int e = 0; e < 16; ++e) {
             const int i = i0 + (e & 3) + 8 * (e >> 2) + 4 * lh;
             if (i < R && j < R) {
-                const long p = base + (long)i * R + j;
-                const float d = tot[e] / sc - L.target[p] / sc;      // as the reference divides (:438-441)
+                const float d = tot[e] / sc - tgt[e] / sc;      // as the reference divides (:438-441)
                 const float ad = fabsf(d);
                 sq = __builtin_fmaf(d, d, sq);
                 ab += ad;
-                ds = __builtin_fmaf(ad, L.dmaps[p], ds);
+                ds = __builtin_fmaf(ad, dmp[e], ds);
             }
         }
-        sq = block_sum(sq, scratch);
-        ab = block_sum(ab, scratch);
-        ds = block_sum(ds, scratch);
-        if (tid == 0) {
-            float* o = L.part_img + 3l * ((long)b * gridDim.x + blockIdx.x);
-            o[0] = sq; o[1] = ab; o[2] = ds;
-        }
-        if (writer) {            // block-uniform
-            ray_sa = block_sum(ray_sa, scratch);
-            ray_sb = block_sum(ray_sb, scratch);
-            if (tid == 0) { L.part_ray[2l * b] = ray_sa; L.part_ray[2l * b + 1] = ray_sb; }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { sq += __shfl_xor(sq, d); ab += __shfl_xor(ab, d); ds += __shfl_xor(ds, d); }
+        if (lane == 0) { scratch[3 * wave] = sq; scratch[3 * wave + 1] = ab; scratch[3 * wave + 2] = ds; }
+        __syncthreads();
+        if (tid < 3) {
+            float* o = L.part_img + 3l * ((long)b * (gridDim.x - 1) + blockIdx.x);
+            o[tid] = (scratch[tid] + scratch[3 + tid]) + (scratch[6 + tid] + scratch[9 + tid]);
         }
     }
 }
@@ -563,7 +594,7 @@ void launch_env_step_fused(int B, int N, int R, const float* helios, const float
     L.part_img = workspace; L.part_ray = workspace + 3l * B * t * t;
     L.align_err = align_err; L.all_bounds = all_bounds; L.aux = aux;
     L.g = make_geom(tp, tn, W, H, exponential_risk);
-    hipLaunchKernelGGL(render_fwd_fused_small<true>, dim3(t * t, B), dim3(256), 0, st, B, N, R, helios, sun, action,
+    hipLaunchKernelGGL(render_fwd_fused_small<true>, dim3(t * t + 1, B), dim3(256), 0, st, B, N, R, helios, sun, action,
                        trig, trig_b_stride, to_k(plane), xs, ys, actual, refl, rays, image, L);
     launch_step_losses_final(B, N, R, t * t, B, mask_ratio, L.part_img, L.part_ray, out, mae, keep, notify, ticket, st);
 }

@@ -103,20 +103,26 @@ __global__ void __launch_bounds__(SL_THREADS)
 step_losses_final(int B, int N, int R, int chunks, int ray_wgs, float mask_ratio, const float* __restrict__ part_img,
                   const float* __restrict__ part_ray, float* __restrict__ out, float* __restrict__ mae,
                   float* __restrict__ keep, int* notify, int ticket) {
-    __shared__ double red[4][SL_THREADS];
+    __shared__ double red[4][SL_THREADS / 64];
     __shared__ float smae[SL_MAX_MASK_B];
     __shared__ float order[2];
     const int tid = threadIdx.x;
     const double P = (double)R * R;
     const bool masked = mask_ratio >= 0.0f;
+    double sq = 0, ds = 0, sa = 0, sb = 0;
+    // one pass over the image partials: per-image mean error, and (no mask) the two image sums
     for (int b = tid; b < B; b += SL_THREADS) {
-        double bab = 0;
-        for (int c = 0; c < chunks; ++c) bab += part_img[3l * ((long)b * chunks + c) + 1];
+        double bsq = 0, bab = 0, bds = 0;
+        for (int c = 0; c < chunks; ++c) {
+            const float* p = part_img + 3l * ((long)b * chunks + c);
+            bsq += p[0]; bab += p[1]; bds += p[2];
+        }
         const float m = (float)(bab / P);
         mae[b] = m;
         if (masked) smae[b] = m;
+        else { keep[b] = 1.0f; sq += bsq; ds += bds; }
     }
-    float cutoff = 0.0f;
+    for (int w = tid; w < ray_wgs; w += SL_THREADS) { sa += part_ray[2l * w]; sb += part_ray[2l * w + 1]; }
     if (masked) {
         // torch.quantile(mae, q): rank = q (B-1); lerp between the two neighbouring order statistics
         const float pos = (1.0f - mask_ratio) * (float)(B - 1);
@@ -131,31 +137,31 @@ step_losses_final(int B, int N, int R, int chunks, int ray_wgs, float mask_ratio
         }
         __syncthreads();
         const float w = pos - (float)lo;
-        cutoff = w < 0.5f ? order[0] + w * (order[1] - order[0]) : order[1] - (order[1] - order[0]) * (1.0f - w);
+        const float cutoff = w < 0.5f ? order[0] + w * (order[1] - order[0]) : order[1] - (order[1] - order[0]) * (1.0f - w);
+        for (int b = tid; b < B; b += SL_THREADS) {
+            const float k = smae[b] > cutoff ? 1.0f : 0.0f;
+            keep[b] = k;
+            if (k != 0.0f)
+                for (int c = 0; c < chunks; ++c) {
+                    const float* p = part_img + 3l * ((long)b * chunks + c);
+                    sq += p[0]; ds += p[2];
+                }
+        }
     }
-    double sq = 0, ds = 0, sa = 0, sb = 0;
-    for (int b = tid; b < B; b += SL_THREADS) {
-        const float k = (!masked || mae[b] > cutoff) ? 1.0f : 0.0f;
-        keep[b] = k;
-        if (k != 0.0f)
-            for (int c = 0; c < chunks; ++c) {
-                const float* p = part_img + 3l * ((long)b * chunks + c);
-                sq += p[0]; ds += p[2];
-            }
-    }
-    for (int w = tid; w < ray_wgs; w += SL_THREADS) { sa += part_ray[2l * w]; sb += part_ray[2l * w + 1]; }
-    red[0][tid] = sq; red[1][tid] = ds; red[2][tid] = sa; red[3][tid] = sb;
-    __syncthreads();
-    for (int s = SL_THREADS / 2; s > 0; s >>= 1) {
-        if (tid < s)
+    // fixed-order fp64 reduction: lanes by shuffles, then the four waves
 #pragma unroll
-            for (int k = 0; k < 4; ++k) red[k][tid] += red[k][tid + s];
-        __syncthreads();
+    for (int d = 32; d >= 1; d >>= 1) {
+        sq += __shfl_xor(sq, d); ds += __shfl_xor(ds, d); sa += __shfl_xor(sa, d); sb += __shfl_xor(sb, d);
     }
+    if ((tid & 63) == 0) { red[0][tid >> 6] = sq; red[1][tid >> 6] = ds; red[2][tid >> 6] = sa; red[3][tid >> 6] = sb; }
+    __syncthreads();
     if (tid == 0) {
+        double t[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) t[k] = (red[k][0] + red[k][1]) + (red[k][2] + red[k][3]);
         const double M = (double)B * N;
-        const float mse = (float)(red[0][0] / (B * P)), dist = (float)(red[1][0] / B);
-        const float bound = (float)(red[3][0] / M), align = (float)(red[2][0] / M);
+        const float mse = (float)(t[0] / (B * P)), dist = (float)(t[1] / B);
+        const float bound = (float)(t[3] / M), align = (float)(t[2] / M);
         out[0] = mse; out[1] = dist; out[2] = bound; out[3] = align;
         const bool bad = !(isfinite(mse) && isfinite(dist) && isfinite(bound));
         out[4] = bad ? 1.0f : 0.0f;

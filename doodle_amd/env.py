@@ -166,7 +166,7 @@ class HelioEnv(_EnvBase):
                 ideal = self.ref_field.calculate_ideal_normals(self.sun_pos)
                 target, _ = self.ref_field.render(self.sun_pos, ideal.flatten(1), ideal)
                 tx = target.amax((1, 2)).clamp_min(1e-6)
-            self._ref_cache = (key, ideal, target, tx, (errs, single))
+            self._ref_cache = (key, ideal, target, tx, (errs, single), ideal.view([-1, 3]))
         return self._ref_cache[1:4]
 
     def set_sun_pos(self, sun_positions: torch.Tensor):
@@ -208,48 +208,51 @@ class HelioEnv(_EnvBase):
         if self.use_error_mask and self.batch_size > 4096:
             raise NotImplementedError("use_error_mask: the fused quantile covers batch_size <= 4096")
         ideal, target, tx = self._reference()
-        normals = action.view(self.batch_size, -1, 3)                    # :460
         consts = StepConstants(target, tx, self.distance_maps, ideal, self.noisy_field.heliostat_positions,
                                self._tp3, self._tn3, float(self.targ_area[0]), float(self.targ_area[1]),
                                bool(self.exponential_risk),
                                float(self.error_mask_ratio) if self.use_error_mask else -1.0)
         fast, ticket = None, 0
-        if torch.is_grad_enabled() and action.requires_grad:
-            # render + loss block as one autograd node
-            (img, actual, reflected, mse, dist_l, bound, alignment_loss, mae, angles, all_bounds,
-             flag) = env_step_fused(self.noisy_field, self.sun_pos, normals.contiguous(), consts,
-                                    notify=self.check_finite)
-            ticket = consts.ticket
-        else:
+        differentiate = torch.is_grad_enabled() and action.requires_grad
+        if not differentiate and type(action) is torch.Tensor:
             step_fn = getattr(_field._get_ops(), "env_step_nograd", None)
-            if step_fn is not None and type(action) is torch.Tensor:
+            if step_fn is not None:      # everything in one call of the compiled binding
                 trig, stride = self.noisy_field._select_trig(self.batch_size)
                 fast = step_fn(self.noisy_field, self.sun_pos, action, trig, stride, consts,
                                notify=self.check_finite)
-            if fast is not None:     # everything in one call of the compiled binding
-                img, actual, reflected, out, mae, angles, all_bounds, aux, normals, ticket = fast
-                mse, dist_l, bound, alignment_loss, flag = out[0], out[1], out[2], out[3], out[4]
+        if fast is not None:
+            (img, actual, reflected, mse, dist_l, bound, alignment_loss, flag, mae, angles, all_bounds, aux,
+             normals, ticket) = fast
+        else:
+            normals = action.view(self.batch_size, -1, 3)                # :460
+            if differentiate:
+                # render + loss block as one autograd node
+                (img, actual, reflected, mse, dist_l, bound, alignment_loss, mae, angles, all_bounds,
+                 flag) = env_step_fused(self.noisy_field, self.sun_pos, normals.contiguous(), consts,
+                                        notify=self.check_finite)
+                ticket = consts.ticket
             else:
                 img, actual, reflected = self.noisy_field.render(self.sun_pos, action, ideal, monitor=True)
                 mse, dist_l, bound, alignment_loss, mae, angles, all_bounds, flag = step_losses(img, actual, normals,
                                                                                              consts)
-        if fast is None:
             aux = torch.cat([self.sun_pos.detach(), action.flatten(1)], dim=1)
-        if self.check_finite:                                          # :495-501, one wait instead of six syncs
-            # the finishing workgroup publishes the flag to pinned host memory (helio_notify_*)
-            bad = _field._get_ops().notify_wait(ticket) if ticket else None
-            if bool(flag) if bad is None else bad:
-                raise AssertionError("MSE, distance loss or boundary loss is NaN or Inf")
+            reflected, mae, angles = reflected.view([-1, 3]), mae.view([-1, 1]), angles.view([-1])
         metrics = {"mse": mse, "dist": dist_l, "bound": bound, "alignment_loss": alignment_loss}
         obs = {"img": img, "aux": aux}
         monitor = {
             "normals": normals,
-            "reflected_rays": reflected.view([-1, 3]),
-            "ideal_normals": ideal.view([-1, 3]),
+            "reflected_rays": reflected,
+            "ideal_normals": self._ref_cache[5],
             "all_bounds": all_bounds,
-            "mae_image": mae.view([-1, 1]),
-            "alignment_errors": angles.view([-1]),
+            "mae_image": mae,
+            "alignment_errors": angles,
         }
+        if self.check_finite:                                          # :495-501, one wait instead of six syncs;
+            # last, so that the dictionaries above are built while the GPU finishes the step.  The
+            # finishing workgroup publishes the flag to pinned host memory (helio_notify_*)
+            bad = _field._get_ops().notify_wait(ticket) if ticket else None
+            if bool(flag) if bad is None else bad:
+                raise AssertionError("MSE, distance loss or boundary loss is NaN or Inf")
         return obs, metrics, monitor
 
     def seed(self, seed=None):

@@ -247,8 +247,9 @@ class HipOps:
 
     def env_step_nograd(self, field, sun, action, trig, trig_b_stride, c, notify=False):
         """HelioEnv.step without autograd in one call of the compiled binding (render + loss block +
-        aux).  Returns None when that binding is not built.  → (image, actual, refl [B,N,3], out[5],
-        mae, angles, all_bounds, aux, normals, ticket)."""
+        aux, outputs already in the shapes step() returns).  None when that binding is not built.
+        → (image, actual, refl [B·N,3], mse, dist, bound, alignment_loss, flag, mae [B,1],
+        angles [B·N], all_bounds [B,N], aux, normals [B,N,3], ticket)."""
         if self.hb is None:
             return None
         rec, ticket = self._next_ticket() if notify else (0, 0)
@@ -257,7 +258,7 @@ class HipOps:
                                  c.tx, c.dmaps, c.ideal, list(c.tp), list(c.tn), c.W, c.H, bool(c.exp_risk),
                                  float(c.mask_ratio), rec, ticket)
         field._ray_ws = r[3]
-        return r[0], r[1], r[2], r[4], r[5], r[6], r[7], r[9], r[10], ticket
+        return (*r[:3], *r[4:], ticket)
 
     def splat_fwd(self, rays, xs, ys, variant=None):
         B, N, R = rays.shape[0], rays.shape[1], xs.shape[0]

@@ -40,3 +40,15 @@ with torch.no_grad():
     print("step_losses                %.2f" % t(lambda: step_losses(img, actual, normals, c)))
     out = step_losses(img, actual, normals, c)
     print("bool(flag) after sync      %.2f" % t(lambda: bool(out[7])))
+    from doodle_amd import field as _field
+    ops = _field._get_ops()
+    trig, stride = env.noisy_field._select_trig(B)
+    print("ops.env_step_nograd        %.2f" % t(lambda: ops.env_step_nograd(env.noisy_field, env.sun_pos, act, trig, stride, c)))
+    print("ops.env_step_nograd+notify %.2f" % t(lambda: ops.env_step_nograd(env.noisy_field, env.sun_pos, act, trig, stride, c, notify=True)))
+    def stepwait():
+        r = ops.env_step_nograd(env.noisy_field, env.sun_pos, act, trig, stride, c, notify=True)
+        ops.notify_wait(r[-1])
+    print("  ... + notify_wait        %.2f" % t(stepwait))
+    print("ops.render_nograd          %.2f" % t(lambda: ops.render_nograd(env.noisy_field, env.sun_pos, act, trig, stride, True)))
+    e = torch.empty
+    print("torch.empty x10            %.2f" % t(lambda: [e(5, device=dev) for _ in range(10)]))
