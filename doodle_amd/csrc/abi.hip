@@ -35,6 +35,14 @@ void launch_step_losses_bwd(int, int, int, const float*, const float*, const flo
                             float*, hipStream_t);
 void launch_render_fused(int, int, int, const float*, const float*, const float*, const float*, long,
                          const helio_plane*, const float*, const float*, float*, float*, float*, float*, hipStream_t);
+bool splat_bwd_is_few(int, int);
+void launch_splat_bwd_fused_loss_raw(int, int, int, const float*, const float*, const float*, const float*,
+                                     const float*, const float*, const float*, const float*, const float*,
+                                     const float*, float*, hipStream_t);
+void launch_geometry_bwd_losses(int, int, int, const float*, const float*, const float*, const float*, long,
+                                const helio_plane*, const float*, const float*, const float*, float*, const float*,
+                                const float*, const float*, const float*, const float*, float, float, int,
+                                hipStream_t);
 long env_step_fused_workspace(int, int);
 void launch_env_step_fused(int, int, int, const float*, const float*, const float*, const float*, long,
                            const helio_plane*, const float*, const float*, float*, float*, float*, float*,
@@ -353,6 +361,55 @@ int helio_notify_wait(const int* record, int ticket, double timeout_seconds) {
             std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_seconds)
             return fail(HELIO_E_TIMEOUT, "notify_wait: ticket %d not published within %.3f s", ticket, timeout_seconds);
     }
+}
+
+int helio_env_step_bwd_image_ws(int B, int N, int R) {
+    (void)R;
+    return helio::splat_bwd_is_few(B, N) ? 0 : 1;
+}
+
+int helio_env_step_bwd(int B, int N, int R, const float* helios_d, const float* sun_d, const float* action_d,
+                       const float* trig_d, long trig_b_stride, const helio_plane* plane, const float* rays_d,
+                       const float* xs_d, const float* ys_d, const float* image_d, const float* target_d,
+                       const float* tx_d, const float* dmaps_d, const float* ideal_d, const float target_position[3],
+                       const float target_normal[3], float width, float height, int exponential_risk,
+                       const float* g_mse_d, const float* g_dist_d, const float* g_bound_d, const float* g_align_d,
+                       const float* keep_d, const float* grad_actual_d, const float* grad_refl_d,
+                       float* grad_image_ws_d, float* moments_d, float* grad_action_d, int variant, void* stream) {
+    if (!sizes_ok(B, N) || R < 1 || R > 16384) return fail(HELIO_E_INVALID, "env_step_bwd: bad sizes B=%d N=%d R=%d", B, N, R);
+    if (!helios_d || !sun_d || !action_d || !trig_d || !plane || !ideal_d || !target_position || !target_normal ||
+        !grad_action_d)
+        return fail(HELIO_E_INVALID, "env_step_bwd: null pointer");
+    if (trig_b_stride != 0 && trig_b_stride != 4l * N)
+        return fail(HELIO_E_INVALID, "env_step_bwd: trig_b_stride must be 0 or 4*N");
+    if (!aligned16(trig_d)) return fail(HELIO_E_INVALID, "env_step_bwd: trig must be 16-byte aligned");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const bool through_image = g_mse_d || g_dist_d;
+    if (through_image) {
+        if (!rays_d || !xs_d || !ys_d || !image_d || !target_d || !tx_d || !dmaps_d || !moments_d)
+            return fail(HELIO_E_INVALID, "env_step_bwd: null pointer (image path)");
+        if (!aligned16(rays_d)) return fail(HELIO_E_INVALID, "env_step_bwd: rays must be 16-byte aligned");
+        if ((variant == 0 || variant == 4) && helio::splat_bwd_is_few(B, N)) {
+            helio::launch_splat_bwd_fused_loss_raw(B, N, R, rays_d, xs_d, ys_d, image_d, target_d, tx_d, dmaps_d,
+                                                   keep_d, g_mse_d, g_dist_d, moments_d, st);
+        } else {
+            if (!grad_image_ws_d) return fail(HELIO_E_INVALID, "env_step_bwd: this problem size needs grad_image_ws_d");
+            if (!aligned16(image_d) || !aligned16(target_d) || !aligned16(dmaps_d) || !aligned16(grad_image_ws_d))
+                return fail(HELIO_E_INVALID, "env_step_bwd: images must be 16-byte aligned");
+            helio::launch_step_losses_bwd(B, N, R, image_d, target_d, tx_d, dmaps_d, ideal_d, nullptr, action_d,
+                                          helios_d, target_position, target_normal, width, height, exponential_risk,
+                                          g_mse_d, g_dist_d, nullptr, nullptr, keep_d, grad_image_ws_d, nullptr,
+                                          nullptr, st);
+            if (helio::launch_splat_bwd(B, N, R, rays_d, xs_d, ys_d, grad_image_ws_d, moments_d, variant, st) != HELIO_OK)
+                return fail(HELIO_E_INVALID, "env_step_bwd: unknown variant %d", variant);
+        }
+    }
+    helio::launch_geometry_bwd_losses(B, N, helio::splat_bwd_blocks(R), helios_d, sun_d, action_d, trig_d,
+                                      trig_b_stride, plane, through_image ? moments_d : nullptr, grad_actual_d,
+                                      grad_refl_d, grad_action_d, (g_align_d || g_bound_d) ? ideal_d : nullptr,
+                                      g_align_d, g_bound_d, target_position, target_normal, width, height,
+                                      exponential_risk, st);
+    return after_launch("env_step_bwd");
 }
 
 }  // extern "C"

@@ -12,6 +12,7 @@
 #include "helio.h"
 #include "helio_math.h"
 #include "ray_trace.h"
+#include "step_loss_math.h"
 
 namespace helio {
 
@@ -44,7 +45,7 @@ geometry_bwd_kernel(int B, int N, int n_blocks,
                     const float* __restrict__ action, const float* __restrict__ trig, long trig_b_stride,
                     PlaneK P, const float* __restrict__ moments,
                     const float* __restrict__ g_actual, const float* __restrict__ g_refl,
-                    float* __restrict__ g_action) {
+                    float* __restrict__ g_action, RayLossBwdArgs RL) {
     const float LN2 = 0.69314718055994530942f;
     const long M = (long)B * N;
     for (long m = (long)blockIdx.x * blockDim.x + threadIdx.x; m < M; m += (long)gridDim.x * blockDim.x) {
@@ -96,6 +97,18 @@ geometry_bwd_kernel(int B, int N, int n_blocks,
         // n̂ = act / max(|act|,1e-9) ; act also is an output
         vec3 gact = unit_bwd(gnh, q.nh, q.na, norm3(q.act) < 1e-9f);
         if (g_actual) { vec3 e = ld3(g_actual + 3 * m); gact.x += e.x; gact.y += e.y; gact.z += e.z; }
+        // HelioEnv.step's ray losses (alignment angle of `actual`, boundary term of the action itself)
+        float lv[3] = {0.f, 0.f, 0.f};
+        if (RL.ideal) {
+            const float act[3] = {q.act.x, q.act.y, q.act.z};
+            const RayLoss r = ray_loss(RL.ideal + 3 * m, act, action + 3 * m, helios + 3l * n, RL.g);
+            const float inv = 1.0f / ((float)B * (float)N);
+            float la[3];
+            ray_loss_bwd(r, RL.ideal + 3 * m, action + 3 * m, RL.g, (RL.g_align ? *RL.g_align : 0.0f) * inv,
+                         (RL.g_bound ? *RL.g_bound : 0.0f) * inv, la, lv);
+            if (RL.g_align) { gact.x += la[0]; gact.y += la[1]; gact.z += la[2]; }
+            if (!RL.g_bound) lv[0] = lv[1] = lv[2] = 0.0f;
+        }
         // act = vrot / max(|vrot|,1e-9)
         vec3 gv = unit_bwd(gact, q.act, q.nv, norm3(q.vrot) < 1e-9f);
         // leaky ReLU on Z, then the two rotations transposed
@@ -104,7 +117,8 @@ geometry_bwd_kernel(int B, int N, int n_blocks,
         const float gz = -se * gv.y + ce * gze;
         const float gxin = cu * gv.x + su * gyu;
         const float gyin = -su * gv.x + cu * gyu;
-        st3(g_action + 3 * m, {gxin, gyin, gz});
+        if (RL.ideal && RL.g_bound) st3(g_action + 3 * m, {gxin + lv[0], gyin + lv[1], gz + lv[2]});
+        else st3(g_action + 3 * m, {gxin, gyin, gz});
     }
 }
 
@@ -149,7 +163,22 @@ void launch_geometry_bwd(int B, int N, int n_blocks, const float* helios, const 
                          const float* g_refl, float* g_action, hipStream_t st) {
     hipLaunchKernelGGL(geometry_bwd_kernel, dim3(ray_grid((long)B * N)), dim3(256), 0, st,
                        B, N, n_blocks, helios, sun, action, trig, trig_b_stride, to_k(plane), moments,
-                       g_actual, g_refl, g_action);
+                       g_actual, g_refl, g_action, RayLossBwdArgs{});
+}
+
+// geometry backward with the adjoint of HelioEnv.step's two ray losses folded in
+void launch_geometry_bwd_losses(int B, int N, int n_blocks, const float* helios, const float* sun,
+                                const float* action, const float* trig, long trig_b_stride,
+                                const helio_plane* plane, const float* moments, const float* g_actual,
+                                const float* g_refl, float* g_action, const float* ideal, const float* g_align,
+                                const float* g_bound, const float* tp, const float* tn, float W, float H,
+                                int exponential_risk, hipStream_t st) {
+    RayLossBwdArgs RL;
+    RL.ideal = ideal; RL.g_align = g_align; RL.g_bound = g_bound;
+    RL.g = make_geom(tp, tn, W, H, exponential_risk);
+    hipLaunchKernelGGL(geometry_bwd_kernel, dim3(ray_grid((long)B * N)), dim3(256), 0, st,
+                       B, N, n_blocks, helios, sun, action, trig, trig_b_stride, to_k(plane), moments,
+                       g_actual, g_refl, g_action, RL);
 }
 
 void launch_error_trig(long M, const float* errs, float* trig, hipStream_t st) {

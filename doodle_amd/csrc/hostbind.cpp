@@ -193,6 +193,38 @@ py::tuple env_step_fwd(int64_t plane, const at::Tensor& helios, const at::Tensor
                           normals);
 }
 
+// Backward of the env step in one call (helio_env_step_bwd): cotangents of the four scalars (0-d
+// device tensors or None) and of actual / refl (or None) → grad_action [B,N,3]
+at::Tensor env_step_bwd(int64_t plane, const at::Tensor& helios, const at::Tensor& sun, const at::Tensor& normals,
+                        const at::Tensor& trig, int64_t trig_b_stride, const at::Tensor& rays, const at::Tensor& xs,
+                        const at::Tensor& ys, const at::Tensor& image, const at::Tensor& target, const at::Tensor& tx,
+                        const at::Tensor& dmaps, const at::Tensor& ideal, const std::vector<double>& tp,
+                        const std::vector<double>& tn, double W, double H, bool exp_risk,
+                        c10::optional<at::Tensor> g_mse, c10::optional<at::Tensor> g_dist,
+                        c10::optional<at::Tensor> g_bound, c10::optional<at::Tensor> g_align,
+                        c10::optional<at::Tensor> keep, c10::optional<at::Tensor> g_actual,
+                        c10::optional<at::Tensor> g_refl, int64_t variant) {
+    const int64_t B = normals.size(0), N = normals.size(1), R = xs.size(0);
+    const float tpf[3] = {(float)tp[0], (float)tp[1], (float)tp[2]}, tnf[3] = {(float)tn[0], (float)tn[1], (float)tn[2]};
+    const bool through_image = g_mse.has_value() || g_dist.has_value();
+    at::Tensor grad = at::empty_like(normals), moments, gws;
+    if (through_image) {
+        moments = at::empty({B, (int64_t)helio_splat_bwd_blocks((int)R), N, HELIO_MOMENT_STRIDE}, normals.options());
+        if (helio_env_step_bwd_image_ws((int)B, (int)N, (int)R) || (variant != 0 && variant != 4)) gws = at::empty_like(image);
+    }
+    check(helio_env_step_bwd((int)B, (int)N, (int)R, fp(helios, "heliostat_positions"), fp(sun, "sun"),
+                             fp(normals, "action"), fp(trig, "trig"), (long)trig_b_stride,
+                             reinterpret_cast<const helio_plane*>(plane), fp(rays, "rays"), fp(xs, "xs"), fp(ys, "ys"),
+                             fp(image, "img"), fp(target, "target"), fp(tx, "tx"), fp(dmaps, "distance_maps"),
+                             fp(ideal, "ideal"), tpf, tnf, (float)W, (float)H, exp_risk ? 1 : 0, fpo(g_mse, "g_mse"),
+                             fpo(g_dist, "g_dist"), fpo(g_bound, "g_bound"), fpo(g_align, "g_align"), fpo(keep, "keep"),
+                             fpo(g_actual, "grad_actual"), fpo(g_refl, "grad_refl"),
+                             gws.defined() ? gws.data_ptr<float>() : nullptr,
+                             through_image ? moments.data_ptr<float>() : nullptr, grad.data_ptr<float>(), (int)variant,
+                             cur_stream(normals)));
+    return grad;
+}
+
 // helio_notify_wait with the GIL released: → 0/1 flag, or a negative HELIO_E_* code
 int64_t notify_wait(int64_t record, int64_t ticket, double timeout_seconds) {
     py::gil_scoped_release nogil;
@@ -226,5 +258,6 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("env_step_fwd", &env_step_fwd);
     m.def("env_step_core", &env_step_core);
     m.def("notify_wait", &notify_wait);
+    m.def("env_step_bwd", &env_step_bwd);
     m.def("ideal_normals", &ideal_normals);
 }

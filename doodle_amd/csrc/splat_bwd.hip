@@ -15,6 +15,7 @@
 // bit-reproducible.
 #include <hip/hip_runtime.h>
 #include "helio.h"
+#include "step_loss_math.h"
 
 namespace helio {
 
@@ -398,16 +399,137 @@ static void launch_bwd_mfma(int B, int N, int R, const float* rays, const float*
     hipLaunchKernelGGL(splat_bwd_mfma<PASS>, dim3(ct * nt, B), dim3(1024), lds, st, B, N, R, rays, xs, ys, gimg, moments);
 }
 
+// Few rays per image (the reference's test-time-compute sweeps run ONE heliostat and 500 suns,
+// run_experiments.py:31-56): the 64-ray tiles of the kernels above would be ≥ 90 % padding and the
+// pass is bound by streaming grad_image once.  A workgroup owns 64 image columns of one sun
+// (lanes ↔ columns, waves ↔ rows i ≡ wave mod 4) and NR rays in registers; per (pixel, ray) it
+// evaluates only the row factor A — the column factor E is constant per lane and multiplies
+// the finished sums.  Partials have the same [b, column block, ray, 5] layout.
+// FUSED: grad_image is not read but formed on the fly from HelioEnv.step's loss block
+// (loss_grad_pixel on img / target / distance map): backward through mse and dist without ever
+// materialising the [B,R,R] cotangent.
+template <int NR, bool FUSED>
+__global__ void __launch_bounds__(256)
+splat_bwd_few(int B, int N, int R, const float* __restrict__ rays, const float* __restrict__ xs,
+              const float* __restrict__ ys, const float* __restrict__ gimg, LossGradArgs L,
+              float* __restrict__ moments) {
+    __shared__ float sRed[4][NR][5];
+    const int jb = blockIdx.x, b = blockIdx.y, n0 = blockIdx.z * NR;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int j = jb * 64 + lane;
+    const bool col_ok = j < R;
+    const long base = (long)b * R * R + (col_ok ? j : 0);
+
+    float qa[NR], qk[NR], qc[NR], sj[NR], ej[NR];
+    const float yj = ys[min(j, R - 1)];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n0 + r < N) q = reinterpret_cast<const float4*>(rays)[(long)b * N + n0 + r];      // wave-uniform
+        qa[r] = q.x; qk[r] = q.z; qc[r] = q.w;
+        sj[r] = yj + q.y;
+        ej[r] = col_ok ? __builtin_amdgcn_exp2f(-((sj[r] * sj[r]) * q.z)) : 0.0f;
+    }
+    float ls = 1.0f, km = 0.0f, kd = 0.0f;
+    if constexpr (FUSED) L.constants(b, B, (long)R * R, ls, km, kd);
+
+    float m0[NR], mt[NR], mtt[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) { m0[r] = 0.f; mt[r] = 0.f; mtt[r] = 0.f; }
+
+    constexpr int U = 8;                      // rows in flight per lane
+    for (int i0 = wave; i0 < R; i0 += 4 * U) {
+        float g[U], xi[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + 4 * u;
+            const bool ok = col_ok && i < R;
+            const long p = base + (long)min(i, R - 1) * R;
+            xi[u] = xs[min(i, R - 1)];
+            if constexpr (FUSED) {
+                const float v = loss_grad_pixel(L.img[p], L.target[p], L.dmaps[p], ls, km, kd);
+                g[u] = ok ? v : 0.0f;
+            } else {
+                g[u] = ok ? gimg[p] : 0.0f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const float t = xi[u] + qa[r];
+                const float w = __builtin_amdgcn_exp2f(-(__builtin_fmaf(t, t, qc[r]) * qk[r])) * g[u];
+                m0[r] += w;
+                mt[r] = __builtin_fmaf(t, w, mt[r]);
+                mtt[r] = __builtin_fmaf(t * t, w, mtt[r]);
+            }
+    }
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        float v[5] = {ej[r] * m0[r], ej[r] * mt[r], sj[r] * (ej[r] * m0[r]), ej[r] * mtt[r],
+                      (sj[r] * sj[r]) * (ej[r] * m0[r])};            // M0, Mt, Ms, Mtt, Mss
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) v[k] += __shfl_xor(v[k], d);
+            if (lane == 0) sRed[wave][r][k] = v[k];
+        }
+    }
+    __syncthreads();
+    if (tid < NR * 5) {
+        const int r = tid / 5, k = tid % 5;
+        if (n0 + r < N) {
+            const int JB = (R + 63) / 64;
+            moments[(((long)b * JB + jb) * N + n0 + r) * HELIO_MOMENT_STRIDE + k] =
+                (sRed[0][r][k] + sRed[1][r][k]) + (sRed[2][r][k] + sRed[3][r][k]);
+        }
+    }
+}
+
+template <bool FUSED>
+static void launch_bwd_few(int B, int N, int R, const float* rays, const float* xs, const float* ys,
+                           const float* gimg, const LossGradArgs& L, float* moments, hipStream_t st) {
+    const int JB = (R + 63) / 64;
+    if (N == 1)
+        hipLaunchKernelGGL((splat_bwd_few<1, FUSED>), dim3(JB, B, N), dim3(256), 0, st, B, N, R, rays, xs, ys, gimg, L, moments);
+    else if (N <= 2)
+        hipLaunchKernelGGL((splat_bwd_few<2, FUSED>), dim3(JB, B, 1), dim3(256), 0, st, B, N, R, rays, xs, ys, gimg, L, moments);
+    else
+        hipLaunchKernelGGL((splat_bwd_few<4, FUSED>), dim3(JB, B, (N + 3) / 4), dim3(256), 0, st, B, N, R, rays, xs, ys, gimg, L, moments);
+}
+
+// where the few-ray kernel wins (tools/sweep_bwd.py, MI355X): its time grows with B·N·R², the
+// MFMA kernels' with the number of 64-ray tiles
+bool splat_bwd_is_few(int B, int N) { return N <= 8 || (N <= 16 && B <= 64) || (N <= 32 && B <= 8); }
+
+// backward through the image losses with the cotangent formed on the fly (few rays only)
+void launch_splat_bwd_fused_loss(int B, int N, int R, const float* rays, const float* xs, const float* ys,
+                                 const LossGradArgs& L, float* moments, hipStream_t st) {
+    launch_bwd_few<true>(B, N, R, rays, xs, ys, nullptr, L, moments, st);
+}
+
+void launch_splat_bwd_fused_loss_raw(int B, int N, int R, const float* rays, const float* xs, const float* ys,
+                                     const float* img, const float* target, const float* tx, const float* dmaps,
+                                     const float* keep, const float* g_mse, const float* g_dist, float* moments,
+                                     hipStream_t st) {
+    launch_splat_bwd_fused_loss(B, N, R, rays, xs, ys, LossGradArgs{img, target, tx, dmaps, keep, g_mse, g_dist}, moments, st);
+}
+
 int splat_bwd_blocks(int R) { return (R + BW_JT - 1) / BW_JT; }
 
-// variant: 0 = by problem size, 1 = VALU kernel, 2 = MFMA kernels (256-tiles), 3 = MFMA small tiles
+// variant: 0 = by problem size, 1 = VALU kernel, 2 = MFMA kernels (256-tiles), 3 = MFMA small tiles,
+// 4 = few-ray streaming kernel
 int launch_splat_bwd(int B, int N, int R, const float* rays, const float* xs, const float* ys,
                      const float* gimg, float* moments, int variant, hipStream_t st) {
     if (variant == 0) {
         const long wgs = (long)B * ((R + 255) / 256) * ((N + 255) / 256);
         // tools/sweep_bwd.py: the 256-wide tiles pay off only when the image is wider than 128
         // pixels (at R = 128 half of every tile is padding) and there are enough of them
-        variant = (R > 128 && N >= 96 && wgs >= 128) ? 2 : 3;
+        variant = splat_bwd_is_few(B, N) ? 4 : (R > 128 && N >= 96 && wgs >= 128) ? 2 : 3;
+    }
+    if (variant == 4) {
+        launch_bwd_few<false>(B, N, R, rays, xs, ys, gimg, LossGradArgs{}, moments, st);
+        return HELIO_OK;
     }
     if (variant == 3) {
         const int ct = (R + 63) / 64, nt = (N + 63) / 64;

@@ -68,6 +68,59 @@ inline LossGeom make_geom(const float* tp, const float* tn, float W, float H, in
     return g;
 }
 
+// Adjoint of ray_loss: ka = cotangent of the mean alignment angle / (B·N), go = cotangent of the
+// mean boundary term / (B·N).  ga[3] → d/d actual (through the angle), gv[3] → d/d action
+// (through the boundary term); either may be skipped with a zero factor.
+__device__ __forceinline__ void ray_loss_bwd(const RayLoss& r, const float* __restrict__ ideal,
+                                             const float* __restrict__ v, const LossGeom& g, float ka, float go,
+                                             float ga[3], float gv[3]) {
+    // d acos(c)·1000 / dc = -1000 / sqrt(1 - c²); zero where the clamp is active
+    const float k = r.clamped ? 0.0f : ka * (-1000.0f / sqrtf(1.0f - r.c * r.c));
+    ga[0] = k * ideal[0]; ga[1] = k * ideal[1]; ga[2] = k * ideal[2];
+    if (g.exponential_risk) go *= expf(r.out + 1e-6f);
+    gv[0] = gv[1] = gv[2] = 0.0f;
+    if (!r.inside) {
+        const float gdx = go * r.dx / r.dist, gdy = go * r.dy / r.dist;
+        const float gxl = (fabsf(r.xl) - g.hwt > 0.0f) ? (r.xl > 0.0f ? gdx : (r.xl < 0.0f ? -gdx : 0.0f)) : 0.0f;
+        const float gyl = (fabsf(r.yl) - g.hht > 0.0f) ? (r.yl > 0.0f ? gdy : (r.yl < 0.0f ? -gdy : 0.0f)) : 0.0f;
+        // xl = h.x + v.x t - tp.x ; yl = h.z + v.z t - tp.z
+        const float gt = gxl * v[0] + gyl * v[2];
+        gv[0] = gxl * r.t; gv[2] = gyl * r.t;
+        // t = (tp·v) / den ; den = -(v·tn) (+1e-6)
+        // torch's div backward associates as grad·((num/den)/den); keep that order: with the
+        // reference's target (position ∥ normal) t is a constant and the two terms below cancel
+        const float gnum = gt / r.den, gden = -(gt * (r.t / r.den));
+#pragma unroll
+        for (int k2 = 0; k2 < 3; ++k2) gv[k2] += gnum * g.tp[k2] - gden * g.tn[k2];
+    }
+}
+
+// the ray losses' adjoint folded into the geometry backward (helio_env_step_bwd): ideal == null → off
+struct RayLossBwdArgs {
+    const float* ideal; const float* g_align; const float* g_bound;    // cotangents: device scalars, may be null
+    LossGeom g;
+};
+
+// d(mse, dist)/d img at one pixel (test_environment.py:436-457 differentiated): x = img, y = target,
+// dm = distance map, s = target peak; km, kd carry the cotangents, the means and the error mask
+__device__ __forceinline__ float loss_grad_pixel(float x, float y, float dm, float s, float km, float kd) {
+    const float d = x / s - y / s;
+    const float sg = d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f);
+    return (km * d + kd * sg * dm) / s;
+}
+
+// per-image constants of loss_grad_pixel
+struct LossGradArgs {
+    const float* img; const float* target; const float* tx; const float* dmaps;
+    const float* keep; const float* g_mse; const float* g_dist;     // keep / cotangents may be null
+    __device__ __forceinline__ void constants(int b, int B, long P, float& s, float& km, float& kd) const {
+        s = tx[b];
+        const float kb = keep ? keep[b] : 1.0f;                                         // error mask (0/1)
+        km = kb * (g_mse ? *g_mse : 0.0f) * 2.0f / ((float)B * (float)P);             // d mean(d²)
+        kd = kb * (g_dist ? *g_dist : 0.0f) / (float)B;                                // d mean_b Σ e·dm
+    }
+};
+
 // raw pointers of the loss block, by value into the fused env kernel
 struct StepLossArgs {
     const float* target; const float* tx; const float* dmaps; const float* ideal;

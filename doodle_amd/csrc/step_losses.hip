@@ -190,15 +190,9 @@ step_losses_bwd(int B, int N, int R, int chunks, const float* __restrict__ img,
     if ((int)blockIdx.x < img_wgs) {
         const int b = blockIdx.x / chunks, ch = blockIdx.x % chunks;
         const long P = (long)R * R, base = (long)b * P;
-        const float s = tx[b];
-        const float kb = keep ? keep[b] : 1.0f;                                     // error mask (0/1, constant)
-        const float km = kb * (g_mse ? *g_mse : 0.0f) * 2.0f / ((float)B * (float)P);   // d mean(d²)
-        const float kd = kb * (g_dist ? *g_dist : 0.0f) / (float)B;                      // d mean_b Σ e·dm
-        auto one = [&](float x, float y, float dm) -> float {
-            const float d = x / s - y / s;
-            const float sg = d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f);
-            return (km * d + kd * sg * dm) / s;
-        };
+        float s, km, kd;
+        LossGradArgs{img, target, tx, dmaps, keep, g_mse, g_dist}.constants(b, B, P, s, km, kd);
+        auto one = [&](float x, float y, float dm) -> float { return loss_grad_pixel(x, y, dm, s, km, kd); };
         const long p0 = (long)ch * SL_PIX_PER_WG;
         if ((P & 3) == 0) {
 #pragma unroll
@@ -226,32 +220,10 @@ step_losses_bwd(int B, int N, int R, int chunks, const float* __restrict__ img,
         const float* id = ideal + 3 * m;
         const RayLoss r = ray_loss(id, actual + 3 * m, v, helios + 3l * n, g);
         const float inv = 1.0f / ((float)B * (float)N);
-        if (grad_actual) {
-            // d acos(c)·1000 / dc = -1000 / sqrt(1 - c²); zero where the clamp is active
-            const float ga = (g_align ? *g_align : 0.0f) * inv;
-            const float k = r.clamped ? 0.0f : ga * (-1000.0f / sqrtf(1.0f - r.c * r.c));
-            grad_actual[3 * m] = k * id[0]; grad_actual[3 * m + 1] = k * id[1]; grad_actual[3 * m + 2] = k * id[2];
-        }
-        if (grad_action) {
-            float go = (g_bound ? *g_bound : 0.0f) * inv;
-            if (g.exponential_risk) go *= expf(r.out + 1e-6f);
-            float gv[3] = {0.f, 0.f, 0.f};
-            if (!r.inside) {
-                const float gdx = go * r.dx / r.dist, gdy = go * r.dy / r.dist;
-                const float gxl = (fabsf(r.xl) - g.hwt > 0.0f) ? (r.xl > 0.0f ? gdx : (r.xl < 0.0f ? -gdx : 0.0f)) : 0.0f;
-                const float gyl = (fabsf(r.yl) - g.hht > 0.0f) ? (r.yl > 0.0f ? gdy : (r.yl < 0.0f ? -gdy : 0.0f)) : 0.0f;
-                // xl = h.x + v.x t - tp.x ; yl = h.z + v.z t - tp.z
-                const float gt = gxl * v[0] + gyl * v[2];
-                gv[0] = gxl * r.t; gv[2] = gyl * r.t;
-                // t = (tp·v) / den ; den = -(v·tn) (+1e-6)
-                // torch's div backward associates as grad·((num/den)/den); keep that order: with the
-                // reference's target (position ∥ normal) t is a constant and the two terms below cancel
-                const float gnum = gt / r.den, gden = -(gt * (r.t / r.den));
-#pragma unroll
-                for (int k = 0; k < 3; ++k) gv[k] += gnum * g.tp[k] - gden * g.tn[k];
-            }
-            grad_action[3 * m] = gv[0]; grad_action[3 * m + 1] = gv[1]; grad_action[3 * m + 2] = gv[2];
-        }
+        float ga[3], gv[3];
+        ray_loss_bwd(r, id, v, g, (g_align ? *g_align : 0.0f) * inv, (g_bound ? *g_bound : 0.0f) * inv, ga, gv);
+        if (grad_actual) { grad_actual[3 * m] = ga[0]; grad_actual[3 * m + 1] = ga[1]; grad_actual[3 * m + 2] = ga[2]; }
+        if (grad_action) { grad_action[3 * m] = gv[0]; grad_action[3 * m + 1] = gv[1]; grad_action[3 * m + 2] = gv[2]; }
     }
 }
 
@@ -288,7 +260,10 @@ void launch_step_losses_bwd(int B, int N, int R, const float* img, const float* 
                             const float* g_align, const float* keep, float* grad_img, float* grad_actual,
                             float* grad_action, hipStream_t st) {
     const int chunks = step_losses_chunks(R), rw = step_losses_ray_wgs(B, N);
-    const int grid = (grad_img ? B * chunks : 0) + rw;
+    // ray workgroups only when a ray gradient is asked for (helio_env_step_bwd folds them into the
+    // geometry backward and passes neither)
+    const int grid = (grad_img ? B * chunks : 0) + ((grad_actual || grad_action) ? rw : 0);
+    if (grid == 0) return;
     hipLaunchKernelGGL(step_losses_bwd, dim3(grid), dim3(SL_THREADS), 0, st, B, N, R, chunks, img, target, tx, dmaps,
                        ideal, actual, action, helios, make_geom(tp, tn, W, H, exponential_risk), g_mse, g_dist,
                        g_bound, g_align, keep, grad_img, grad_actual, grad_action);

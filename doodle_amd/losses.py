@@ -57,7 +57,7 @@ class _StepLosses(torch.autograd.Function):
 
 class _EnvStep(torch.autograd.Function):
     """render + loss block as ONE autograd node (what HelioEnv.step differentiates): forward =
-    helio_env_step_fwd (render + loss block; 2 launches for small problems), backward = helio_step_losses_bwd + helio_render_bwd.
+    helio_env_step_fwd (render + loss block; 2 launches for small problems), backward = helio_env_step_bwd (or, with an external image cotangent, helio_step_losses_bwd + helio_render_bwd).
     Same kernels as ``_Render`` followed by ``_StepLosses``; it only spares the autograd engine
     five graph nodes per step (the TTT inner loop of the reference calls step+backward 800 times
     per optimiser step)."""
@@ -81,6 +81,14 @@ class _EnvStep(torch.autograd.Function):
         normals, sun, trig, rays, image, actual, keep = ctx.saved_tensors
         field, ops = ctx.field, _field._get_ops()
         c = lambda g: g.contiguous() if g is not None else None  # noqa: E731
+        step_bwd = getattr(ops, "env_step_bwd", None)
+        if g_image is None and step_bwd is not None:
+            # the whole backward in one C call (helio_env_step_bwd): 1-3 launches, no temporaries
+            # for the ray-loss adjoints, no [B,R,R] image cotangent when there are few rays
+            g = step_bwd(field.heliostat_positions, sun, normals, trig, ctx.trig_stride, field._plane, rays,
+                         field._xs, field._ys, image, ctx.consts, c(g_mse), c(g_dist), c(g_bound), c(g_align), keep,
+                         c(g_actual), c(g_refl))
+            return g, None, None, None, None, None, None
         need_img = g_mse is not None or g_dist is not None
         gi = ga = gn = None
         if need_img or g_align is not None or g_bound is not None:

@@ -25,6 +25,7 @@ EXPORTS = (
     "helio_distance_maps_workspace", "helio_distance_maps",
     "helio_env_step_workspace", "helio_env_step_launches", "helio_env_step_fwd",
     "helio_notify_create", "helio_notify_destroy", "helio_notify_wait",
+    "helio_env_step_bwd_image_ws", "helio_env_step_bwd",
 )
 
 
@@ -74,6 +75,9 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
         "helio_env_step_launches": (_i, [_i, _i, _i]),
         "helio_env_step_fwd": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _l, pp, _vp, _vp, _vp, _vp, _vp, _vp, _i]
                                + [_vp] * 4 + [_f3, _f3, _f, _f, _i, _f] + [_vp] * 7 + [_vp, _i, _vp]),
+        "helio_env_step_bwd_image_ws": (_i, [_i, _i, _i]),
+        "helio_env_step_bwd": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _l, pp] + [_vp] * 8 + [_f3, _f3, _f, _f, _i]
+                               + [_vp] * 10 + [_i, _vp]),
         "helio_notify_create": (_i, [ctypes.POINTER(_vp)]),
         "helio_notify_destroy": (_i, [_vp]),
         "helio_notify_wait": (_i, [_vp, _i, ctypes.c_double]),
@@ -244,6 +248,31 @@ class HipOps:
             float(c.mask_ratio), ws.data_ptr(), out.data_ptr(), mae.data_ptr(), keep.data_ptr(), align.data_ptr(),
             allb.data_ptr(), aux.data_ptr() if want_aux else None, rec or None, ticket, _stream()))
         return image, actual, refl, rays, out, mae, align, allb, keep, aux, ticket
+
+    def env_step_bwd(self, helios, sun, normals, trig, trig_b_stride, plane, rays, xs, ys, image, c, g_mse, g_dist,
+                     g_bound, g_align, keep, g_actual, g_refl):
+        """Backward of ``env_step_fwd`` w.r.t. the action in ONE C call (``helio_env_step_bwd``);
+        every cotangent may be None.  → grad_action [B,N,3]."""
+        if self.hb is not None:
+            return self.hb.env_step_bwd(_plane_handle(self.hb, plane), helios, sun, normals, trig, trig_b_stride, rays,
+                                        xs, ys, image, c.target, c.tx, c.dmaps, c.ideal, list(c.tp), list(c.tn), c.W,
+                                        c.H, bool(c.exp_risk), g_mse, g_dist, g_bound, g_align, keep, g_actual, g_refl,
+                                        self.bwd_variant)
+        B, N, R = normals.shape[0], normals.shape[1], xs.shape[0]
+        grad = torch.empty_like(normals)
+        moments = gws = None
+        if g_mse is not None or g_dist is not None:
+            moments = torch.empty((B, self.lib.helio_splat_bwd_blocks(R), N, MOMENT_STRIDE), dtype=torch.float32,
+                                  device=normals.device)
+            if self.lib.helio_env_step_bwd_image_ws(B, N, R) or self.bwd_variant not in (0, 4):
+                gws = torch.empty_like(image)
+        ptr = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
+        _check(self.lib, self.lib.helio_env_step_bwd(
+            B, N, R, _dev(helios), _dev(sun), _dev(normals), _dev(trig), trig_b_stride, plane, _dev(rays), _dev(xs),
+            _dev(ys), _dev(image), _dev(c.target), _dev(c.tx), _dev(c.dmaps), _dev(c.ideal), c.tp, c.tn, c.W, c.H,
+            int(c.exp_risk), ptr(g_mse), ptr(g_dist), ptr(g_bound), ptr(g_align), ptr(keep), ptr(g_actual),
+            ptr(g_refl), ptr(gws), ptr(moments), grad.data_ptr(), self.bwd_variant, _stream()))
+        return grad
 
     def env_step_nograd(self, field, sun, action, trig, trig_b_stride, c, notify=False):
         """HelioEnv.step without autograd in one call of the compiled binding (render + loss block +

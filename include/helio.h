@@ -136,7 +136,8 @@ int helio_splat_bwd_blocks(int R);
  * 64 image columns for (M0, Ms, Mss) and — in the MFMA kernels — 64 image rows for (Mt, Mtt);
  * only the sum over blocks is meaningful.
  * variant: 0 = by problem size, 1 = VALU kernel, 2 = f32 MFMA kernels (256-wide tiles, two
- * launches), 3 = f32 MFMA small-tile kernel (both passes in one launch).
+ * launches), 3 = f32 MFMA small-tile kernel (both passes in one launch), 4 = streaming VALU kernel
+ * for a handful of rays per image (bound by reading grad_image once).
  */
 int helio_splat_bwd(int B, int N, int R,
                     const float *rays_d, const float *xs_d, const float *ys_d,
@@ -261,6 +262,32 @@ int helio_env_step_fwd(int B, int N, int R,
                        float width, float height, int exponential_risk, float error_mask_ratio,
                        float *workspace_d, float *out_d, float *mae_d, float *keep_d, float *align_err_d,
                        float *all_bounds_d, float *aux_d, int *notify, int ticket, void *stream);
+
+/*
+ * Backward of helio_env_step_fwd w.r.t. the action in one call: the cotangents of the four
+ * scalars (device scalars, NULL = none; keep_d = the mask the forward wrote, NULL = all ones)
+ * plus optional cotangents of `actual` and `refl` → grad_action_d [B,N,3].
+ *   - through mse/dist: d/d image is formed by the loss block's adjoint and contracted with the
+ *     footprints (helio_splat_bwd).  helio_env_step_bwd_image_ws(B,N,R) == 0: few rays per image,
+ *     the [B,R,R] image cotangent is never materialised (it is evaluated on the fly while
+ *     image / target / distance map stream through the moment kernel once) and grad_image_ws_d
+ *     may be NULL; otherwise it is a [B,R,R] work buffer.
+ *   - through alignment_loss and bound: the per-ray adjoints are evaluated inside the geometry
+ *     backward (no extra launch, no [B,N,3] temporaries).
+ * moments_d: [B, helio_splat_bwd_blocks(R), N, 5] work buffer, needed with g_mse_d or g_dist_d.
+ * Launches: 1 (ray losses only), 2 (few rays) or 3.
+ */
+int helio_env_step_bwd_image_ws(int B, int N, int R);     /* 1: grad_image_ws_d is needed */
+int helio_env_step_bwd(int B, int N, int R,
+                       const float *helios_d, const float *sun_d, const float *action_d,
+                       const float *trig_d, long trig_b_stride, const helio_plane *plane,
+                       const float *rays_d, const float *xs_d, const float *ys_d,
+                       const float *image_d, const float *target_d, const float *tx_d, const float *dmaps_d,
+                       const float *ideal_d, const float target_position[3], const float target_normal[3],
+                       float width, float height, int exponential_risk,
+                       const float *g_mse_d, const float *g_dist_d, const float *g_bound_d, const float *g_align_d,
+                       const float *keep_d, const float *grad_actual_d, const float *grad_refl_d,
+                       float *grad_image_ws_d, float *moments_d, float *grad_action_d, int variant, void *stream);
 
 #ifdef __cplusplus
 }

@@ -525,7 +525,7 @@ def test_kernel_variants_agree_on_random_shapes():
         G = torch.randn(B, R, R, device=DEV, generator=g)
         m1 = ops.splat_bwd(rays, xs, ys, G, variant=1).sum(1)
         scale = m1.abs().amax(dim=(0, 1)).clamp_min(1e-20)
-        for v in (2, 3, 0):
+        for v in (2, 3, 4, 0):
             mv = ops.splat_bwd(rays, xs, ys, G, variant=v).sum(1)
             assert ((mv - m1).abs().amax(dim=(0, 1)) / scale).max().item() <= 2e-5, (B, N, R, v)
 
@@ -710,3 +710,113 @@ def test_completion_record_of_the_env_step():
     assert ops.lib.helio_notify_wait(None, 1, 0.0) < 0 and ops.lib.helio_notify_wait(ops._notify, 0, 0.0) < 0
     # a ticket that was never issued times out instead of hanging
     assert ops.lib.helio_notify_wait(ops._notify, ops._ticket + 1000, 0.01) == -4
+
+
+def test_graphed_env_step_replays_the_eager_iteration_bit_for_bit():
+    """doodle_amd.graphed.GraphedEnvStep: env.step + backward captured in a HIP graph gives, on
+    every replay, exactly what the eager calls give (same kernels, same order), for the shape of
+    the reference's test-time-compute loop (train_with_env_com_trunc_advantage_ttt.py:291-312)."""
+    import torch.nn.functional as F
+    from doodle_amd.env import HelioEnv
+    from doodle_amd.graphed import GraphedEnvStep
+    torch.manual_seed(3)
+    N, B, R = 6, 40, 64
+    hp = torch.rand(N, 3, device=DEV) * 10 + 80
+    hp[:, 2] = 0
+    env = HelioEnv(hp, torch.tensor([0., -5., 0.], device=DEV), (15., 15.), torch.tensor([0., 1., 0.], device=DEV),
+                   sigma_scale=0.05, error_scale_mrad=3.0, resolution=R, batch_size=B, device=DEV)
+    env.reset()
+    base = env.ideal_normals.detach()
+    prepare = lambda v: F.normalize(base + v, dim=2)  # noqa: E731
+    vec = torch.empty_like(base).uniform_(-1e-3, 1e-3)
+    g = GraphedEnvStep(env, like=vec, objective="dist", prepare=prepare)
+    assert env.check_finite is True                      # restored after the capture
+    for k in range(3):
+        v = (vec * (k + 1)).requires_grad_(True)
+        _, m, mon = env.step(prepare(v))
+        (want,) = torch.autograd.grad(m["dist"], v)
+        gm, grad = g(v.detach())
+        assert torch.equal(grad, want)
+        for key in ("mse", "dist", "bound", "alignment_loss"):
+            assert torch.equal(gm[key], m[key]), key
+        assert torch.equal(g.obs["img"], env.step(prepare(v.detach()))[0]["img"])
+        assert torch.equal(g.monitor["alignment_errors"], mon["alignment_errors"])
+        assert g.nonfinite() is False
+    # descent by replay only: the inner loop of the reference with a capturable Adam
+    x = g.x
+    opt = torch.optim.Adam([x], lr=2e-4, capturable=True)
+    first = None
+    for _ in range(30):
+        m, grad = g()
+        first = m["dist"].item() if first is None else first
+        x.grad = grad
+        opt.step()
+    assert g()[0]["dist"].item() < first
+    bad = vec.clone()
+    bad[0, 0, 0] = float("nan")
+    g(bad)
+    assert g.nonfinite() is True
+
+
+@pytest.mark.parametrize("N,B,R,mask", [(1, 40, 128, None), (3, 5, 33, None), (8, 30, 100, 0.3), (16, 4, 64, None),
+                                         (50, 25, 128, None), (70, 3, 65, 0.5), (300, 6, 256, None)])
+def test_env_step_bwd_abi_call_matches_the_composed_backward(N, B, R, mask):
+    """helio_env_step_bwd (ray-loss adjoints inside the geometry backward; for few rays the image
+    cotangent evaluated on the fly in the moment kernel) against helio_step_losses_bwd +
+    helio_render_bwd + add, for every combination of cotangents the callers use, on both bindings."""
+    import ctypes
+    from doodle_amd import native
+    from doodle_amd.losses import StepConstants
+    ops = native.get_ops()
+    f, _, suns, _, act = make_case(N=N, B=B, R=R, seed=N * 3 + B, err=5.0)
+    g = torch.Generator().manual_seed(N + R)
+    target = torch.rand(B, R, R, generator=g) * 3
+    dmaps = torch.rand(B, R, R, generator=g) * 40
+    ideal = f.calculate_ideal_normals(suns)
+    f3 = ctypes.c_float * 3
+    c = StepConstants(target.to(DEV), target.amax((1, 2)).clamp_min(1e-6).to(DEV), dmaps.to(DEV), ideal,
+                      f.heliostat_positions, f3(*f.target_position.tolist()), f3(*f.target_normal.tolist()),
+                      15.0, 12.0, False, -1.0 if mask is None else mask)
+    normals = act.to(DEV).reshape(B, N, 3).contiguous()
+    sun = suns.to(DEV)
+    trig, stride = f._select_trig(B)
+    hp = f.heliostat_positions
+    image, actual, refl, rays, out, mae, align, allb, keep, _, _ = ops.env_step_fwd(hp, sun, normals, trig, stride,
+                                                                                     f._plane, f._xs, f._ys, c)
+    w = {k: torch.tensor(v, device=DEV) for k, v in (("mse", 0.7), ("dist", 1.3), ("bound", -0.4), ("align", 2.1))}
+    ext_a, ext_r = torch.randn(B, N, 3, device=DEV, generator=torch.Generator(DEV).manual_seed(1)), None
+    combos = [("dist",), ("mse",), ("align",), ("bound",), ("mse", "dist", "bound", "align"), ("dist", "ext"), ("ext",)]
+    for names in combos:
+        gm, gd, gb, gal = (w[k] if k in names else None for k in ("mse", "dist", "bound", "align"))
+        ga_ext = ext_a if "ext" in names else None
+        res = {}
+        for name, hb in (("hostbind", ops.hb), ("ctypes", None)):
+            if name == "hostbind" and hb is None:
+                continue
+            saved, ops.hb = ops.hb, hb
+            try:
+                res[name] = ops.env_step_bwd(hp, sun, normals, trig, stride, f._plane, rays, f._xs, f._ys, image, c,
+                                             gm, gd, gb, gal, keep, ga_ext, ext_r)
+            finally:
+                ops.hb = saved
+        got = next(iter(res.values()))
+        for other in res.values():
+            assert torch.equal(got, other)
+        # the composed path
+        need_img = gm is not None or gd is not None
+        gi = ga = gn = None
+        if need_img or gal is not None or gb is not None:
+            gi, ga, gn = ops.step_losses_bwd(image, actual, normals, c, gm, gd, gb, gal, keep, need_img,
+                                             gal is not None, gb is not None)
+        if ga_ext is not None:
+            ga = ga_ext if ga is None else ga_ext + ga
+        want = ops.render_bwd(hp, sun, normals, trig, stride, f._plane, rays, f._xs, f._ys, gi, ga, None) \
+            if (gi is not None or ga is not None) else torch.zeros_like(normals)
+        if gn is not None:
+            want = want + gn
+        scale = want.abs().max().item()
+        if not need_img:
+            assert torch.equal(got, want), names                      # same arithmetic, same order
+        else:                                                          # moment kernels may differ (few-ray vs MFMA)
+            assert (got - want).abs().max().item() <= 2e-5 * max(scale, 1e-30), names
+    assert ops.lib.helio_env_step_bwd_image_ws(B, N, R) == (0 if (N <= 8 or (N <= 16 and B <= 64) or (N <= 32 and B <= 8)) else 1)

@@ -23,3 +23,14 @@ def fb():
 with torch.no_grad():
     print(f"N=1 B=500 R=128: env.step fwd {timeit(lambda: env.step(a)):.1f} us")
 print(f"                 env.step + dist.backward {timeit(fb):.1f} us")
+
+# the same iteration replayed from a HIP graph (doodle_amd/graphed.py)
+from doodle_amd.graphed import GraphedEnvStep
+base = env.ideal_normals.detach()
+vec = torch.empty_like(base).uniform_(-1e-3, 1e-3)
+g = GraphedEnvStep(env, like=vec, objective="dist", prepare=lambda v: torch.nn.functional.normalize(base + v, dim=2))
+print(f"                 graphed normalize + env.step + dist.backward {timeit(lambda: g()):.1f} us")
+v = vec.clone().requires_grad_(True)
+def eager():
+    _, m, _ = env.step(torch.nn.functional.normalize(base + v, dim=2)); m["dist"].backward(); v.grad = None
+print(f"                 eager   normalize + env.step + dist.backward {timeit(eager):.1f} us")
