@@ -15,12 +15,17 @@ obs = env.reset()
 act = (env.ideal_normals + 0.003 * torch.randn_like(env.ideal_normals))
 act = torch.nn.functional.normalize(act, dim=2).reshape(B, -1)
 
-def timeit(fn, n=300):
-    for _ in range(20): fn()
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(n): fn()
-    torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / n * 1e6
+def timeit(fn, n=300, repeats=5):
+    """best of `repeats` timed loops (the GPU boxes' host cores are shared: single loops vary by ±20 %)"""
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 0.3: fn()          # host warm-up: the first ~0.1 s of a loop runs slow
+    best = float("inf")
+    for _ in range(repeats):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(n): fn()
+        torch.cuda.synchronize()
+        best = min(best, (time.perf_counter() - t0) / n * 1e6)
+    return best
 
 with torch.no_grad():
     t_fwd = timeit(lambda: env.step(act))
@@ -31,6 +36,15 @@ def fb(key):
     a.grad = None
 t_align = timeit(lambda: fb("alignment_loss"))
 t_dist = timeit(lambda: fb("dist"))
+if "--ab" in sys.argv:      # A/B, interleaved: helio_env_step_bwd vs the composed backward (step_losses_bwd + render_bwd + add)
+    from doodle_amd import field as _field
+    ops = _field._get_ops()
+    for rnd in range(3):
+        one = (timeit(lambda: fb("alignment_loss")), timeit(lambda: fb("dist")))
+        ops.env_step_bwd = None
+        two = (timeit(lambda: fb("alignment_loss")), timeit(lambda: fb("dist")))
+        del ops.env_step_bwd
+        print(f"round {rnd}: one call {one[0]:7.1f} / {one[1]:7.1f} us   composed {two[0]:7.1f} / {two[1]:7.1f} us   (alignment / dist)")
 print(f"env.step forward-only {t_fwd:8.1f} us = {B/t_fwd*1e6:10.0f} frames/s | step+backward(alignment) {t_align:8.1f} us | step+backward(dist) {t_dist:8.1f} us")
 with torch.no_grad():
     print(f"reset() {timeit(lambda: env.reset(), 100):8.1f} us")
