@@ -104,6 +104,61 @@ int main(int argc, char** argv) {
                arch, bits ? "bit-exact" : "DIFFERS", maxd / peak, bad, ok ? "ok" : "FAIL");
         worst |= !ok;
     }
+    // HelioEnv.step forward in one call (helio_env_step_fwd) with a completion record: the image
+    // it writes equals helio_render_fwd's bit for bit; mse / dist / per-image mean error agree with
+    // a scalar restatement of test_environment.py:436-457 on the oracle image; the NaN/Inf flag
+    // arrives through pinned host memory (helio_notify_wait), no device read.
+    {
+        std::vector<float> target((size_t)B * R * R), dmap((size_t)B * R * R), tx(B), ideal(3 * B * N);
+        for (size_t p = 0; p < target.size(); ++p) { target[p] = 2.0f * rnd(); dmap[p] = 30.0f * rnd(); }
+        for (int b = 0; b < B; ++b) {
+            float m = 1e-6f;
+            for (size_t p = 0; p < (size_t)R * R; ++p) m = std::fmax(m, target[(size_t)b * R * R + p]);
+            tx[b] = m;
+        }
+        for (size_t k = 0; k < ideal.size(); ++k) ideal[k] = o_actual[k];       // any unit vectors will do
+        float *d_target = to_device(target), *d_dm = to_device(dmap), *d_tx = to_device(tx), *d_ideal = to_device(ideal);
+        float *d_ws, *d_out, *d_mae, *d_keep, *d_align, *d_allb, *d_img2;
+        HIP_OK(hipMalloc(&d_ws, 4ul * helio_env_step_workspace(B, N, R))); HIP_OK(hipMalloc(&d_out, 20));
+        HIP_OK(hipMalloc(&d_mae, 4ul * B)); HIP_OK(hipMalloc(&d_keep, 4ul * B)); HIP_OK(hipMalloc(&d_align, 4ul * B * N));
+        HIP_OK(hipMalloc(&d_allb, 4ul * B * N)); HIP_OK(hipMalloc(&d_img2, 4ul * B * R * R));
+        int* record = nullptr;
+        ABI_OK(helio_notify_create(&record));
+        ABI_OK(helio_render_fwd(B, N, R, d_h, d_s, d_a, d_t, 4l * N, &plane, d_x, d_y, d_actual, d_refl, d_rays, d_img, 0, st));
+        ABI_OK(helio_env_step_fwd(B, N, R, d_h, d_s, d_a, d_t, 4l * N, &plane, d_x, d_y, d_actual, d_refl, d_rays, d_img2, 0,
+                                  d_target, d_tx, d_dm, d_ideal, tp, tn, 15.0f, 15.0f, 0, -1.0f, d_ws, d_out, d_mae, d_keep,
+                                  d_align, d_allb, nullptr, record, 7, st));
+        const int flag = helio_notify_wait(record, 7, 10.0);       // returns once the finishing workgroup has published
+        std::vector<float> img2((size_t)B * R * R), mae(B);
+        float out[5];
+        HIP_OK(hipStreamSynchronize(st));
+        HIP_OK(hipMemcpy(img.data(), d_img, 4ul * B * R * R, hipMemcpyDeviceToHost));
+        HIP_OK(hipMemcpy(img2.data(), d_img2, 4ul * B * R * R, hipMemcpyDeviceToHost));
+        HIP_OK(hipMemcpy(out, d_out, 20, hipMemcpyDeviceToHost));
+        HIP_OK(hipMemcpy(mae.data(), d_mae, 4ul * B, hipMemcpyDeviceToHost));
+        double sq = 0, ds = 0, worst_mae = 0;
+        for (int b = 0; b < B; ++b) {
+            double ab = 0, dsb = 0;
+            for (size_t p = 0; p < (size_t)R * R; ++p) {
+                const size_t q = (size_t)b * R * R + p;
+                const float d = o_img[q] / tx[b] - target[q] / tx[b];
+                sq += (double)d * d; ab += std::fabs(d); dsb += std::fabs(d) * (double)dmap[q];
+            }
+            ds += dsb;
+            worst_mae = std::fmax(worst_mae, std::fabs(mae[b] - ab / ((double)R * R)) / (ab / ((double)R * R)));
+        }
+        const double mse = sq / ((double)B * R * R), dist = ds / B;
+        const bool same = memcmp(img.data(), img2.data(), 4ul * B * R * R) == 0;
+        const bool ok = same && flag == 0 && out[4] == 0.0f && std::fabs(out[0] - mse) <= 2e-5 * mse &&
+                        std::fabs(out[1] - dist) <= 2e-5 * dist && worst_mae <= 2e-5 &&
+                        helio_env_step_launches(B, N, R) == (helio_render_fwd_launches(B, N, R) == 1 ? 2 : 4) &&
+                        helio_notify_wait(record, 8, 0.01) == HELIO_E_TIMEOUT;
+        printf("env step (%d launches): image %s, mse %.6e vs %.6e, dist %.6e vs %.6e, mae rel err %.1e, flag %d -> %s\n",
+               helio_env_step_launches(B, N, R), same ? "bit-identical" : "DIFFERS", out[0], mse, out[1], dist, worst_mae,
+               flag, ok ? "ok" : "FAIL");
+        worst |= !ok;
+        ABI_OK(helio_notify_destroy(record));
+    }
     // error behaviour: invalid arguments are refused before any launch
     if (helio_render_fwd(0, N, R, d_h, d_s, d_a, d_t, 4l * N, &plane, d_x, d_y, d_actual, d_refl, d_rays, d_img, 0, st) != HELIO_E_INVALID) worst = 1;
     if (helio_render_fwd(B, N, R, nullptr, d_s, d_a, d_t, 4l * N, &plane, d_x, d_y, d_actual, d_refl, d_rays, d_img, 0, st) != HELIO_E_INVALID) worst = 1;
