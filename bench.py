@@ -153,10 +153,18 @@ def main():
                          "so that every kernel in the trace belongs to one workload")
     ap.add_argument("--mode", default="fwd", choices=["fwd", "fwdbwd"])
     ap.add_argument("--overlap", action="store_true",
-                    help="run the all-gather on a side stream (overlaps the next render)")
+                    help="run the all-gather on a side stream (pays for steps of milliseconds — the config-5 "
+                         "shard leg uses it; at config 2 the cross-stream events cost more than they hide: "
+                         "35 vs 14 µs per step measured with one rank)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed and all-gather even with one rank (testing)")
     args = ap.parse_args()
+
+    # stdout carries the ONE JSON line and nothing else: libraries that print to fd 1 (RCCL's
+    # version banner at communicator creation) are sent to stderr for the whole run
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -181,7 +189,7 @@ def main():
     gather, gathered = None, None
     if dist is not None:
         from doodle_amd.comm import ImageGather
-        gather = ImageGather()                 # RCCL all-gather on a side stream (libhelio_comm.so)
+        gather = ImageGather()                 # RCCL all-gather (libhelio_comm.so)
         gathered = [torch.empty((world * w.B, w.R, w.R), dtype=torch.float32, device=dev) for _ in range(2)]
     stepno = [0]
     if args.mode == "fwdbwd":
@@ -269,7 +277,7 @@ def main():
             if not args.no_cpu:
                 out["cpu_baseline"] = cpu_baseline(w, args.seed)
                 out["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
-        print(json.dumps(out), flush=True)
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()                 # rank 0 runs extra single-GPU legs; tear down together
     if gather is not None:
