@@ -357,6 +357,7 @@ int helio_notify_wait(const int* record, int ticket, double timeout_seconds) {
         if (seen == ticket) return __atomic_load_n(slot, __ATOMIC_RELAXED) ? 1 : 0;
         if (seen != 0 && (int)((unsigned)seen - (unsigned)ticket) > 0)
             return fail(HELIO_E_STALE, "notify_wait: slot reused by ticket %d while waiting for %d", seen, ticket);
+        __builtin_ia32_pause();
         if ((spin & 1023) == 0 &&
             std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_seconds)
             return fail(HELIO_E_TIMEOUT, "notify_wait: ticket %d not published within %.3f s", ticket, timeout_seconds);

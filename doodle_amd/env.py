@@ -166,8 +166,8 @@ class HelioEnv(_EnvBase):
                 ideal = self.ref_field.calculate_ideal_normals(self.sun_pos)
                 target, _ = self.ref_field.render(self.sun_pos, ideal.flatten(1), ideal)
                 tx = target.amax((1, 2)).clamp_min(1e-6)
-            self._ref_cache = (key, ideal, target, tx, (errs, single), ideal.view([-1, 3]))
-        return self._ref_cache[1:4]
+            self._ref_cache = (key, ideal, target, tx, ideal.view([-1, 3]), (errs, single))
+        return self._ref_cache[1:5]
 
     def set_sun_pos(self, sun_positions: torch.Tensor):
         """Fix the sun positions and precompute the reference image statistics (:359-370)."""
@@ -207,7 +207,7 @@ class HelioEnv(_EnvBase):
             action = torch.tensor(action, dtype=torch.float32, device=self.device)
         if self.use_error_mask and self.batch_size > 4096:
             raise NotImplementedError("use_error_mask: the fused quantile covers batch_size <= 4096")
-        ideal, target, tx = self._reference()
+        ideal, target, tx, ideal_flat = self._reference()
         consts = StepConstants(target, tx, self.distance_maps, ideal, self.noisy_field.heliostat_positions,
                                self._tp3, self._tn3, float(self.targ_area[0]), float(self.targ_area[1]),
                                bool(self.exponential_risk),
@@ -228,9 +228,8 @@ class HelioEnv(_EnvBase):
             if differentiate:
                 # render + loss block as one autograd node
                 (img, actual, reflected, mse, dist_l, bound, alignment_loss, mae, angles, all_bounds,
-                 flag) = env_step_fused(self.noisy_field, self.sun_pos, normals.contiguous(), consts,
-                                        notify=self.check_finite)
-                ticket = consts.ticket
+                 flag, ticket) = env_step_fused(self.noisy_field, self.sun_pos, normals.contiguous(), consts,
+                                                notify=self.check_finite)
             else:
                 img, actual, reflected = self.noisy_field.render(self.sun_pos, action, ideal, monitor=True)
                 mse, dist_l, bound, alignment_loss, mae, angles, all_bounds, flag = step_losses(img, actual, normals,
@@ -242,7 +241,7 @@ class HelioEnv(_EnvBase):
         monitor = {
             "normals": normals,
             "reflected_rays": reflected,
-            "ideal_normals": self._ref_cache[5],
+            "ideal_normals": ideal_flat,
             "all_bounds": all_bounds,
             "mae_image": mae,
             "alignment_errors": angles,

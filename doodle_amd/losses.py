@@ -30,7 +30,6 @@ class StepConstants:
     H: float
     exp_risk: bool
     mask_ratio: float = -1.0  # use_error_mask: fraction of worst images kept (< 0: no mask)
-    ticket: int = 0           # out: completion ticket of the last env_step_fused(notify=True)
 
 
 class _StepLosses(torch.autograd.Function):
@@ -68,13 +67,12 @@ class _EnvStep(torch.autograd.Function):
         image, actual, refl, rays, out, mae, align, allb, keep, _, ticket = ops.env_step_fwd(
             field.heliostat_positions, sun, normals, trig, trig_stride, field._plane, field._xs, field._ys, consts,
             notify=notify)
-        consts.ticket = ticket
         ctx.field, ctx.trig_stride, ctx.consts = field, trig_stride, consts
         ctx.save_for_backward(normals, sun, trig, rays, image, actual, keep)
         ctx.set_materialize_grads(False)
         flag = out[4]
         ctx.mark_non_differentiable(mae, align, allb, flag)
-        return image, actual, refl, out[0], out[1], out[2], out[3], mae, align, allb, flag
+        return image, actual, refl, out[0], out[1], out[2], out[3], mae, align, allb, flag, ticket
 
     @staticmethod
     def backward(ctx, g_image, g_actual, g_refl, g_mse, g_dist, g_bound, g_align, *_unused):
@@ -108,8 +106,8 @@ class _EnvStep(torch.autograd.Function):
 
 def env_step_fused(field, sun, normals, consts: StepConstants, notify: bool = False):
     """One autograd node for HelioEnv.step: → (image, actual, refl [B,N,3], mse, dist, bound,
-    alignment_loss, mae [B], angles [B,N], all_bounds [B,N], flag).  With ``notify`` the step's
-    completion ticket (for ``ops.notify_wait``) is left in ``consts.ticket``."""
+    alignment_loss, mae [B], angles [B,N], all_bounds [B,N], flag, ticket) — ``ticket`` (an int,
+    0 without ``notify``) is the step's completion ticket for ``ops.notify_wait``."""
     trig, stride = field._select_trig(sun.shape[0])
     return _EnvStep.apply(normals, field, sun, trig, stride, consts, notify)
 

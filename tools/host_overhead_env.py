@@ -28,7 +28,7 @@ with torch.no_grad():
     env.check_finite = False
     print("step (check_finite=False)  %.1f us" % t(lambda: env.step(act)))
     env.check_finite = True
-    ideal, target, tx = env._reference()
+    ideal, target, tx, _ = env._reference()
     print("_reference() cached        %.2f" % t(lambda: env._reference()))
     print("render monitor=True        %.2f" % t(lambda: env.noisy_field.render(env.sun_pos, act, ideal, monitor=True)))
     print("cat aux                    %.2f" % t(lambda: torch.cat([env.sun_pos.detach(), act.flatten(1)], dim=1)))
