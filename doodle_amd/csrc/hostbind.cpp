@@ -116,6 +116,31 @@ py::tuple step_losses_fwd(const at::Tensor& img, const at::Tensor& target, const
     return py::make_tuple(out, mae, align, allb, keep);
 }
 
+struct LossGrads { at::Tensor img, actual, action; };
+
+LossGrads step_losses_bwd_core(const at::Tensor& img, const at::Tensor& target, const at::Tensor& tx, const at::Tensor& dmaps,
+                               const at::Tensor& ideal, const at::Tensor& actual, const at::Tensor& action,
+                               const at::Tensor& helios, const std::vector<double>& tp, const std::vector<double>& tn,
+                               double W, double H, bool exp_risk, c10::optional<at::Tensor> g_mse,
+                               c10::optional<at::Tensor> g_dist, c10::optional<at::Tensor> g_bound,
+                               c10::optional<at::Tensor> g_align, c10::optional<at::Tensor> keep, bool want_img,
+                               bool want_actual, bool want_action) {
+    const int64_t B = action.size(0), N = action.size(1), R = img.size(-1);
+    const float tpf[3] = {(float)tp[0], (float)tp[1], (float)tp[2]}, tnf[3] = {(float)tn[0], (float)tn[1], (float)tn[2]};
+    LossGrads g;
+    if (want_img) g.img = at::empty_like(img);
+    if (want_actual) g.actual = at::empty_like(actual);
+    if (want_action) g.action = at::empty_like(action);
+    check(helio_step_losses_bwd((int)B, (int)N, (int)R, fp(img, "img"), fp(target, "target"), fp(tx, "tx"),
+                                fp(dmaps, "distance_maps"), fp(ideal, "ideal"), fp(actual, "actual"),
+                                fp(action, "action"), fp(helios, "heliostat_positions"), tpf, tnf, (float)W, (float)H,
+                                exp_risk ? 1 : 0, fpo(g_mse, "g_mse"), fpo(g_dist, "g_dist"), fpo(g_bound, "g_bound"),
+                                fpo(g_align, "g_align"), fpo(keep, "keep"), want_img ? g.img.data_ptr<float>() : nullptr,
+                                want_actual ? g.actual.data_ptr<float>() : nullptr,
+                                want_action ? g.action.data_ptr<float>() : nullptr, cur_stream(img)));
+    return g;
+}
+
 py::tuple step_losses_bwd(const at::Tensor& img, const at::Tensor& target, const at::Tensor& tx, const at::Tensor& dmaps,
                           const at::Tensor& ideal, const at::Tensor& actual, const at::Tensor& action,
                           const at::Tensor& helios, const std::vector<double>& tp, const std::vector<double>& tn,
@@ -123,23 +148,47 @@ py::tuple step_losses_bwd(const at::Tensor& img, const at::Tensor& target, const
                           c10::optional<at::Tensor> g_dist, c10::optional<at::Tensor> g_bound,
                           c10::optional<at::Tensor> g_align, c10::optional<at::Tensor> keep, bool want_img,
                           bool want_actual, bool want_action) {
-    const int64_t B = action.size(0), N = action.size(1), R = img.size(-1);
-    const float tpf[3] = {(float)tp[0], (float)tp[1], (float)tp[2]}, tnf[3] = {(float)tn[0], (float)tn[1], (float)tn[2]};
-    at::Tensor gi = want_img ? at::empty_like(img) : at::Tensor();
-    at::Tensor ga = want_actual ? at::empty_like(actual) : at::Tensor();
-    at::Tensor gn = want_action ? at::empty_like(action) : at::Tensor();
-    check(helio_step_losses_bwd((int)B, (int)N, (int)R, fp(img, "img"), fp(target, "target"), fp(tx, "tx"),
-                                fp(dmaps, "distance_maps"), fp(ideal, "ideal"), fp(actual, "actual"),
-                                fp(action, "action"), fp(helios, "heliostat_positions"), tpf, tnf, (float)W, (float)H,
-                                exp_risk ? 1 : 0, fpo(g_mse, "g_mse"), fpo(g_dist, "g_dist"), fpo(g_bound, "g_bound"),
-                                fpo(g_align, "g_align"), fpo(keep, "keep"), want_img ? gi.data_ptr<float>() : nullptr,
-                                want_actual ? ga.data_ptr<float>() : nullptr,
-                                want_action ? gn.data_ptr<float>() : nullptr, cur_stream(img)));
+    const LossGrads g = step_losses_bwd_core(img, target, tx, dmaps, ideal, actual, action, helios, tp, tn, W, H, exp_risk,
+                                             g_mse, g_dist, g_bound, g_align, keep, want_img, want_actual, want_action);
     auto o = [](const at::Tensor& t) -> py::object { return t.defined() ? py::cast(t) : py::none(); };
-    return py::make_tuple(o(gi), o(ga), o(gn));
+    return py::make_tuple(o(g.img), o(g.actual), o(g.action));
 }
 
-// HelioEnv.step forward (render + loss block + optional `aux` row) through helio_env_step_fwd:
+// HelioEnv.step forward (render + loss block + optional `aux` row) through helio_env_step_fwd
+struct StepOut { at::Tensor image, actual, refl, rays, out, mae, align, allb, keep, aux; };
+
+StepOut step_core(int64_t plane, const at::Tensor& helios, const at::Tensor& sun, const at::Tensor& normals,
+                  const at::Tensor& trig, int64_t trig_b_stride, const at::Tensor& xs, const at::Tensor& ys,
+                  c10::optional<at::Tensor> rays_ws, int64_t variant, const at::Tensor& target, const at::Tensor& tx,
+                  const at::Tensor& dmaps, const at::Tensor& ideal, const std::vector<double>& tp,
+                  const std::vector<double>& tn, double W, double H, bool exp_risk, double mask_ratio, bool want_aux,
+                  int64_t notify, int64_t ticket) {
+    const int64_t B = normals.size(0), N = normals.size(1), R = xs.size(0);
+    const float tpf[3] = {(float)tp[0], (float)tp[1], (float)tp[2]}, tnf[3] = {(float)tn[0], (float)tn[1], (float)tn[2]};
+    const auto opt = normals.options();
+    const float* pn = fp(normals, "action");
+    StepOut o;
+    o.actual = at::empty_like(normals);
+    o.refl = at::empty_like(normals);
+    o.rays = rays_ws.has_value() ? *rays_ws : at::empty({B, N, HELIO_RAY_STRIDE}, opt);
+    o.image = at::empty({B, R, R}, opt);
+    at::Tensor ws = at::empty({helio_env_step_workspace((int)B, (int)N, (int)R)}, opt);
+    o.out = at::empty({5}, opt); o.mae = at::empty({B}, opt); o.keep = at::empty({B}, opt);
+    o.align = at::empty({B, N}, opt); o.allb = at::empty({B, N}, opt);
+    if (want_aux) o.aux = at::empty({B, 3 + 3 * N}, opt);
+    check(helio_env_step_fwd((int)B, (int)N, (int)R, fp(helios, "heliostat_positions"), fp(sun, "sun"), pn,
+                             fp(trig, "trig"), (long)trig_b_stride, reinterpret_cast<const helio_plane*>(plane),
+                             fp(xs, "xs"), fp(ys, "ys"), o.actual.data_ptr<float>(), o.refl.data_ptr<float>(),
+                             o.rays.data_ptr<float>(), o.image.data_ptr<float>(), (int)variant, fp(target, "target"),
+                             fp(tx, "tx"), fp(dmaps, "distance_maps"), fp(ideal, "ideal"), tpf, tnf, (float)W,
+                             (float)H, exp_risk ? 1 : 0, (float)mask_ratio, ws.data_ptr<float>(),
+                             o.out.data_ptr<float>(), o.mae.data_ptr<float>(), o.keep.data_ptr<float>(),
+                             o.align.data_ptr<float>(), o.allb.data_ptr<float>(),
+                             want_aux ? o.aux.data_ptr<float>() : nullptr, reinterpret_cast<int*>(notify), (int)ticket,
+                             cur_stream(normals)));
+    return o;
+}
+
 // → (image, actual, refl, rays, out[5], mae, angles, all_bounds, keep, aux|None)
 py::tuple env_step_core(int64_t plane, const at::Tensor& helios, const at::Tensor& sun, const at::Tensor& normals,
                         const at::Tensor& trig, int64_t trig_b_stride, const at::Tensor& xs, const at::Tensor& ys,
@@ -147,29 +196,10 @@ py::tuple env_step_core(int64_t plane, const at::Tensor& helios, const at::Tenso
                         const at::Tensor& tx, const at::Tensor& dmaps, const at::Tensor& ideal,
                         const std::vector<double>& tp, const std::vector<double>& tn, double W, double H,
                         bool exp_risk, double mask_ratio, bool want_aux, int64_t notify, int64_t ticket) {
-    const int64_t B = normals.size(0), N = normals.size(1), R = xs.size(0);
-    const float tpf[3] = {(float)tp[0], (float)tp[1], (float)tp[2]}, tnf[3] = {(float)tn[0], (float)tn[1], (float)tn[2]};
-    const auto opt = normals.options();
-    const float* pn = fp(normals, "action");
-    at::Tensor actual = at::empty_like(normals), refl = at::empty_like(normals);
-    at::Tensor rays = rays_ws.has_value() ? *rays_ws : at::empty({B, N, HELIO_RAY_STRIDE}, opt);
-    at::Tensor image = at::empty({B, R, R}, opt);
-    at::Tensor ws = at::empty({helio_env_step_workspace((int)B, (int)N, (int)R)}, opt);
-    at::Tensor out = at::empty({5}, opt), mae = at::empty({B}, opt), keep = at::empty({B}, opt);
-    at::Tensor align = at::empty({B, N}, opt), allb = at::empty({B, N}, opt);
-    at::Tensor aux = want_aux ? at::empty({B, 3 + 3 * N}, opt) : at::Tensor();
-    check(helio_env_step_fwd((int)B, (int)N, (int)R, fp(helios, "heliostat_positions"), fp(sun, "sun"), pn,
-                             fp(trig, "trig"), (long)trig_b_stride, reinterpret_cast<const helio_plane*>(plane),
-                             fp(xs, "xs"), fp(ys, "ys"), actual.data_ptr<float>(), refl.data_ptr<float>(),
-                             rays.data_ptr<float>(), image.data_ptr<float>(), (int)variant, fp(target, "target"),
-                             fp(tx, "tx"), fp(dmaps, "distance_maps"), fp(ideal, "ideal"), tpf, tnf, (float)W,
-                             (float)H, exp_risk ? 1 : 0, (float)mask_ratio, ws.data_ptr<float>(),
-                             out.data_ptr<float>(), mae.data_ptr<float>(), keep.data_ptr<float>(),
-                             align.data_ptr<float>(), allb.data_ptr<float>(),
-                             want_aux ? aux.data_ptr<float>() : nullptr, reinterpret_cast<int*>(notify), (int)ticket,
-                             cur_stream(normals)));
-    py::object aux_o = want_aux ? py::cast(aux) : py::none();
-    return py::make_tuple(image, actual, refl, rays, out, mae, align, allb, keep, aux_o);
+    const StepOut o = step_core(plane, helios, sun, normals, trig, trig_b_stride, xs, ys, rays_ws, variant, target, tx, dmaps,
+                                ideal, tp, tn, W, H, exp_risk, mask_ratio, want_aux, notify, ticket);
+    py::object aux_o = want_aux ? py::cast(o.aux) : py::none();
+    return py::make_tuple(o.image, o.actual, o.refl, o.rays, o.out, o.mae, o.align, o.allb, o.keep, aux_o);
 }
 
 // HelioEnv.step without autograd in ONE binding call: the dtype/shape fix-ups of the action
@@ -184,13 +214,12 @@ py::tuple env_step_fwd(int64_t plane, const at::Tensor& helios, const at::Tensor
     at::Tensor action = action_in.to(helios.options(), false, false);
     at::Tensor normals = action.reshape({B, N, 3}).contiguous();
     if (rays_ws.has_value() && (rays_ws->size(0) != B || rays_ws->device() != normals.device())) rays_ws.reset();
-    py::tuple r = env_step_core(plane, helios, sun, normals, trig, trig_b_stride, xs, ys, rays_ws, variant, target, tx,
-                                dmaps, ideal, tp, tn, W, H, exp_risk, mask_ratio, true, notify, ticket);
+    const StepOut r = step_core(plane, helios, sun, normals, trig, trig_b_stride, xs, ys, rays_ws, variant, target, tx, dmaps,
+                                ideal, tp, tn, W, H, exp_risk, mask_ratio, true, notify, ticket);
     // the shapes step() hands out (:503-514), made here: a view costs ≈0.3 µs in C++, ≈1.5 µs in Python
-    const std::vector<at::Tensor> o = r[4].cast<at::Tensor>().unbind(0);
-    return py::make_tuple(r[0], r[1], r[2].cast<at::Tensor>().view({B * N, 3}), r[3], o[0], o[1], o[2], o[3], o[4],
-                          r[5].cast<at::Tensor>().view({B, 1}), r[6].cast<at::Tensor>().view({B * N}), r[7], r[9],
-                          normals);
+    const std::vector<at::Tensor> o = r.out.unbind(0);
+    return py::make_tuple(r.image, r.actual, r.refl.view({B * N, 3}), r.rays, o[0], o[1], o[2], o[3], o[4],
+                          r.mae.view({B, 1}), r.align.view({B * N}), r.allb, r.aux, normals);
 }
 
 // Backward of the env step in one call (helio_env_step_bwd): cotangents of the four scalars (0-d
@@ -231,6 +260,136 @@ int64_t notify_wait(int64_t record, int64_t ticket, double timeout_seconds) {
     return helio_notify_wait(reinterpret_cast<const int*>(record), (int)ticket, timeout_seconds);
 }
 
+// ---------------------------------------------------------------------------------------------
+// The two autograd nodes of the path as C++ torch::autograd::Function: same C-ABI calls as the
+// Python Functions of field.py / losses.py (which stay, for the ctypes binding), but the engine
+// runs their backward without the GIL and apply() costs ≈3 µs instead of ≈15 µs — at config 2 the
+// GPU work of step + backward is ≈40 µs, so that overhead is the difference that matters.
+// ---------------------------------------------------------------------------------------------
+using torch::autograd::AutogradContext;
+using torch::autograd::variable_list;
+
+c10::optional<at::Tensor> opt_contig(const at::Tensor& g) {
+    return g.defined() ? c10::optional<at::Tensor>(g.contiguous()) : c10::nullopt;
+}
+
+class RenderFn : public torch::autograd::Function<RenderFn> {
+ public:
+    static variable_list forward(AutogradContext* ctx, at::Tensor normals, int64_t plane, at::Tensor helios, at::Tensor sun,
+                                 at::Tensor trig, int64_t trig_b_stride, at::Tensor xs, at::Tensor ys, int64_t variant,
+                                 int64_t bwd_variant) {
+        const int64_t B = normals.size(0), N = normals.size(1), R = xs.size(0);
+        at::Tensor actual = at::empty_like(normals), refl = at::empty_like(normals);
+        at::Tensor rays = at::empty({B, N, HELIO_RAY_STRIDE}, normals.options());
+        at::Tensor image = at::empty({B, R, R}, normals.options());
+        check(helio_render_fwd((int)B, (int)N, (int)R, fp(helios, "heliostat_positions"), fp(sun, "sun"),
+                               fp(normals, "action"), fp(trig, "trig"), (long)trig_b_stride,
+                               reinterpret_cast<const helio_plane*>(plane), fp(xs, "xs"), fp(ys, "ys"),
+                               actual.data_ptr<float>(), refl.data_ptr<float>(), rays.data_ptr<float>(),
+                               image.data_ptr<float>(), (int)variant, cur_stream(normals)));
+        ctx->save_for_backward({normals, sun, trig, rays, helios, xs, ys});
+        ctx->saved_data["plane"] = plane;
+        ctx->saved_data["stride"] = trig_b_stride;
+        ctx->saved_data["bwd_variant"] = bwd_variant;
+        ctx->set_materialize_grads(false);        // unused outputs arrive undefined, not as zero tensors
+        return {image, actual, refl};
+    }
+
+    static variable_list backward(AutogradContext* ctx, variable_list g) {
+        const auto sv = ctx->get_saved_variables();
+        variable_list out(10);
+        if (!g[0].defined() && !g[1].defined() && !g[2].defined()) return out;
+        out[0] = render_bwd(ctx->saved_data["plane"].toInt(), sv[4], sv[1], sv[0], sv[2], ctx->saved_data["stride"].toInt(),
+                            sv[3], sv[5], sv[6], opt_contig(g[0]), opt_contig(g[1]), opt_contig(g[2]),
+                            ctx->saved_data["bwd_variant"].toInt());
+        return out;
+    }
+};
+
+py::tuple render_autograd(int64_t plane, const at::Tensor& helios, const at::Tensor& sun, const at::Tensor& normals,
+                          const at::Tensor& trig, int64_t trig_b_stride, const at::Tensor& xs, const at::Tensor& ys,
+                          int64_t variant, int64_t bwd_variant) {
+    variable_list o = RenderFn::apply(normals, plane, helios, sun, trig, trig_b_stride, xs, ys, variant, bwd_variant);
+    return py::make_tuple(o[0], o[1], o[2]);
+}
+
+class EnvStepFn : public torch::autograd::Function<EnvStepFn> {
+ public:
+    static variable_list forward(AutogradContext* ctx, at::Tensor normals, int64_t plane, at::Tensor helios, at::Tensor sun,
+                                 at::Tensor trig, int64_t trig_b_stride, at::Tensor xs, at::Tensor ys, int64_t variant,
+                                 int64_t bwd_variant, at::Tensor target, at::Tensor tx, at::Tensor dmaps, at::Tensor ideal,
+                                 std::vector<double> tp, std::vector<double> tn, double W, double H, bool exp_risk,
+                                 double mask_ratio, int64_t notify, int64_t ticket) {
+        const StepOut r = step_core(plane, helios, sun, normals, trig, trig_b_stride, xs, ys, c10::nullopt, variant, target, tx,
+                                    dmaps, ideal, tp, tn, W, H, exp_risk, mask_ratio, false, notify, ticket);
+        const at::Tensor &image = r.image, &actual = r.actual, &refl = r.refl, &rays = r.rays, &out = r.out, &mae = r.mae,
+                         &align = r.align, &allb = r.allb, &keep = r.keep;
+        ctx->save_for_backward({normals, sun, trig, rays, image, actual, keep, helios, xs, ys, target, tx, dmaps, ideal});
+        ctx->saved_data["plane"] = plane;
+        ctx->saved_data["stride"] = trig_b_stride;
+        ctx->saved_data["bwd_variant"] = bwd_variant;
+        ctx->saved_data["tp"] = tp;
+        ctx->saved_data["tn"] = tn;
+        ctx->saved_data["W"] = W;
+        ctx->saved_data["H"] = H;
+        ctx->saved_data["exp_risk"] = exp_risk;
+        ctx->set_materialize_grads(false);
+        const std::vector<at::Tensor> o = out.unbind(0);
+        ctx->mark_non_differentiable({mae, align, allb, o[4]});
+        return {image, actual, refl, o[0], o[1], o[2], o[3], mae, align, allb, o[4]};
+    }
+
+    static variable_list backward(AutogradContext* ctx, variable_list g) {
+        const auto sv = ctx->get_saved_variables();
+        const at::Tensor &normals = sv[0], &sun = sv[1], &trig = sv[2], &rays = sv[3], &image = sv[4], &actual = sv[5],
+                         &keep = sv[6], &helios = sv[7], &xs = sv[8], &ys = sv[9], &target = sv[10], &tx = sv[11],
+                         &dmaps = sv[12], &ideal = sv[13];
+        const int64_t plane = ctx->saved_data["plane"].toInt(), stride = ctx->saved_data["stride"].toInt();
+        const int64_t bwd_variant = ctx->saved_data["bwd_variant"].toInt();
+        const std::vector<double> tp = ctx->saved_data["tp"].toDoubleVector(), tn = ctx->saved_data["tn"].toDoubleVector();
+        const double W = ctx->saved_data["W"].toDouble(), H = ctx->saved_data["H"].toDouble();
+        const bool exp_risk = ctx->saved_data["exp_risk"].toBool();
+        variable_list res(22);
+        auto g_mse = opt_contig(g[3]), g_dist = opt_contig(g[4]), g_bound = opt_contig(g[5]), g_align = opt_contig(g[6]);
+        if (!g[0].defined()) {
+            // the whole backward in one C call (helio_env_step_bwd)
+            res[0] = env_step_bwd(plane, helios, sun, normals, trig, stride, rays, xs, ys, image, target, tx, dmaps, ideal,
+                                  tp, tn, W, H, exp_risk, g_mse, g_dist, g_bound, g_align, keep, opt_contig(g[1]),
+                                  opt_contig(g[2]), bwd_variant);
+            return res;
+        }
+        // an external cotangent of the image as well: loss gradients first, then the render backward
+        const bool need_img = g_mse.has_value() || g_dist.has_value();
+        at::Tensor g_image = g[0], g_actual = g[1], gn;
+        if (need_img || g_align.has_value() || g_bound.has_value()) {
+            const LossGrads l = step_losses_bwd_core(image, target, tx, dmaps, ideal, actual, normals, helios, tp, tn, W, H,
+                                                     exp_risk, g_mse, g_dist, g_bound, g_align, keep, need_img,
+                                                     g_align.has_value(), g_bound.has_value());
+            if (need_img) g_image = g_image + l.img;
+            if (g_align.has_value()) g_actual = g_actual.defined() ? g_actual + l.actual : l.actual;
+            gn = l.action;
+        }
+        at::Tensor gr = render_bwd(plane, helios, sun, normals, trig, stride, rays, xs, ys, opt_contig(g_image),
+                                   opt_contig(g_actual), opt_contig(g[2]), bwd_variant);
+        res[0] = gn.defined() ? gr + gn : gr;
+        return res;
+    }
+};
+
+// → (image, actual, refl, mse, dist, bound, alignment_loss, mae, angles, all_bounds, flag)
+py::tuple env_step_autograd(int64_t plane, const at::Tensor& helios, const at::Tensor& sun, const at::Tensor& normals,
+                            const at::Tensor& trig, int64_t trig_b_stride, const at::Tensor& xs, const at::Tensor& ys,
+                            int64_t variant, int64_t bwd_variant, const at::Tensor& target, const at::Tensor& tx,
+                            const at::Tensor& dmaps, const at::Tensor& ideal, const std::vector<double>& tp,
+                            const std::vector<double>& tn, double W, double H, bool exp_risk, double mask_ratio,
+                            int64_t notify, int64_t ticket) {
+    variable_list o = EnvStepFn::apply(normals, plane, helios, sun, trig, trig_b_stride, xs, ys, variant, bwd_variant, target,
+                                       tx, dmaps, ideal, tp, tn, W, H, exp_risk, mask_ratio, notify, ticket);
+    py::tuple t(o.size());
+    for (size_t k = 0; k < o.size(); ++k) t[k] = o[k];
+    return t;
+}
+
 at::Tensor ideal_normals(const at::Tensor& helios, const at::Tensor& sun, const std::vector<double>& target) {
     const int64_t B = sun.size(0), N = helios.size(0);
     const float t[3] = {(float)target[0], (float)target[1], (float)target[2]};
@@ -259,5 +418,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("env_step_core", &env_step_core);
     m.def("notify_wait", &notify_wait);
     m.def("env_step_bwd", &env_step_bwd);
+    m.def("render_autograd", &render_autograd);
+    m.def("env_step_autograd", &env_step_autograd);
     m.def("ideal_normals", &ideal_normals);
 }

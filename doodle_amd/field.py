@@ -231,7 +231,10 @@ class HelioField:
         trig, stride = self._select_trig(global_batch, row_offset, B)
 
         if torch.is_grad_enabled() and normals.requires_grad:
-            images, actual, refl = _Render.apply(normals, self, sun, trig, stride)
+            node = getattr(_get_ops(), "render_node", None)
+            out = node(self, sun, normals, trig, stride) if node is not None else None
+            # (the same node as a C++ autograd Function when the compiled binding is built)
+            images, actual, refl = out if out is not None else _Render.apply(normals, self, sun, trig, stride)
         else:
             # no autograd: the ray work buffer is scratch, reuse it between calls
             ws = self._ray_ws

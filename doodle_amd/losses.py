@@ -109,6 +109,10 @@ def env_step_fused(field, sun, normals, consts: StepConstants, notify: bool = Fa
     alignment_loss, mae [B], angles [B,N], all_bounds [B,N], flag, ticket) — ``ticket`` (an int,
     0 without ``notify``) is the step's completion ticket for ``ops.notify_wait``."""
     trig, stride = field._select_trig(sun.shape[0])
+    node = getattr(_field._get_ops(), "env_step_node", None)
+    out = node(field, sun, normals, trig, stride, consts, notify) if node is not None else None
+    if out is not None:          # the same node as a C++ autograd Function (csrc/hostbind.cpp)
+        return out
     return _EnvStep.apply(normals, field, sun, trig, stride, consts, notify)
 
 

@@ -274,6 +274,26 @@ class HipOps:
             ptr(g_refl), ptr(gws), ptr(moments), grad.data_ptr(), self.bwd_variant, _stream()))
         return grad
 
+    # -- the two autograd nodes as C++ torch::autograd::Function (compiled binding only) ------------
+    def render_node(self, field, sun, normals, trig, trig_b_stride):
+        """``_Render.apply`` of field.py without the Python Function (None: binding not built)."""
+        if self.hb is None:
+            return None
+        return self.hb.render_autograd(_plane_handle(self.hb, field._plane), field.heliostat_positions, sun, normals,
+                                       trig, trig_b_stride, field._xs, field._ys, self.splat_variant, self.bwd_variant)
+
+    def env_step_node(self, field, sun, normals, trig, trig_b_stride, c, notify=False):
+        """``_EnvStep.apply`` of losses.py without the Python Function (None: binding not built).
+        → (image, actual, refl, mse, dist, bound, alignment_loss, mae, angles, all_bounds, flag, ticket)."""
+        if self.hb is None:
+            return None
+        rec, ticket = self._next_ticket() if notify else (0, 0)
+        out = self.hb.env_step_autograd(_plane_handle(self.hb, field._plane), field.heliostat_positions, sun, normals,
+                                        trig, trig_b_stride, field._xs, field._ys, self.splat_variant, self.bwd_variant,
+                                        c.target, c.tx, c.dmaps, c.ideal, list(c.tp), list(c.tn), c.W, c.H,
+                                        bool(c.exp_risk), float(c.mask_ratio), rec, ticket)
+        return (*out, ticket)
+
     def env_step_nograd(self, field, sun, action, trig, trig_b_stride, c, notify=False):
         """HelioEnv.step without autograd in one call of the compiled binding (render + loss block +
         aux, outputs already in the shapes step() returns).  None when that binding is not built.

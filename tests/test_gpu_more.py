@@ -820,3 +820,52 @@ def test_env_step_bwd_abi_call_matches_the_composed_backward(N, B, R, mask):
         else:                                                          # moment kernels may differ (few-ray vs MFMA)
             assert (got - want).abs().max().item() <= 2e-5 * max(scale, 1e-30), names
     assert ops.lib.helio_env_step_bwd_image_ws(B, N, R) == (0 if (N <= 8 or (N <= 16 and B <= 64) or (N <= 32 and B <= 8)) else 1)
+
+
+def test_cpp_and_python_autograd_nodes_agree():
+    """The C++ torch::autograd::Function nodes of the compiled binding (render, env step) and the
+    Python Functions used with the ctypes binding give identical values and gradients, including
+    the path with an external cotangent on the image and on `actual`/`refl` next to the metrics."""
+    from doodle_amd import native
+    from doodle_amd.env import HelioEnv
+    ops = native.get_ops()
+    if ops.hb is None:
+        pytest.skip("_hostbind not built")
+    torch.manual_seed(11)
+    N, B, R = 12, 9, 96
+    hp = torch.rand(N, 3, device=DEV) * 10 + 80
+    hp[:, 2] = 0
+    env = HelioEnv(hp, torch.tensor([0., -5., 0.], device=DEV), (15., 15.), torch.tensor([0., 1., 0.], device=DEV),
+                   sigma_scale=0.03, error_scale_mrad=20.0, resolution=R, batch_size=B, device=DEV)
+    env.reset()
+    act = torch.nn.functional.normalize(env.ideal_normals + 0.01 * torch.randn_like(env.ideal_normals), dim=2)
+    G = torch.randn(B, R, R, device=DEV)
+    Ha, Hr = torch.randn(B, N, 3, device=DEV), torch.randn(B * N, 3, device=DEV)
+    losses = {
+        "dist": lambda o, m, mon: m["dist"],
+        "all metrics": lambda o, m, mon: m["mse"] + 0.5 * m["dist"] - 0.2 * m["bound"] + 0.01 * m["alignment_loss"],
+        "metrics + image": lambda o, m, mon: m["dist"] + (o["img"] * G).sum() * 1e-3,
+        "image + reflected": lambda o, m, mon: (o["img"] * G).sum() + (mon["reflected_rays"] * Hr).sum() + m["bound"],
+        "alignment only": lambda o, m, mon: m["alignment_loss"],
+    }
+    for name, fn in losses.items():
+        got = {}
+        for binding, hb in (("cpp", ops.hb), ("python", None)):
+            saved, ops.hb = ops.hb, hb
+            try:
+                a = act.clone().requires_grad_(True)
+                o, m, mon = env.step(a)
+                val = fn(o, m, mon)
+                (g,) = torch.autograd.grad(val, a)
+                a2 = act.reshape(B, -1).clone().requires_grad_(True)
+                img, actual, refl = env.noisy_field.render(env.sun_pos, a2, None, monitor=True)
+                (g2,) = torch.autograd.grad((img * G).sum() + (actual * Ha).sum() + (refl * Hr).sum(), a2)
+            finally:
+                ops.hb = saved
+            got[binding] = (val.detach(), g, o["img"].detach(), m["mse"].detach(), g2)
+        for p, q in zip(got["cpp"], got["python"]):
+            assert torch.equal(p, q), name
+    # unused outputs: no gradient requested through the node at all
+    a = act.clone().requires_grad_(True)
+    o, m, mon = env.step(a)
+    assert m["dist"].requires_grad and not mon["mae_image"].requires_grad and not mon["alignment_errors"].requires_grad
