@@ -528,6 +528,7 @@ int launch_splat_bwd(int B, int N, int R, const float* rays, const float* xs, co
         variant = splat_bwd_is_few(B, N) ? 4 : (R > 128 && N >= 96 && wgs >= 128) ? 2 : 3;
     }
     if (variant == 4) {
+        if ((N + 3) / 4 > 65535) return HELIO_E_INVALID;          // grid.z; never chosen for that many rays
         launch_bwd_few<false>(B, N, R, rays, xs, ys, gimg, LossGradArgs{}, moments, st);
         return HELIO_OK;
     }
