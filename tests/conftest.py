@@ -36,3 +36,14 @@ def render_fixture_names():
 @pytest.fixture(scope="session")
 def golden_loader():
     return golden
+
+
+# HelioEnv fixtures recorded from the reference (tests/golden/make_golden.py, make_env_golden):
+# tag → (file stem, use_error_mask, exponential_risk, single_sun, azimuth, elevation)
+ENV_FIXTURES = {
+    "train": ("g6_env_train_n50_b25_r64", False, False, False, 45.0, 45.0),
+    "readme": ("g6_env_readme_n50_b25_r64", False, False, False, 45.0, 45.0),
+    "mask": ("g6_env_mask_n50_b25_r64", True, False, False, 45.0, 45.0),
+    "exprisk": ("g6_env_exprisk_n20_b12_r48", False, True, False, 45.0, 45.0),
+    "single": ("g6_env_single_n20_b12_r48", True, False, True, 30.0, 50.0),
+}

@@ -275,31 +275,44 @@ def make_env_golden(helios, suns):
     sys.modules["gymnasium"], sys.modules["gymnasium.spaces"] = gym, spaces
     import test_environment as refenv  # noqa: E402
 
-    for tag, sig, err, masked in (("train", 0.01, 90.0, False), ("readme", 0.1, 180.0, False),
-                                  ("mask", 0.02, 60.0, True)):
+    # (tag, sigma_scale, err mrad, use_error_mask, exponential_risk, single_sun, N, B, R, action noise)
+    cases = (("train", 0.01, 90.0, False, False, False, 50, 25, 64, 0.003),
+             ("readme", 0.1, 180.0, False, False, False, 50, 25, 64, 0.003),
+             ("mask", 0.02, 60.0, True, False, False, 50, 25, 64, 0.003),
+             # exponential_risk (:464-488) with actions far enough off for rays to leave the target;
+             # single_sun (:297-305): the env builds its own repeated sun, set_sun_pos is not called
+             ("exprisk", 0.03, 30.0, False, True, False, 20, 12, 48, 0.03),
+             ("single", 0.02, 45.0, True, False, True, 20, 12, 48, 0.01))
+    for tag, sig, err, masked, exp_risk, single, N, B, R, noise in cases:
         torch.manual_seed(21)
+        hel = helios[:N]
         env = refenv.HelioEnv(
-            heliostat_pos=helios, targ_pos=torch.tensor([0.0, -5.0, 0.0]),
+            heliostat_pos=hel, targ_pos=torch.tensor([0.0, -5.0, 0.0]),
             targ_area=(15.0, 15.0), targ_norm=torch.tensor([0.0, 1.0, 0.0]),
             sigma_scale=sig, error_scale_mrad=err, initial_action_noise=0.0,
-            resolution=64, batch_size=25, device="cpu",
-            new_errors_every_reset=False, use_error_mask=masked, error_mask_ratio=0.2)
+            resolution=R, batch_size=B, device="cpu",
+            new_errors_every_reset=False, use_error_mask=masked, error_mask_ratio=0.2,
+            exponential_risk=exp_risk, single_sun=single, azimuth=30.0 if single else 45.0,
+            elevation=50.0 if single else 45.0)
         cone_suns = env.sun_pos.clone()
-        env.set_sun_pos(suns)
+        if not single:
+            env.set_sun_pos(suns[:B])
         obs0 = env.reset()
         gen = torch.Generator().manual_seed(5)
-        act = env.ideal_normals + 0.003 * torch.randn(env.ideal_normals.shape, generator=gen)
-        act = (act / act.norm(dim=2, keepdim=True)).reshape(25, -1).requires_grad_(True)
+        act = env.ideal_normals + noise * torch.randn(env.ideal_normals.shape, generator=gen)
+        act = (act / act.norm(dim=2, keepdim=True)).reshape(B, -1).requires_grad_(True)
         obs, metrics, monitor = env.step(act)
         grads = {}
         for k in ("mse", "dist", "bound", "alignment_loss"):
             (g,) = torch.autograd.grad(metrics[k], act, retain_graph=True, allow_unused=True)
             grads["grad_" + k] = (g if g is not None else torch.zeros_like(act)).numpy()
         np.savez_compressed(
-            os.path.join(OUT, f"g6_env_{tag}_n50_b25_r64.npz"),
-            helios=helios.numpy(), sigma_scale=np.float64(sig),
-            error_scale_mrad=np.float64(err), resolution=np.int64(64),
-            cone_suns=cone_suns.numpy(), suns=suns.numpy(),
+            os.path.join(OUT, f"g6_env_{tag}_n{N}_b{B}_r{R}.npz"),
+            helios=hel.numpy(), sigma_scale=np.float64(sig),
+            error_scale_mrad=np.float64(err), resolution=np.int64(R), batch_size=np.int64(B),
+            use_error_mask=np.bool_(masked), exponential_risk=np.bool_(exp_risk), single_sun=np.bool_(single),
+            azimuth=np.float64(30.0 if single else 45.0), elevation=np.float64(50.0 if single else 45.0),
+            cone_suns=cone_suns.numpy(), suns=env.sun_pos.numpy(),
             error_angles_mrad=env.noisy_field.error_angles_mrad.numpy(),
             batch_error_angles_mrad=env.noisy_field.batch_error_angles_mrad.numpy(),
             distance_maps=env.distance_maps.numpy(),
@@ -310,7 +323,8 @@ def make_env_golden(helios, suns):
             **{"metric_" + k: v.detach().numpy() for k, v in metrics.items()},
             **{"monitor_" + k: v.detach().numpy() for k, v in monitor.items()},
             **grads)
-        print(f"g6_env_{tag}", {k: float(v) for k, v in metrics.items()})
+        print(f"g6_env_{tag}", {k: float(v) for k, v in metrics.items()},
+              "rays off target:", int((monitor["all_bounds"] > 0).sum()))
 
 
 if __name__ == "__main__":

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import golden
+from conftest import ENV_FIXTURES, golden
 from oracle import torch_oracle as to
 
 pytestmark = pytest.mark.gpu
@@ -69,15 +69,18 @@ def test_abi_size_limits_fail_cleanly():
         native.get_ops().splat_fwd(torch.zeros(1, 2, 4), f._xs, f._ys)
 
 
-@pytest.mark.parametrize("tag", ["train", "readme", "mask"])
+@pytest.mark.parametrize("tag", sorted(ENV_FIXTURES))
 def test_env_matches_reference_fixture(tag):
     from doodle_amd.env import HelioEnv
-    g = golden(f"g6_env_{tag}_n50_b25_r64")
+    stem, masked, exp_risk, single, az, el = ENV_FIXTURES[tag]
+    g = golden(stem)
+    N, B, R = g["helios"].shape[0], g["suns"].shape[0], int(g["resolution"])
     env = HelioEnv(heliostat_pos=torch.from_numpy(g["helios"]).to(DEV), targ_pos=torch.tensor([0.0, -5.0, 0.0], device=DEV),
                    targ_area=(15.0, 15.0), targ_norm=torch.tensor([0.0, 1.0, 0.0], device=DEV),
                    sigma_scale=float(g["sigma_scale"]), error_scale_mrad=float(g["error_scale_mrad"]),
-                   initial_action_noise=0.0, resolution=64, batch_size=25, device=DEV, new_errors_every_reset=False,
-                   use_error_mask=(tag == "mask"), error_mask_ratio=0.2)
+                   initial_action_noise=0.0, resolution=R, batch_size=B, device=DEV, new_errors_every_reset=False,
+                   use_error_mask=masked, error_mask_ratio=0.2, exponential_risk=exp_risk, single_sun=single,
+                   azimuth=az, elevation=el)
     env.noisy_field.error_angles_mrad = torch.from_numpy(g["error_angles_mrad"])
     env.noisy_field.batch_error_angles_mrad = torch.from_numpy(g["batch_error_angles_mrad"])
     env.set_sun_pos(torch.from_numpy(g["suns"]).to(DEV))
@@ -87,9 +90,9 @@ def test_env_matches_reference_fixture(tag):
     # its own initial_action_noise, test_environment.py:255-277): not comparable across
     # devices.  tests/test_host_logic.py pins them on CPU with the reference's seed; here
     # the reference's distance maps are injected and step() is compared.
-    assert obs0["img"].shape == (25, 64, 64) and torch.isfinite(obs0["img"]).all()
+    assert obs0["img"].shape == (B, R, R) and torch.isfinite(obs0["img"]).all()
     assert np.array_equal(obs0["aux"].cpu().numpy(), g["reset_aux"])
-    assert env.distance_maps.shape == (25, 64, 64) and float(env.ref_max) > 0
+    assert env.distance_maps.shape == (B, R, R) and float(env.ref_max) > 0
     env.distance_maps = torch.from_numpy(g["distance_maps"]).to(DEV)
     act = torch.from_numpy(g["action"]).to(DEV).requires_grad_(True)
     obs, metrics, monitor = env.step(act)

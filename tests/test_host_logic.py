@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import ROOT, golden, render_fixture_names
+from conftest import ENV_FIXTURES, ROOT, golden, render_fixture_names
 import oracle_backend
 
 NAMES = render_fixture_names()
@@ -218,22 +218,28 @@ def test_init_actions(monkeypatch):
 
 
 # ------------------------------------------------------------------ HelioEnv
-@pytest.mark.parametrize("tag", ["train", "readme", "mask"])
+@pytest.mark.parametrize("tag", sorted(ENV_FIXTURES))
 def test_env_reset_step_match_reference(tag, monkeypatch):
     oracle_backend.install(monkeypatch)
     from doodle_amd.env import HelioEnv
-    g = golden(f"g6_env_{tag}_n50_b25_r64")
+    stem, masked, exp_risk, single, az, el = ENV_FIXTURES[tag]
+    g = golden(stem)
+    N, B, R = g["helios"].shape[0], g["suns"].shape[0], int(g["resolution"])
     torch.manual_seed(21)
     env = HelioEnv(heliostat_pos=torch.from_numpy(g["helios"]), targ_pos=torch.tensor([0.0, -5.0, 0.0]),
                    targ_area=(15.0, 15.0), targ_norm=torch.tensor([0.0, 1.0, 0.0]),
                    sigma_scale=float(g["sigma_scale"]), error_scale_mrad=float(g["error_scale_mrad"]),
-                   initial_action_noise=0.0, resolution=64, batch_size=25, device="cpu",
-                   new_errors_every_reset=False, use_error_mask=(tag == "mask"), error_mask_ratio=0.2)
+                   initial_action_noise=0.0, resolution=R, batch_size=B, device="cpu",
+                   new_errors_every_reset=False, use_error_mask=masked, error_mask_ratio=0.2,
+                   exponential_risk=exp_risk, single_sun=single, azimuth=az, elevation=el)
     # same seed, same RNG call order → same cone suns and the same error tensors
     assert np.array_equal(env.sun_pos.numpy(), g["cone_suns"])
     assert np.array_equal(env.noisy_field.batch_error_angles_mrad.numpy(), g["batch_error_angles_mrad"])
-    assert env.observation_space["img"].shape == (25, 64, 64) and env.action_space.shape == (150,)
-    env.set_sun_pos(torch.from_numpy(g["suns"]))
+    assert env.observation_space["img"].shape == (B, R, R) and env.action_space.shape == (3 * N,)
+    if single:          # the env's own repeated sun (:297-305); set_sun_pos was not called by the reference either
+        assert np.array_equal(env.sun_pos.numpy(), g["suns"]) and (env.sun_pos == env.sun_pos[0]).all()
+    else:
+        env.set_sun_pos(torch.from_numpy(g["suns"]))
     np.testing.assert_allclose(env.distance_maps.numpy(), g["distance_maps"], atol=1e-6)
     np.testing.assert_allclose(float(env.ref_max), float(g["ref_max"]), rtol=1e-5)
     obs0 = env.reset()

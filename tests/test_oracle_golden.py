@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import golden, render_fixture_names
+from conftest import ENV_FIXTURES, golden, render_fixture_names
 from oracle import c_oracle, torch_oracle as to
 
 NAMES = render_fixture_names()
@@ -127,14 +127,15 @@ def test_tiny_scene_properties():
 import pytest as _pytest
 
 
-@_pytest.mark.parametrize("tag", ["train", "readme", "mask"])
+@_pytest.mark.parametrize("tag", sorted(ENV_FIXTURES))
 def test_step_loss_oracle_matches_reference_env(tag):
     """oracle.step_losses on the reference's recorded step() inputs reproduces its metrics,
     monitors and gradients bit for bit (same ATen ops in the same order)."""
-    g = golden(f"g6_env_{tag}_n50_b25_r64")
+    stem, masked, exp_risk, _, _, _ = ENV_FIXTURES[tag]
+    g = golden(stem)
     helios = torch.from_numpy(g["helios"])
     tp, tn = torch.tensor([0.0, -5.0, 0.0]), torch.tensor([0.0, 1.0, 0.0])
-    sc = to.Scene.build(helios, tp, (15.0, 15.0), tn, 64, float(g["sigma_scale"]))
+    sc = to.Scene.build(helios, tp, (15.0, 15.0), tn, int(g["resolution"]), float(g["sigma_scale"]))
     suns = torch.from_numpy(g["suns"])
     act = torch.from_numpy(g["action"]).clone().requires_grad_(True)
     errs = torch.from_numpy(g["batch_error_angles_mrad"])
@@ -143,7 +144,7 @@ def test_step_loss_oracle_matches_reference_env(tag):
     with torch.no_grad():
         target, _ = to.render(sc, suns, ideal.flatten(1), torch.zeros_like(errs))
     out = to.step_losses(img, target, torch.from_numpy(g["distance_maps"]), ideal, actual, act, helios, tp, tn,
-                         (15.0, 15.0), error_mask_ratio=0.2 if tag == "mask" else None)
+                         (15.0, 15.0), exp_risk, error_mask_ratio=0.2 if masked else None)
     names = ("mse", "dist", "bound", "alignment_loss")
     for k, v in zip(names, out[:4]):
         assert np.array_equal(v.detach().numpy(), g["metric_" + k]), k
