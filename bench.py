@@ -166,6 +166,7 @@ def main():
     json_fd = os.dup(1)
     os.dup2(2, 1)
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC for RCCL; before HIP initialises
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -176,7 +177,6 @@ def main():
     dist = None
     if world > 1 or args.force_dist:
         import torch.distributed as dist
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29517"), ("RANK", "0"), ("WORLD_SIZE", "1")):
             os.environ.setdefault(k, v)          # only matters for a bare --force-dist run
         dist.init_process_group("nccl", device_id=dev)
