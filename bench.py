@@ -229,6 +229,26 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
 
+    # beyond one GPU the config-2 step is bound by delivering 7 x 1.64 MB to every rank (DESIGN.md
+    # §5); the same loop without the all-gather separates the renderers' scaling from the
+    # interconnect's (reported beside `value`, never instead of it)
+    el_local = None
+    if gather is not None and (world > 1 or args.force_dist):
+        saved, gather = gather, None
+        for _ in range(min(args.warmup, 50)):
+            step()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el_local = float(t.item())
+        gather = saved
+
     # secondary weak-scaling point on EVERY rank (collective): a config-5-like shard, where
     # compute (ms) dominates the all-gather — see DESIGN.md §5
     shard = None
@@ -253,6 +273,10 @@ def main():
                           f"{'side stream' if args.overlap else 'stream-ordered'})"
                           if gather is not None else "")},
         }
+        if el_local is not None:
+            out["without_all_gather"] = {"frames_per_s": round(frames / el_local, 1),
+                                         "ms_per_step": round(el_local / args.steps * 1e3, 5),
+                                         "note": "same shards, images left on the rank that rendered them"}
         if shard is not None:
             out["weak_scaling_config5_shard"] = shard
         iters = 200 if w.B * w.N * w.R * w.R < 1e10 else 10
