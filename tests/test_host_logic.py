@@ -3,6 +3,7 @@ for the HIP library (tests/oracle_backend.py).  Also: the C-ABI library loads an
 every symbol include/helio.h declares, and the product refuses to run without a GPU.
 """
 import inspect
+import ctypes
 import os
 import re
 
@@ -60,6 +61,17 @@ def test_abi_rejects_bad_arguments_without_launching():
     assert lib.helio_splat_fwd(1, 1, 8, None, None, None, None, 0, None) == -1
     assert lib.helio_render_fwd_launches(25, 50, 128) == 1 and lib.helio_render_fwd_launches(512, 2000, 512) == 2
     assert b"null pointer" in lib.helio_last_error_string()
+    # the env-step entry points: size queries and argument checks are host code
+    assert lib.helio_env_step_launches(25, 50, 128) == 2 and lib.helio_env_step_launches(512, 2000, 512) == 4
+    assert lib.helio_env_step_workspace(25, 50, 128) >= 3 * 25 * 4 + 2 * 25
+    assert lib.helio_env_step_workspace(25, 50, 100) >= max(3 * 25 * 4 + 2 * 25, lib.helio_step_losses_workspace(25, 50, 100))
+    assert lib.helio_env_step_bwd_image_ws(500, 1, 128) == 0 and lib.helio_env_step_bwd_image_ws(25, 50, 128) == 1
+    f3 = (ctypes.c_float * 3)()
+    assert lib.helio_env_step_fwd(25, 50, 128, *([None] * 4), 0, plane, *([None] * 6), 0, *([None] * 4), f3, f3, 15.0, 15.0,
+                                  0, -1.0, *([None] * 7), None, 0, None) == -1
+    assert lib.helio_env_step_bwd(25, 50, 128, *([None] * 4), 0, plane, *([None] * 8), f3, f3, 15.0, 15.0, 0,
+                                  *([None] * 10), 0, None) == -1
+    assert lib.helio_notify_wait(None, 1, 0.0) == -1 and lib.helio_notify_destroy(None) == 0
 
 
 def test_no_cpu_fallback():
