@@ -872,3 +872,60 @@ def test_cpp_and_python_autograd_nodes_agree():
     a = act.clone().requires_grad_(True)
     o, m, mon = env.step(a)
     assert m["dist"].requires_grad and not mon["mae_image"].requires_grad and not mon["alignment_errors"].requires_grad
+
+
+def test_optimisation_trajectories_follow_the_cpu_restatement(monkeypatch):
+    """End to end over many dependent steps: the loops of the reference's sanity scripts (Adam on
+    the alignment loss from random normals, then test-time compute on `dist` through the image —
+    env_sanity_check.py:55-84, fine_adjustment_sanity_check.py:118-146) on the HIP path and on the
+    CPU restatement (tests/oracle_backend.py), same inputs: the loss trajectories stay together."""
+    import torch.nn.functional as F
+    import oracle_backend
+    from doodle_amd.env import HelioEnv
+    N, B, R = 3, 12, 64
+    g = torch.Generator().manual_seed(666)
+    hp = torch.rand(N, 3, generator=g) * 10 + 80
+    hp[:, 2] = 0
+    suns = F.normalize(torch.randn(B, 3, generator=g), dim=1)
+    suns[:, 2] = suns[:, 2].abs()
+    suns = suns * 14142.1356
+    errs1, errsB = torch.randn(N, 2, generator=g) * 2.0, torch.randn(B, N, 2, generator=g) * 2.0
+    raw0 = torch.randn(B, N, 3, generator=g)
+    fine0 = torch.empty(B, N, 3).uniform_(-1e-3, 1e-3, generator=g)
+
+    def run(dev, dmaps=None):
+        env = HelioEnv(hp.to(dev), torch.tensor([0., -5., 0.], device=dev), (15., 15.), torch.tensor([0., 1., 0.], device=dev),
+                       sigma_scale=0.03, error_scale_mrad=2.0, initial_action_noise=0.0, resolution=R, batch_size=B,
+                       device=dev, new_errors_every_reset=False)
+        env.noisy_field.error_angles_mrad, env.noisy_field.batch_error_angles_mrad = errs1.clone(), errsB.clone()
+        env.set_sun_pos(suns.to(dev))
+        if dmaps is not None:                      # set_sun_pos renders noisy initial actions (device RNG)
+            env.distance_maps = dmaps.to(dev)
+        env.reset()
+        raw = raw0.to(dev).clone().requires_grad_(True)
+        opt = torch.optim.Adam([raw], lr=1e-1)
+        traj = []
+        for _ in range(12):                        # pretrain on the alignment loss
+            opt.zero_grad(set_to_none=True)
+            _, m, _ = env.step(F.normalize(raw, dim=2))
+            m["alignment_loss"].backward()
+            opt.step()
+            traj.append(m["alignment_loss"].item())
+        base = F.normalize(raw, dim=2).detach()
+        fine = fine0.to(dev).clone().requires_grad_(True)
+        fopt = torch.optim.Adam([fine], lr=3e-4)
+        for _ in range(10):                        # test-time compute on dist, through the image
+            fopt.zero_grad(set_to_none=True)
+            _, m, _ = env.step(F.normalize(base + fine, dim=2))
+            m["dist"].backward()
+            fopt.step()
+            traj.append(m["dist"].item())
+        return np.array(traj), env.distance_maps.cpu()
+
+    with monkeypatch.context() as mp:
+        oracle_backend.install(mp)
+        want, dmaps = run("cpu")
+    got, _ = run(DEV, dmaps)
+    assert want[11] < 0.5 * want[0]                            # the pretraining converges …
+    np.testing.assert_allclose(got[:12], want[:12], rtol=2e-4)      # … along the same path (acos-conditioned)
+    np.testing.assert_allclose(got[12:], want[12:], rtol=2e-3, atol=1e-6)
