@@ -486,16 +486,127 @@ splat_bwd_few(int B, int N, int R, const float* __restrict__ rays, const float* 
     }
 }
 
+// The same with 16-byte lanes for R % 4 == 0: a wave reads 4 rows × 64 columns per load
+// instruction (lane = row-in-group × 16 + column quad), so the stream runs at the rate of the
+// float4 loss kernels instead of 256-byte row segments.
+template <int NR, bool FUSED>
+__global__ void __launch_bounds__(256)
+splat_bwd_few_vec(int B, int N, int R, const float* __restrict__ rays, const float* __restrict__ xs,
+                  const float* __restrict__ ys, const float* __restrict__ gimg, LossGradArgs L,
+                  float* __restrict__ moments) {
+    __shared__ float sRed[4][NR][5];
+    const int jb = blockIdx.x, b = blockIdx.y, n0 = blockIdx.z * NR;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int sub = lane >> 4, j = jb * 64 + 4 * (lane & 15);           // R % 4 == 0: a quad is in or out as a whole
+    const bool col_ok = j < R;
+    const long base = (long)b * R * R + (col_ok ? j : 0);
+
+    float qa[NR], qk[NR], qc[NR], sj[NR][4], ej[NR][4];
+    float yj[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) yj[c] = ys[min(j + c, R - 1)];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n0 + r < N) q = reinterpret_cast<const float4*>(rays)[(long)b * N + n0 + r];
+        qa[r] = q.x; qk[r] = q.z; qc[r] = q.w;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            sj[r][c] = yj[c] + q.y;
+            ej[r][c] = col_ok ? __builtin_amdgcn_exp2f(-((sj[r][c] * sj[r][c]) * q.z)) : 0.0f;
+        }
+    }
+    float ls = 1.0f, km = 0.0f, kd = 0.0f;
+    if constexpr (FUSED) L.constants(b, B, (long)R * R, ls, km, kd);
+
+    float m0[NR][4], mt[NR][4], mtt[NR][4];
+#pragma unroll
+    for (int r = 0; r < NR; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { m0[r][c] = 0.f; mt[r][c] = 0.f; mtt[r][c] = 0.f; }
+
+    constexpr int U = NR == 4 ? 2 : 4;          // 16-row groups in flight per lane
+    for (int i0 = 4 * wave + sub; i0 < R; i0 += 16 * U) {
+        float4 g[U];
+        float xi[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + 16 * u;
+            const bool ok = col_ok && i < R;
+            const long p = base + (long)min(i, R - 1) * R;
+            xi[u] = xs[min(i, R - 1)];
+            if constexpr (FUSED) {
+                const float4 a = *reinterpret_cast<const float4*>(L.img + p);
+                const float4 t = *reinterpret_cast<const float4*>(L.target + p);
+                const float4 d = *reinterpret_cast<const float4*>(L.dmaps + p);
+                g[u] = make_float4(loss_grad_pixel(a.x, t.x, d.x, ls, km, kd), loss_grad_pixel(a.y, t.y, d.y, ls, km, kd),
+                                   loss_grad_pixel(a.z, t.z, d.z, ls, km, kd), loss_grad_pixel(a.w, t.w, d.w, ls, km, kd));
+            } else {
+                g[u] = *reinterpret_cast<const float4*>(gimg + p);
+            }
+            if (!ok) g[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float gv[4] = {g[u].x, g[u].y, g[u].z, g[u].w};
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const float t = xi[u] + qa[r];
+                const float a = __builtin_amdgcn_exp2f(-(__builtin_fmaf(t, t, qc[r]) * qk[r]));
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float w = a * gv[c];
+                    m0[r][c] += w;
+                    mt[r][c] = __builtin_fmaf(t, w, mt[r][c]);
+                    mtt[r][c] = __builtin_fmaf(t * t, w, mtt[r][c]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        float v[5] = {0.f, 0.f, 0.f, 0.f, 0.f};                      // M0, Mt, Ms, Mtt, Mss
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float e0 = ej[r][c] * m0[r][c];
+            v[0] += e0; v[1] += ej[r][c] * mt[r][c]; v[2] += sj[r][c] * e0; v[3] += ej[r][c] * mtt[r][c];
+            v[4] += (sj[r][c] * sj[r][c]) * e0;
+        }
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) v[k] += __shfl_xor(v[k], d);
+            if (lane == 0) sRed[wave][r][k] = v[k];
+        }
+    }
+    __syncthreads();
+    if (tid < NR * 5) {
+        const int r = tid / 5, k = tid % 5;
+        if (n0 + r < N) {
+            const int JB = (R + 63) / 64;
+            moments[(((long)b * JB + jb) * N + n0 + r) * HELIO_MOMENT_STRIDE + k] =
+                (sRed[0][r][k] + sRed[1][r][k]) + (sRed[2][r][k] + sRed[3][r][k]);
+        }
+    }
+}
+
 template <bool FUSED>
 static void launch_bwd_few(int B, int N, int R, const float* rays, const float* xs, const float* ys,
                            const float* gimg, const LossGradArgs& L, float* moments, hipStream_t st) {
     const int JB = (R + 63) / 64;
-    if (N == 1)
-        hipLaunchKernelGGL((splat_bwd_few<1, FUSED>), dim3(JB, B, N), dim3(256), 0, st, B, N, R, rays, xs, ys, gimg, L, moments);
-    else if (N <= 2)
-        hipLaunchKernelGGL((splat_bwd_few<2, FUSED>), dim3(JB, B, 1), dim3(256), 0, st, B, N, R, rays, xs, ys, gimg, L, moments);
-    else
-        hipLaunchKernelGGL((splat_bwd_few<4, FUSED>), dim3(JB, B, (N + 3) / 4), dim3(256), 0, st, B, N, R, rays, xs, ys, gimg, L, moments);
+    auto a16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    const bool vec = (R & 3) == 0 && (FUSED ? (a16(L.img) && a16(L.target) && a16(L.dmaps)) : a16(gimg));
+#define HELIO_FEW(K, NRV, GZ) hipLaunchKernelGGL((K<NRV, FUSED>), dim3(JB, B, GZ), dim3(256), 0, st, B, N, R, rays, xs, ys, gimg, L, moments)
+    if (vec) {
+        if (N == 1) HELIO_FEW(splat_bwd_few_vec, 1, 1);
+        else if (N == 2) HELIO_FEW(splat_bwd_few_vec, 2, 1);
+        else HELIO_FEW(splat_bwd_few_vec, 4, (N + 3) / 4);
+    } else {
+        if (N == 1) HELIO_FEW(splat_bwd_few, 1, 1);
+        else if (N == 2) HELIO_FEW(splat_bwd_few, 2, 1);
+        else HELIO_FEW(splat_bwd_few, 4, (N + 3) / 4);
+    }
+#undef HELIO_FEW
 }
 
 // where the few-ray kernel wins (tools/sweep_bwd.py, MI355X): its time grows with B·N·R², the
