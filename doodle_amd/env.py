@@ -191,8 +191,9 @@ class HelioEnv(_EnvBase):
         if self.new_errors_every_reset:
             self.noisy_field.reset_errors()
         with torch.no_grad():
-            self.noisy_field.init_actions(self.sun_pos)
-            ideal = self.ref_field.calculate_ideal_normals(self.sun_pos)
+            # the reference recomputes the ideal normals twice here (:386-392); they are the cached ones
+            ideal = self._reference()[0]
+            self.noisy_field._init_actions_from(ideal)
             img, _ = self.noisy_field.render(self.sun_pos, self.noisy_field.initial_action, ideal)
         self.ideal_normals = ideal
         return {"img": img, "aux": torch.cat([self.sun_pos, ideal.flatten(1)], dim=1)}

@@ -178,7 +178,11 @@ class HelioField:
 
     def init_actions(self, sun_position) -> None:
         """Noisy initial mirror orientations (:291-304); always consumes one randn_like."""
-        ideal = self.calculate_ideal_normals(sun_position)
+        self._init_actions_from(self.calculate_ideal_normals(sun_position))
+
+    def _init_actions_from(self, ideal: torch.Tensor) -> None:
+        """``init_actions`` given the ideal normals of the sun position(s) (HelioEnv.reset has them
+        cached: they depend only on geometry the two fields share)."""
         noisy = ideal + torch.randn_like(ideal) * self.initial_action_noise
         if ideal.dim() == 2:
             noisy = noisy / noisy.norm(dim=1, keepdim=True).clamp_min(_TINY)
