@@ -46,6 +46,9 @@ if "--ab" in sys.argv:      # A/B, interleaved: helio_env_step_bwd vs the compos
         del ops.env_step_bwd
         print(f"round {rnd}: one call {one[0]:7.1f} / {one[1]:7.1f} us   composed {two[0]:7.1f} / {two[1]:7.1f} us   (alignment / dist)")
 print(f"env.step forward-only {t_fwd:8.1f} us = {B/t_fwd*1e6:10.0f} frames/s | step+backward(alignment) {t_align:8.1f} us | step+backward(dist) {t_dist:8.1f} us")
+from doodle_amd.graphed import GraphedEnvStep
+gs = GraphedEnvStep(env, like=act.reshape(B, -1, 3), objective="dist")
+print(f"graph replay of step + dist gradient (doodle_amd/graphed.py) {timeit(lambda: gs()):8.1f} us")
 with torch.no_grad():
     print(f"reset() {timeit(lambda: env.reset(), 100):8.1f} us")
 if "--profile" in sys.argv:
