@@ -49,7 +49,7 @@ def test_odd_sizes_against_oracle(N, B, R, normal):
         assert np.array_equal(refl.detach().cpu().numpy(), refl_o.detach().numpy())
         np.testing.assert_allclose(img.detach().cpu().numpy(), img_o.detach().numpy(), rtol=1e-5, atol=1e-8)
     scale = grad_o.abs().max().item()
-    for bwd_variant in (1, 2, 3):
+    for bwd_variant in (1, 2, 3, 4):
         native.get_ops().bwd_variant = bwd_variant
         try:
             (grad,) = torch.autograd.grad((img * G.to(DEV)).sum() + (actual * H.to(DEV)).sum(), a_dev, retain_graph=True)
@@ -929,3 +929,60 @@ def test_optimisation_trajectories_follow_the_cpu_restatement(monkeypatch):
     assert want[11] < 0.5 * want[0]                            # the pretraining converges …
     np.testing.assert_allclose(got[:12], want[:12], rtol=2e-4)      # … along the same path (acos-conditioned)
     np.testing.assert_allclose(got[12:], want[12:], rtol=2e-3, atol=1e-6)
+
+
+def test_random_scenes_against_oracle():
+    """Seeded fuzz over the SCENE rather than the sizes: arbitrary target normals and positions,
+    sigma_scale 0.005…0.2, errors up to 250 mrad, suns down to the horizon, heliostats on every
+    side of the target (so that backward rays and grazing, near-parallel rays occur, which the
+    reference lands or masks, :52-75), wild actions.  Forward bit-exact / 1e-5 and the gradient
+    against the oracle, through whichever kernels the sizes select."""
+    from doodle_amd import HelioField
+    rng = np.random.default_rng(2024)
+    worst_img, worst_grad = 0.0, 0.0
+    for case in range(40):
+        g = torch.Generator().manual_seed(1000 + case)
+        N, B, R = int(rng.integers(1, 40)), int(rng.integers(1, 7)), int(rng.choice([8, 17, 32, 50, 64, 96]))
+        sigma = float(10 ** rng.uniform(np.log10(0.005), np.log10(0.2)))
+        err = float(rng.choice([0.0, 2.0, 40.0, 250.0]))
+        normal = torch.randn(3, generator=g)
+        normal = (normal / normal.norm()).tolist() if case % 4 else [0.0, 1.0, 0.0]
+        tpos = (torch.randn(3, generator=g) * 5).tolist()
+        area = (float(rng.uniform(5, 30)), float(rng.uniform(5, 30)))
+        helios = (torch.rand(N, 3, generator=g) - 0.5) * float(rng.choice([40.0, 200.0]))
+        if case % 3 == 0:
+            helios[:, 2] = 0
+        suns = torch.randn(B, 3, generator=g)
+        suns[:, 2] = suns[:, 2].abs() * (0.02 if case % 5 == 0 else 1.0)       # some at the horizon
+        suns = suns / suns.norm(dim=1, keepdim=True) * 14142.1356
+        errs = torch.randn(max(B, 2), N, 2, generator=g) * err
+        sc = to.Scene.build(helios, tpos, area, normal, R, sigma)
+        ideal = to.ideal_normals(helios, sc.target_position, suns)
+        wild = float(rng.choice([0.0, 0.01, 0.3, 2.0]))
+        act = ideal + wild * torch.randn(ideal.shape, generator=g)
+        act = (act / act.norm(dim=2, keepdim=True)).reshape(B, -1)
+        e_used = errs[:B] if B > 1 else errs[:1]
+        a_cpu = act.clone().requires_grad_(True)
+        img_o, actual_o, refl_o = to.render(sc, suns, a_cpu, e_used, monitor=True)
+        G, H = torch.randn(img_o.shape, generator=g), torch.randn(actual_o.shape, generator=g)
+        (grad_o,) = torch.autograd.grad((img_o * G).sum() + (actual_o * H).sum(), a_cpu)
+        f = HelioField(helios, tpos, area, normal, error_scale_mrad=err, sigma_scale=sigma, resolution=R, device=DEV,
+                       max_batch_size=max(B, 2))
+        f.error_angles_mrad, f.batch_error_angles_mrad = errs[0], errs
+        a_dev = act.to(DEV).requires_grad_(True)
+        img, actual, refl = f.render(suns if B > 1 else suns[0], a_dev if B > 1 else a_dev[0], None, monitor=True)
+        tag = (case, N, B, R, sigma, err, wild)
+        assert np.array_equal(actual.detach().cpu().numpy().reshape(-1), actual_o.detach().numpy().reshape(-1)), tag
+        assert np.array_equal(refl.detach().cpu().numpy().reshape(-1), refl_o.detach().numpy().reshape(-1)), tag
+        got, want = img.detach().cpu().numpy().reshape(B, R, R), img_o.detach().numpy().reshape(B, R, R)
+        assert np.isfinite(got).all(), tag
+        peak = max(float(np.abs(want).max()), 1e-30)
+        worst_img = max(worst_img, float(np.abs(got - want).max()) / peak)
+        np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-5 * peak, err_msg=str(tag))
+        (grad,) = torch.autograd.grad((img.reshape(B, R, R) * G.reshape(B, R, R).to(DEV)).sum()
+                                      + (actual.reshape(B, N, 3) * H.reshape(B, N, 3).to(DEV)).sum(), a_dev)
+        scale = max(grad_o.abs().max().item(), 1e-30)
+        dev = (grad.cpu().reshape(grad_o.shape) - grad_o).abs().max().item() / scale
+        worst_grad = max(worst_grad, dev)
+        assert dev <= 5e-4, (tag, dev)
+    print(f"worst image deviation {worst_img:.2e} of peak, worst gradient deviation {worst_grad:.2e} of max")
