@@ -387,6 +387,16 @@ def test_error_trig_kernel_and_device_sampled_errors():
     x, _ = f.render(suns, act.to(DEV), None)
     y, _ = f.render(suns, act.to(DEV), None)
     assert torch.equal(x, y) and torch.isfinite(x).all()
+    # the all-device path (errors drawn on the device, trig by the HIP kernel) against the oracle
+    # fed the same error angles: the trig tables differ by at most an ulp, `actual` by a few, and
+    # the image by that times the footprint's amplification — small at this sigma
+    f2, sc2, suns2, _, act2 = make_case(N=40, B=6, R=64, sigma=0.05, seed=9)
+    f2.reset_errors()
+    errs_dev = f2.batch_error_angles_mrad
+    img_o, actual_o = to.render(sc2, suns2, act2, errs_dev.cpu()[:6])
+    img_d, actual_d = f2.render(suns2, act2.to(DEV), None)
+    assert (actual_d.cpu() - actual_o).abs().max().item() <= 8 * ulp
+    assert (img_d.cpu() - img_o).abs().max().item() <= 1e-4 * img_o.max().item()
 
 
 def test_render_is_hip_graph_capturable():
