@@ -4,6 +4,8 @@ CPU only.  This is what pins the oracle: torch_oracle must reproduce every
 fixture bit for bit (forward and autograd); the C oracle must reproduce the
 geometry bit for bit and the image within the stated tolerance.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -167,3 +169,24 @@ def test_reference_fp32_noise_floor_against_fp64():
     img64, _ = to.render(sc64, sun, torch.from_numpy(g["action"]), torch.from_numpy(g["batch_error_angles_mrad"]).double())
     err = (torch.from_numpy(g["image"]).double() - img64).abs().max().item() / img64.max().item()
     assert 1e-6 < err < 1e-4, err
+
+
+def test_c_oracle_under_address_and_ub_sanitizers(tmp_path):
+    """sanitizers run on the CPU build only (GPU ASan is not available on the pool).
+    The C oracle, compiled with -fsanitize=address,undefined, runs ragged and degenerate sizes
+    without a report."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        _pytest.skip("no gcc")
+    exe = str(tmp_path / "oracle_san")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    build = subprocess.run(["gcc", "-O1", "-g", "-ffp-contract=off", "-fsanitize=address,undefined",
+                            "-fno-sanitize-recover=all", os.path.join(root, "oracle", "helio_oracle.c"),
+                            os.path.join(root, "tests", "c", "oracle_san.c"), "-lm", "-o", exe],
+                           capture_output=True, text=True)
+    if build.returncode != 0 and "sanitize" in build.stderr:
+        _pytest.skip("sanitizer runtime not installed")
+    assert build.returncode == 0, build.stderr
+    run = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0 and "ORACLE SAN OK" in run.stdout, run.stdout + run.stderr
