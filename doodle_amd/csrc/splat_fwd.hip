@@ -629,6 +629,161 @@ static void launch_tile(int B, int N, int R, const float* rays, const float* xs,
                        B, N, R, rays, xs, ys, image);
 }
 
+
+// ----------------------------------------------------------------------------------------------
+// Split-bf16 variant (opt-in, variant 7): the same rank-N outer-product sum on the bf16 matrix
+// pipe, which on gfx950 runs 16× the f32 MFMA rate.  Every f32 factor is split EXACTLY into three
+// bf16 pieces by truncation (hi = top 8 significant bits, mid = the next 8, lo = the last 8: 24 bits,
+// so A = Ah + Am + Al with no rounding), and a product A·E is issued as the six partial products
+//   Ah·Eh + Ah·Em + Am·Eh + Ah·El + Al·Eh + Am·Em
+// on v_mfma_f32_32x32x16_bf16 (bf16×bf16 is exact in f32; accumulation stays f32).  What is dropped,
+// Am·El + Al·Em + Al·El, is below 2^-23 of the product: an error of the size of one f32 rounding
+// (always towards zero), where the exact-f32 kernels above make none in the product and one in the
+// add.  Six MFMAs of 32 cycles do the work of eight f32 MFMAs of 64: 2.7× fewer matrix-pipe cycles,
+// and — unlike the f32 MFMA — the bf16 MFMA holds the SIMD's vector issue for only 8 of its 32
+// cycles, so the factor evaluation of the NEXT chunk hides under the MFMAs of the current one.
+//
+// Workgroup = 8 waves = one 256×256 tile (2×4 waves of 128×64 pixels, 8 accumulator blocks each);
+// chunk = 16 rays = one k-step; double-buffered LDS tables in MFMA operand order
+// T[piece][k-half][pixel][8 × bf16] (consecutive lanes ↔ consecutive 16-byte slots: conflict-free
+// ds_write_b128 / ds_read_b128); thread p of the workgroup owns pixel p of the tile's 256 rows + 256
+// columns and produces its 16 factors of the next chunk; one barrier per chunk.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ unsigned pack_hi16(float lo_elem, float hi_elem) {
+    // bf16(lo_elem) | bf16(hi_elem) << 16, both by truncation (v_perm_b32)
+    return __builtin_amdgcn_perm(__float_as_uint(hi_elem), __float_as_uint(lo_elem), 0x07060302u);
+}
+
+__global__ void __launch_bounds__(512)
+splat_fwd_mfma_bf16x3(int B, int N, int R, const float* __restrict__ rays, const float* __restrict__ xs,
+                      const float* __restrict__ ys, float* __restrict__ image) {
+    constexpr int KC = 16, T = 256;
+    constexpr int PIECE = 2 * T * 16;                 // bytes of one piece table: [half][pixel][16 B]
+    constexpr int TABLE = 3 * PIECE;                  // A or E, three pieces
+    constexpr int BUF = 2 * TABLE;                    // A then E
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // 2·BUF + ray tables
+    float4* sRay = reinterpret_cast<float4*>(lds + 2 * BUF);              // [2 buffers][KC][row/col]
+
+    const int tiles = (R + T - 1) / T;
+    const int b = blockIdx.y;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int ti0 = (blockIdx.x / tiles) * T, tj0 = (blockIdx.x % tiles) * T;
+    const int wi = (wave >> 2) * 128, wj = (wave & 3) * 64;
+
+    // producer role: pixel p of the tile (rows 0..255, then columns 0..255)
+    const bool isrow = tid < T;
+    const int pp = isrow ? tid : tid - T;
+    const float coord = isrow ? xs[min(ti0 + pp, R - 1)] : ys[min(tj0 + pp, R - 1)];
+    const int ptab = (isrow ? 0 : TABLE) + pp * 16;
+    const int rsel = isrow ? 0 : 1;
+
+    auto stage_rays = [&](int chunk, int buf) {       // 16 threads: pre-scaled parameters of the chunk's rays
+        if (tid < KC) {
+            const int n = chunk * KC + tid;
+            float4 rowp = make_float4(0.f, 0.f, 1e30f, 0.f), colp = make_float4(0.f, 0.f, 0.f, 0.f);   // padding: A = 0
+            if (n < N) {
+                const float4 q = reinterpret_cast<const float4*>(rays)[(long)b * N + n];
+                const float sk = __builtin_sqrtf(q.z);
+                rowp = make_float4(q.x * sk, sk, q.w * q.z, 0.f);
+                colp = make_float4(q.y * sk, sk, 0.f, 0.f);
+            }
+            sRay[(buf * KC + tid) * 2] = rowp;
+            sRay[(buf * KC + tid) * 2 + 1] = colp;
+        }
+    };
+    auto produce = [&](int buf) {                     // this thread's 16 factors of the chunk staged in sRay[buf]
+        unsigned char* base = lds + buf * BUF + ptab;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            float hi[8], mid[8], lo[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float4 r = sRay[(buf * KC + 8 * h + j) * 2 + rsel];     // (shift·sk, sk, cc): a broadcast read
+                const float q = __builtin_fmaf(coord, r.y, r.x);
+                const float f = exp2_fast(-__builtin_fmaf(q, q, r.z));
+                hi[j] = __uint_as_float(__float_as_uint(f) & 0xFFFF0000u);
+                const float r1 = f - hi[j];
+                mid[j] = __uint_as_float(__float_as_uint(r1) & 0xFFFF0000u);
+                lo[j] = r1 - mid[j];
+            }
+            uint4 vh = make_uint4(pack_hi16(hi[0], hi[1]), pack_hi16(hi[2], hi[3]), pack_hi16(hi[4], hi[5]), pack_hi16(hi[6], hi[7]));
+            uint4 vm = make_uint4(pack_hi16(mid[0], mid[1]), pack_hi16(mid[2], mid[3]), pack_hi16(mid[4], mid[5]), pack_hi16(mid[6], mid[7]));
+            uint4 vl = make_uint4(pack_hi16(lo[0], lo[1]), pack_hi16(lo[2], lo[3]), pack_hi16(lo[4], lo[5]), pack_hi16(lo[6], lo[7]));
+            *reinterpret_cast<uint4*>(base + 0 * PIECE + h * T * 16) = vh;
+            *reinterpret_cast<uint4*>(base + 1 * PIECE + h * T * 16) = vm;
+            *reinterpret_cast<uint4*>(base + 2 * PIECE + h * T * 16) = vl;
+        }
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[rb][cb][e] = 0.0f;
+
+    const int chunks = (N + KC - 1) / KC;
+    stage_rays(0, 0);
+    __syncthreads();
+    produce(0);
+    if (chunks > 1) stage_rays(1, 1);
+    // consumer operand addresses: piece P, half lh, pixel (wave offset + 32·block + lr)
+    const int offA = (lh * T + wi + lr) * 16, offE = TABLE + (lh * T + wj + lr) * 16;
+    for (int c = 0; c < chunks; ++c) {
+        __syncthreads();                               // tables[c&1] complete; rays of chunk c+1 staged
+        const int buf = c & 1;
+        if (c + 1 < chunks) produce(buf ^ 1);          // hides under the MFMAs below
+        if (c + 2 < chunks) stage_rays(c + 2, buf);    // sRay[buf] was read by produce() of the previous trip
+        const unsigned char* tb = lds + buf * BUF;
+        bf16x8 eh[2], em[2], el[2];
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            eh[cb] = *reinterpret_cast<const bf16x8*>(tb + offE + 0 * PIECE + cb * 512);
+            em[cb] = *reinterpret_cast<const bf16x8*>(tb + offE + 1 * PIECE + cb * 512);
+            el[cb] = *reinterpret_cast<const bf16x8*>(tb + offE + 2 * PIECE + cb * 512);
+        }
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) {
+            const bf16x8 ah = *reinterpret_cast<const bf16x8*>(tb + offA + 0 * PIECE + rb * 512);
+            const bf16x8 am = *reinterpret_cast<const bf16x8*>(tb + offA + 1 * PIECE + rb * 512);
+            const bf16x8 al = *reinterpret_cast<const bf16x8*>(tb + offA + 2 * PIECE + rb * 512);
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+                f32x16 v = acc[rb][cb];
+                v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, em[cb], v, 0, 0, 0);      // small terms first
+                v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, eh[cb], v, 0, 0, 0);
+                v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, el[cb], v, 0, 0, 0);
+                v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, eh[cb], v, 0, 0, 0);
+                v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, em[cb], v, 0, 0, 0);
+                v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, eh[cb], v, 0, 0, 0);
+                acc[rb][cb] = v;
+            }
+        }
+    }
+    float* img = image + (long)b * R * R;
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+            store_block(img, R, ti0 + wi + 32 * rb, tj0 + wj + 32 * cb, lr, lh, acc[rb][cb]);
+}
+
+static void launch_bf16x3(int B, int N, int R, const float* rays, const float* xs, const float* ys, float* image,
+                          hipStream_t st) {
+    const int t = (R + 255) / 256;
+    const size_t lds = 2 * (2 * 3 * 2 * 256 * 16) + 2 * 16 * 2 * sizeof(float4);
+    static bool configured = false;
+    if (!configured) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(splat_fwd_mfma_bf16x3),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        configured = true;
+    }
+    hipLaunchKernelGGL(splat_fwd_mfma_bf16x3, dim3(t * t, B), dim3(512), lds, st, B, N, R, rays, xs, ys, image);
+}
+
 // variant: 0/2 = MFMA, kernel chosen by problem size; 1 = VALU; 3/4/5/6 force one MFMA kernel
 // (regs 128², tile 128², tile 256², regs 64²) — used by the tests and tools/bench_splat.py.
 // (tile 128² is never the fastest in the sweep; it stays as a forced variant for A/B runs.)
@@ -663,6 +818,7 @@ int launch_splat_fwd(int B, int N, int R, const float* rays, const float* xs, co
     case 4: launch_tile<2, false>(B, N, R, rays, xs, ys, image, st); return HELIO_OK;
     case 5: launch_tile<4, false>(B, N, R, rays, xs, ys, image, st); return HELIO_OK;
     case 6: launch_regs<1, 1, 2, 2, 128, true>(B, N, R, rays, xs, ys, image, st); return HELIO_OK;
+    case 7: launch_bf16x3(B, N, R, rays, xs, ys, image, st); return HELIO_OK;
     default: return HELIO_E_INVALID;
     }
 }
