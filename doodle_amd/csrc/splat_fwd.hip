@@ -643,6 +643,13 @@ static void launch_tile(int B, int N, int R, const float* rays, const float* xs,
 // and — unlike the f32 MFMA — the bf16 MFMA holds the SIMD's vector issue for only 8 of its 32
 // cycles, so the factor evaluation of the NEXT chunk hides under the MFMAs of the current one.
 //
+// Measured at config 4 (N=2000, B=512, R=512): 1.95 ms against 3.96 ms for splat_fwd_mfma_tile<4>;
+// the chip runs this kernel at 2.06 GHz (2.34 under the f32 MFMA), the bf16 pipe is busy 72–75 % of
+// those cycles (PMC), the rest being the barrier and the first operand fetch of every 16-ray trip.
+// Against fp64 (tools/accuracy_splat.py): worst per-pixel relative error 2.5e-6 (exact-f32 MFMA
+// kernel: 1.2e-6), mean -6e-7 — inside the 1e-5 parity bar on every fixture, but no longer the
+// bit-for-bit f32 chain, hence opt-in.
+//
 // Workgroup = 8 waves = one 256×256 tile (2×4 waves of 128×64 pixels, 8 accumulator blocks each);
 // chunk = 16 rays = one k-step; double-buffered LDS tables in MFMA operand order
 // T[piece][k-half][pixel][8 × bf16] (consecutive lanes ↔ consecutive 16-byte slots: conflict-free
@@ -679,12 +686,18 @@ splat_fwd_mfma_bf16x3(int B, int N, int R, const float* __restrict__ rays, const
     const int ptab = (isrow ? 0 : TABLE) + pp * 16;
     const int rsel = isrow ? 0 : 1;
 
-    auto stage_rays = [&](int chunk, int buf) {       // 16 threads: pre-scaled parameters of the chunk's rays
+    // ray parameters of a chunk: fetched from global memory two trips before they are staged (the load
+    // latency never sits between two barriers), pre-scaled and written to LDS by 16 lanes of wave 0
+    auto fetch_rays = [&](int chunk) -> float4 {
+        const int n = min(chunk * KC + (tid & (KC - 1)), N - 1);
+        return reinterpret_cast<const float4*>(rays)[(long)b * N + n];
+    };
+    auto stage_rays = [&](float4 q, int chunk, int buf) {
+        // lanes 0..15 of wave 0 (measured: 1.98 ms; the same on a vector-phase-first wave: 2.09 ms)
         if (tid < KC) {
             const int n = chunk * KC + tid;
             float4 rowp = make_float4(0.f, 0.f, 1e30f, 0.f), colp = make_float4(0.f, 0.f, 0.f, 0.f);   // padding: A = 0
             if (n < N) {
-                const float4 q = reinterpret_cast<const float4*>(rays)[(long)b * N + n];
                 const float sk = __builtin_sqrtf(q.z);
                 rowp = make_float4(q.x * sk, sk, q.w * q.z, 0.f);
                 colp = make_float4(q.y * sk, sk, 0.f, 0.f);
@@ -726,41 +739,61 @@ splat_fwd_mfma_bf16x3(int B, int N, int R, const float* __restrict__ rays, const
             for (int e = 0; e < 16; ++e) acc[rb][cb][e] = 0.0f;
 
     const int chunks = (N + KC - 1) / KC;
-    stage_rays(0, 0);
+    stage_rays(fetch_rays(0), 0, 0);
+    float4 qnext = fetch_rays(1);
     __syncthreads();
     produce(0);
-    if (chunks > 1) stage_rays(1, 1);
+    stage_rays(qnext, 1, 1);                           // (chunks past the end stage padding rays: A = 0)
+    qnext = fetch_rays(2);
     // consumer operand addresses: piece P, half lh, pixel (wave offset + 32·block + lr)
     const int offA = (lh * T + wi + lr) * 16, offE = TABLE + (lh * T + wj + lr) * 16;
     for (int c = 0; c < chunks; ++c) {
         __syncthreads();                               // tables[c&1] complete; rays of chunk c+1 staged
         const int buf = c & 1;
-        if (c + 1 < chunks) produce(buf ^ 1);          // hides under the MFMAs below
-        if (c + 2 < chunks) stage_rays(c + 2, buf);    // sRay[buf] was read by produce() of the previous trip
-        const unsigned char* tb = lds + buf * BUF;
-        bf16x8 eh[2], em[2], el[2];
+        stage_rays(qnext, c + 2, buf);                 // sRay[buf] was read by produce() of the previous trip
+        qnext = fetch_rays(c + 3);
+        // The factors of chunk c+1 (VALU, into the other buffer; the last trip produces an unused
+        // padding chunk) and the 48 MFMAs of chunk c are independent.  The two waves that share a SIMD
+        // (w and w+4) run them in OPPOSITE order: while one wave's MFMAs occupy the matrix pipe the
+        // other wave's factor evaluation issues on the vector ALU (a bf16 MFMA holds the vector issue
+        // for 8 of its 32 cycles), then they swap — the pipe never waits for a producer phase.
+        auto consume = [&]() {
+            const unsigned char* tb = lds + buf * BUF;
+            // all 18 operand fragments first (72 VGPRs), in the order the MFMAs need them: one exposed
+            // LDS latency per trip instead of one per row block
+            bf16x8 ep[3][2], ap[4][3];
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb) {
-            eh[cb] = *reinterpret_cast<const bf16x8*>(tb + offE + 0 * PIECE + cb * 512);
-            em[cb] = *reinterpret_cast<const bf16x8*>(tb + offE + 1 * PIECE + cb * 512);
-            el[cb] = *reinterpret_cast<const bf16x8*>(tb + offE + 2 * PIECE + cb * 512);
-        }
+            for (int P = 0; P < 3; ++P)
 #pragma unroll
-        for (int rb = 0; rb < 4; ++rb) {
-            const bf16x8 ah = *reinterpret_cast<const bf16x8*>(tb + offA + 0 * PIECE + rb * 512);
-            const bf16x8 am = *reinterpret_cast<const bf16x8*>(tb + offA + 1 * PIECE + rb * 512);
-            const bf16x8 al = *reinterpret_cast<const bf16x8*>(tb + offA + 2 * PIECE + rb * 512);
+                for (int cb = 0; cb < 2; ++cb) ep[P][cb] = *reinterpret_cast<const bf16x8*>(tb + offE + P * PIECE + cb * 512);
 #pragma unroll
-            for (int cb = 0; cb < 2; ++cb) {
-                f32x16 v = acc[rb][cb];
-                v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, em[cb], v, 0, 0, 0);      // small terms first
-                v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, eh[cb], v, 0, 0, 0);
-                v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, el[cb], v, 0, 0, 0);
-                v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, eh[cb], v, 0, 0, 0);
-                v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, em[cb], v, 0, 0, 0);
-                v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, eh[cb], v, 0, 0, 0);
-                acc[rb][cb] = v;
+            for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+                for (int P = 0; P < 3; ++P) ap[rb][P] = *reinterpret_cast<const bf16x8*>(tb + offA + P * PIECE + rb * 512);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb) {
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb) {
+                    f32x16 v = acc[rb][cb];
+                    v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[rb][1], ep[1][cb], v, 0, 0, 0);      // small terms first
+                    v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[rb][2], ep[0][cb], v, 0, 0, 0);
+                    v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[rb][0], ep[2][cb], v, 0, 0, 0);
+                    v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[rb][1], ep[0][cb], v, 0, 0, 0);
+                    v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[rb][0], ep[1][cb], v, 0, 0, 0);
+                    v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[rb][0], ep[0][cb], v, 0, 0, 0);
+                    acc[rb][cb] = v;
+                }
             }
+        };
+        if (wave & 4) {          // measured: 1.98 ms; skew by wave&1 / wave&2 / none: 2.29 / 2.24 / 2.26 ms
+            produce(buf ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+            consume();
+        } else {
+            consume();
+            __builtin_amdgcn_sched_barrier(0);
+            produce(buf ^ 1);
         }
     }
     float* img = image + (long)b * R * R;
