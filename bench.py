@@ -433,17 +433,22 @@ def large_leg(dev, seed):
         _, _, rays = ops.geometry_fwd(field.heliostat_positions, suns_d, normals, trig, stride, field._plane)
         exact = ops.splat_fwd(rays, field._xs, field._ys, variant=0)
         split = torch.empty_like(exact)
-        args = (w.B, w.N, w.R, rays.data_ptr(), field._xs.data_ptr(), field._ys.data_ptr(), split.data_ptr(), 7,
-                native._stream())
-        t7 = time_kernel(lambda: ops.lib.helio_splat_fwd(*args), 5)
-        rel = ((split - exact).abs() / exact.clamp_min(1e-6 * exact.max())).max().item()
         r["split_bf16_kernel"] = {
-            "kernel_us": round(t7 * 1e6, 2), "speedup_vs_f32_mfma_kernel": round(r["kernel_us"] / (t7 * 1e6), 3),
-            "f32_equivalent_TFLOPs": round(r["algorithmic_flops"] / t7 / 1e12, 1),
-            "bf16_mfma_TFLOPs_issued": round(6 * r["algorithmic_flops"] / t7 / 1e12, 1),
-            "max_rel_deviation_from_f32_kernel": float(f"{rel:.3e}"),
-            "note": "opt-in (variant 7): exact 3-way bf16 split of every f32 factor, 6 of the 9 partial products on "
-                    "v_mfma_f32_32x32x16_bf16, f32 accumulation; dropped terms < 2^-23 of each product"}
+            "note": "opt-in: exact 3-way bf16 split of every f32 factor, 6 of the 9 partial products on "
+                    "v_mfma_f32_32x32x16_bf16, f32 accumulation; dropped terms < 2^-23 of each product.  Variant 7 "
+                    "sums in two levels (more accurate against fp64 than the exact-f32 kernel's one-level chain: "
+                    "tools/accuracy_splat.py), variant 8 in one"}
+        for v, name in ((7, "two_level"), (8, "one_level")):
+            args = (w.B, w.N, w.R, rays.data_ptr(), field._xs.data_ptr(), field._ys.data_ptr(), split.data_ptr(), v,
+                    native._stream())
+            t7 = time_kernel(lambda: ops.lib.helio_splat_fwd(*args), 5)
+            rel = ((split - exact).abs() / exact.clamp_min(1e-6 * exact.max())).max().item()
+            r["split_bf16_kernel"][name] = {
+                "variant": v, "kernel_us": round(t7 * 1e6, 2),
+                "speedup_vs_f32_mfma_kernel": round(r["kernel_us"] / (t7 * 1e6), 3),
+                "f32_equivalent_TFLOPs": round(r["algorithmic_flops"] / t7 / 1e12, 1),
+                "bf16_mfma_TFLOPs_issued": round(6 * r["algorithmic_flops"] / t7 / 1e12, 1),
+                "max_rel_deviation_from_f32_kernel": float(f"{rel:.3e}")}
     except Exception as e:  # noqa: BLE001
         r["split_bf16_kernel"] = {"error": repr(e)}
     r["workload"] = w.name + f", span={w.span} m, sigma_scale={w.sigma_scale}"

@@ -643,12 +643,14 @@ static void launch_tile(int B, int N, int R, const float* rays, const float* xs,
 // and — unlike the f32 MFMA — the bf16 MFMA holds the SIMD's vector issue for only 8 of its 32
 // cycles, so the factor evaluation of the NEXT chunk hides under the MFMAs of the current one.
 //
-// Measured at config 4 (N=2000, B=512, R=512): 1.95 ms against 3.96 ms for splat_fwd_mfma_tile<4>;
-// the chip runs this kernel at 2.06 GHz (2.34 under the f32 MFMA), the bf16 pipe is busy 72–75 % of
-// those cycles (PMC), the rest being the barrier and the first operand fetch of every 16-ray trip.
-// Against fp64 (tools/accuracy_splat.py): worst per-pixel relative error 2.5e-6 (exact-f32 MFMA
-// kernel: 1.2e-6), mean -6e-7 — inside the 1e-5 parity bar on every fixture, but no longer the
-// bit-for-bit f32 chain, hence opt-in.
+// Measured at config 4 (N=2000, B=512, R=512), against 3.96 ms for splat_fwd_mfma_tile<4>:
+//   variant 7 (two-level sums, below): 2.39 ms; against fp64 (tools/accuracy_splat.py) worst per-pixel
+//     relative error 8.6e-7, rms 1.6e-7 — tighter than tile<4>'s one-level f32 chain (1.2e-6 / 2.1e-7);
+//   variant 8 (one level): 1.95 ms; worst pixel 2.5e-6, mean -6e-7 (the pipe's truncation, see below).
+// The chip runs these kernels at 2.06 GHz (2.34 under the f32 MFMA); in variant 8 the bf16 pipe is
+// busy 72–75 % of those cycles (PMC), the rest being the barrier and the first operand fetch of every
+// 16-ray trip.  Both pass every parity fixture at 1e-5; neither is the literal f32 fmaf chain of the
+// other kernels, hence opt-in.
 //
 // Workgroup = 8 waves = one 256×256 tile (2×4 waves of 128×64 pixels, 8 accumulator blocks each);
 // chunk = 16 rays = one k-step; double-buffered LDS tables in MFMA operand order
@@ -662,6 +664,7 @@ __device__ __forceinline__ unsigned pack_hi16(float lo_elem, float hi_elem) {
     return __builtin_amdgcn_perm(__float_as_uint(hi_elem), __float_as_uint(lo_elem), 0x07060302u);
 }
 
+template <bool TWO_LEVEL>
 __global__ void __launch_bounds__(512)
 splat_fwd_mfma_bf16x3(int B, int N, int R, const float* __restrict__ rays, const float* __restrict__ xs,
                       const float* __restrict__ ys, float* __restrict__ image) {
@@ -759,31 +762,74 @@ splat_fwd_mfma_bf16x3(int B, int N, int R, const float* __restrict__ rays, const
         // for 8 of its 32 cycles), then they swap — the pipe never waits for a producer phase.
         auto consume = [&]() {
             const unsigned char* tb = lds + buf * BUF;
-            // all 18 operand fragments first (72 VGPRs), in the order the MFMAs need them: one exposed
-            // LDS latency per trip instead of one per row block
-            bf16x8 ep[3][2], ap[4][3];
+            if constexpr (!TWO_LEVEL) {
+                // all 18 operand fragments first (72 VGPRs), in the order the MFMAs need them
+                bf16x8 ep[3][2], ap[4][3];
 #pragma unroll
-            for (int P = 0; P < 3; ++P)
+                for (int P = 0; P < 3; ++P)
 #pragma unroll
-                for (int cb = 0; cb < 2; ++cb) ep[P][cb] = *reinterpret_cast<const bf16x8*>(tb + offE + P * PIECE + cb * 512);
+                    for (int cb = 0; cb < 2; ++cb) ep[P][cb] = *reinterpret_cast<const bf16x8*>(tb + offE + P * PIECE + cb * 512);
 #pragma unroll
-            for (int rb = 0; rb < 4; ++rb)
+                for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
-                for (int P = 0; P < 3; ++P) ap[rb][P] = *reinterpret_cast<const bf16x8*>(tb + offA + P * PIECE + rb * 512);
-            __builtin_amdgcn_sched_barrier(0);
+                    for (int P = 0; P < 3; ++P) ap[rb][P] = *reinterpret_cast<const bf16x8*>(tb + offA + P * PIECE + rb * 512);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int rb = 0; rb < 4; ++rb) {
+                for (int rb = 0; rb < 4; ++rb) {
 #pragma unroll
-                for (int cb = 0; cb < 2; ++cb) {
-                    f32x16 v = acc[rb][cb];
-                    v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[rb][1], ep[1][cb], v, 0, 0, 0);      // small terms first
-                    v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[rb][2], ep[0][cb], v, 0, 0, 0);
-                    v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[rb][0], ep[2][cb], v, 0, 0, 0);
-                    v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[rb][1], ep[0][cb], v, 0, 0, 0);
-                    v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[rb][0], ep[1][cb], v, 0, 0, 0);
-                    v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[rb][0], ep[0][cb], v, 0, 0, 0);
-                    acc[rb][cb] = v;
+                    for (int cb = 0; cb < 2; ++cb) {
+                        f32x16 v = acc[rb][cb];
+                        v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[rb][1], ep[1][cb], v, 0, 0, 0);      // small terms first
+                        v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[rb][2], ep[0][cb], v, 0, 0, 0);
+                        v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[rb][0], ep[2][cb], v, 0, 0, 0);
+                        v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[rb][1], ep[0][cb], v, 0, 0, 0);
+                        v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[rb][0], ep[1][cb], v, 0, 0, 0);
+                        v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[rb][0], ep[0][cb], v, 0, 0, 0);
+                        acc[rb][cb] = v;
+                    }
                 }
+            } else {
+                // Two-level sums.  The bf16 pipe aligns the 16 products of an instruction against the
+                // accumulator's exponent and truncates: against the running total of N = 2000 rays that is
+                // a bias of -6e-7 (worst pixel 2.5e-6); against a ZERO accumulator holding one 16-ray
+                // partial sum it is ~1/125 of that.  So the six partial products of a block go into a
+                // fresh accumulator and the partial sum is added to the running total on the vector ALU,
+                // round-to-nearest — under the MFMAs of the next row block.  Measured against fp64: worst
+                // pixel 8.6e-7, rms 1.6e-7 — tighter than the one-level f32 chain of splat_fwd_mfma_tile<4>
+                // (1.2e-6 / 2.1e-7); the adds cost vector issue slots: 2.39 ms instead of 1.95.
+                bf16x8 ep[3][2];
+#pragma unroll
+                for (int P = 0; P < 3; ++P)
+#pragma unroll
+                    for (int cb = 0; cb < 2; ++cb) ep[P][cb] = *reinterpret_cast<const bf16x8*>(tb + offE + P * PIECE + cb * 512);
+                const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                f32x16 part[2][2];
+#pragma unroll
+                for (int rb = 0; rb < 4; ++rb) {
+                    bf16x8 ap[3];
+#pragma unroll
+                    for (int P = 0; P < 3; ++P) ap[P] = *reinterpret_cast<const bf16x8*>(tb + offA + P * PIECE + rb * 512);
+#pragma unroll
+                    for (int cb = 0; cb < 2; ++cb) {
+                        f32x16 v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[1], ep[1][cb], zero, 0, 0, 0);      // small terms first
+                        v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[2], ep[0][cb], v, 0, 0, 0);
+                        v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0], ep[2][cb], v, 0, 0, 0);
+                        v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[1], ep[0][cb], v, 0, 0, 0);
+                        v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0], ep[1][cb], v, 0, 0, 0);
+                        part[rb & 1][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0], ep[0][cb], v, 0, 0, 0);
+                    }
+                    if (rb > 0) {
+                        acc[rb - 1][0] += part[(rb - 1) & 1][0];
+                        acc[rb - 1][1] += part[(rb - 1) & 1][1];
+                        // the adds stay HERE: left alone they are sunk into the next trip and eight partial
+                        // sums stay live (256 VGPRs + spills)
+                        asm volatile("" : "+v"(acc[rb - 1][0]), "+v"(acc[rb - 1][1]));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                acc[3][0] += part[1][0];
+                acc[3][1] += part[1][1];
+                asm volatile("" : "+v"(acc[3][0]), "+v"(acc[3][1]));
             }
         };
         if (wave & 4) {          // measured: 1.98 ms; skew by wave&1 / wave&2 / none: 2.29 / 2.24 / 2.26 ms
@@ -804,17 +850,18 @@ splat_fwd_mfma_bf16x3(int B, int N, int R, const float* __restrict__ rays, const
             store_block(img, R, ti0 + wi + 32 * rb, tj0 + wj + 32 * cb, lr, lh, acc[rb][cb]);
 }
 
+template <bool TWO_LEVEL>
 static void launch_bf16x3(int B, int N, int R, const float* rays, const float* xs, const float* ys, float* image,
                           hipStream_t st) {
     const int t = (R + 255) / 256;
     const size_t lds = 2 * (2 * 3 * 2 * 256 * 16) + 2 * 16 * 2 * sizeof(float4);
     static bool configured = false;
     if (!configured) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(splat_fwd_mfma_bf16x3),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(splat_fwd_mfma_bf16x3<TWO_LEVEL>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         configured = true;
     }
-    hipLaunchKernelGGL(splat_fwd_mfma_bf16x3, dim3(t * t, B), dim3(512), lds, st, B, N, R, rays, xs, ys, image);
+    hipLaunchKernelGGL(splat_fwd_mfma_bf16x3<TWO_LEVEL>, dim3(t * t, B), dim3(512), lds, st, B, N, R, rays, xs, ys, image);
 }
 
 // variant: 0/2 = MFMA, kernel chosen by problem size; 1 = VALU; 3/4/5/6 force one MFMA kernel
@@ -851,7 +898,8 @@ int launch_splat_fwd(int B, int N, int R, const float* rays, const float* xs, co
     case 4: launch_tile<2, false>(B, N, R, rays, xs, ys, image, st); return HELIO_OK;
     case 5: launch_tile<4, false>(B, N, R, rays, xs, ys, image, st); return HELIO_OK;
     case 6: launch_regs<1, 1, 2, 2, 128, true>(B, N, R, rays, xs, ys, image, st); return HELIO_OK;
-    case 7: launch_bf16x3(B, N, R, rays, xs, ys, image, st); return HELIO_OK;
+    case 7: launch_bf16x3<true>(B, N, R, rays, xs, ys, image, st); return HELIO_OK;
+    case 8: launch_bf16x3<false>(B, N, R, rays, xs, ys, image, st); return HELIO_OK;
     default: return HELIO_E_INVALID;
     }
 }

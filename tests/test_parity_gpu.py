@@ -36,7 +36,7 @@ def assert_image_close(img, ref):
     assert np.abs(img - ref).max() <= 1e-5 * max(np.abs(ref).max(), 1e-30)
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8])
 @pytest.mark.parametrize("name", NAMES)
 def test_forward_matches_reference(name, variant, monkeypatch):
     from doodle_amd import native
