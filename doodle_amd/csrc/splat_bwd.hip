@@ -399,6 +399,218 @@ static void launch_bwd_mfma(int B, int N, int R, const float* rays, const float*
     hipLaunchKernelGGL(splat_bwd_mfma<PASS>, dim3(ct * nt, B), dim3(1024), lds, st, B, N, R, rays, xs, ys, gimg, moments);
 }
 
+// ----------------------------------------------------------------------------------------------
+// Split-bf16 backward (opt-in, variant 5): the two contractions above on the bf16 matrix pipe, with
+// the scheme of splat_fwd_mfma_bf16x3 (splat_fwd.hip): both operands — the grad-image values and
+// the factors — are split exactly into three bf16 pieces and a product is issued as six of its
+// nine partial products on v_mfma_f32_32x32x16_bf16, f32 accumulation; what is dropped is below
+// 2^-23 of each product.  Workgroup = 8 waves = 256 c × 256 rays (2×4 waves of 128×64); trip = 16
+// of the contracted axis; waves 0-3 stage the grad-image slab (thread ↔ c, 16 k of the trip,
+// prefetched a trip ahead), waves 4-7 the factor table (thread ↔ ray); the two waves of a SIMD
+// (w, w+4) run "MFMAs of this trip" and "operands of the next" in opposite order.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ unsigned pack_hi16(float lo_elem, float hi_elem) {
+    return __builtin_amdgcn_perm(__float_as_uint(hi_elem), __float_as_uint(lo_elem), 0x07060302u);
+}
+
+// v[0..7] (f32) → three uint4 of bf16 pieces (hi, mid, lo), exact
+__device__ __forceinline__ void split3(const float* v, uint4& h, uint4& m, uint4& l) {
+    float hi[8], mid[8], lo[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        hi[j] = __uint_as_float(__float_as_uint(v[j]) & 0xFFFF0000u);
+        const float r1 = v[j] - hi[j];
+        mid[j] = __uint_as_float(__float_as_uint(r1) & 0xFFFF0000u);
+        lo[j] = r1 - mid[j];
+    }
+    h = make_uint4(pack_hi16(hi[0], hi[1]), pack_hi16(hi[2], hi[3]), pack_hi16(hi[4], hi[5]), pack_hi16(hi[6], hi[7]));
+    m = make_uint4(pack_hi16(mid[0], mid[1]), pack_hi16(mid[2], mid[3]), pack_hi16(mid[4], mid[5]), pack_hi16(mid[6], mid[7]));
+    l = make_uint4(pack_hi16(lo[0], lo[1]), pack_hi16(lo[2], lo[3]), pack_hi16(lo[4], lo[5]), pack_hi16(lo[6], lo[7]));
+}
+
+template <int PASS>
+__global__ void __launch_bounds__(512)
+splat_bwd_mfma_bf16x3(int B, int N, int R, const float* __restrict__ rays, const float* __restrict__ xs,
+                      const float* __restrict__ ys, const float* __restrict__ gimg, float* __restrict__ moments) {
+    constexpr int KC = 16, T = 256;
+    constexpr int PIECE = 2 * T * 16;                 // bytes: [k-half][c or ray][8 × bf16]
+    constexpr int TABLE = 3 * PIECE, BUF = 2 * TABLE; // grad-image table, then factor table
+    extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
+    float* sCc = reinterpret_cast<float*>(ldsb + 2 * BUF);
+
+    const int c_tiles = (R + T - 1) / T;
+    const int b = blockIdx.y;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int c0 = (blockIdx.x % c_tiles) * T, n0 = (blockIdx.x / c_tiles) * T;
+    const int wi = (wave >> 2) * 128, wj = (wave & 3) * 64;
+    const float* __restrict__ ccoord = PASS == 0 ? ys : xs;   // coordinates along c
+    const float* __restrict__ kcoord = PASS == 0 ? xs : ys;   // coordinates along k
+    const float* __restrict__ G = gimg + (long)b * R * R;
+
+    if (tid < T) sCc[tid] = ccoord[min(c0 + tid, R - 1)];
+
+    const bool grole = tid < T;                      // waves 0-3: grad-image slab; waves 4-7: factor table
+    const int pp = grole ? tid : tid - T;            // c of the tile, or ray of the tile
+    float4 q = make_float4(0.f, 0.f, 1.f, 1e30f);
+    if (!grole && n0 + pp < N) q = reinterpret_cast<const float4*>(rays)[(long)b * N + n0 + pp];
+    const float sk = __builtin_sqrtf(q.z);
+    const float fshift = (PASS == 0 ? q.x : q.y) * sk;
+    const float fcc = PASS == 0 ? q.w * q.z : ((!grole && n0 + pp < N) ? 0.0f : 1e30f);
+    const int ptab = (grole ? 0 : TABLE) + pp * 16;
+    const bool vec_ok = (R & 3) == 0;
+
+    float gv[16];
+    auto load_slab = [&](int k0) {                   // Gm[k][c], 16 k of the trip, for this thread's c
+        if (PASS == 0) {                             // Gm[k][c] = G[k0+k][c0+c]: lanes ↔ c, coalesced rows
+            const int col = c0 + pp;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) gv[j] = (k0 + j < R && col < R) ? G[(long)(k0 + j) * R + col] : 0.0f;
+        } else {                                     // Gm[k][c] = G[c0+c][k0+k]: 64 contiguous bytes per lane
+            const int row = c0 + pp;
+            if (vec_ok && row < R && k0 + 15 < R) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const float4 t = *reinterpret_cast<const float4*>(G + (long)row * R + k0 + 4 * v);
+                    gv[4 * v] = t.x; gv[4 * v + 1] = t.y; gv[4 * v + 2] = t.z; gv[4 * v + 3] = t.w;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) gv[j] = (row < R && k0 + j < R) ? G[(long)row * R + k0 + j] : 0.0f;
+            }
+        }
+    };
+    auto produce = [&](int k0, int buf) {            // this thread's 16 operand values of the trip at k0
+        unsigned char* base = ldsb + buf * BUF + ptab;
+        float v[16];
+        if (grole) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = gv[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const float t = __builtin_fmaf(kcoord[min(k0 + j, R - 1)], sk, fshift);      // wave-uniform coordinate
+                v[j] = (k0 + j < R) ? __builtin_amdgcn_exp2f(-__builtin_fmaf(t, t, fcc)) : 0.0f;
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            uint4 ph, pm, pl;
+            split3(v + 8 * h, ph, pm, pl);
+            *reinterpret_cast<uint4*>(base + 0 * PIECE + h * T * 16) = ph;
+            *reinterpret_cast<uint4*>(base + 1 * PIECE + h * T * 16) = pm;
+            *reinterpret_cast<uint4*>(base + 2 * PIECE + h * T * 16) = pl;
+        }
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[cb][nb][e] = 0.0f;
+
+    const int trips = (R + KC - 1) / KC;
+    if (grole) load_slab(0);
+    produce(0, 0);
+    if (grole) load_slab(KC);                        // (past the image: zeros)
+    const int offG = (lh * T + wi + lr) * 16, offF = TABLE + (lh * T + wj + lr) * 16;
+    for (int t = 0; t < trips; ++t) {
+        __syncthreads();                             // tables[t&1] complete
+        const int buf = t & 1;
+        auto consume = [&]() {
+            const unsigned char* tb = ldsb + buf * BUF;
+            bf16x8 fp[3][2];
+#pragma unroll
+            for (int P = 0; P < 3; ++P)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) fp[P][nb] = *reinterpret_cast<const bf16x8*>(tb + offF + P * PIECE + nb * 512);
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) {
+                bf16x8 gp[3];
+#pragma unroll
+                for (int P = 0; P < 3; ++P) gp[P] = *reinterpret_cast<const bf16x8*>(tb + offG + P * PIECE + cb * 512);
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) {
+                    f32x16 v = acc[cb][nb];
+                    v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gp[1], fp[1][nb], v, 0, 0, 0);      // small terms first
+                    v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gp[2], fp[0][nb], v, 0, 0, 0);
+                    v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gp[0], fp[2][nb], v, 0, 0, 0);
+                    v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gp[1], fp[0][nb], v, 0, 0, 0);
+                    v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gp[0], fp[1][nb], v, 0, 0, 0);
+                    v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gp[0], fp[0][nb], v, 0, 0, 0);
+                    acc[cb][nb] = v;
+                }
+            }
+        };
+        auto next = [&]() {                          // operands of trip t+1 (the last trip stages zeros)
+            produce((t + 1) * KC, buf ^ 1);
+            if (grole) load_slab((t + 2) * KC);
+        };
+        if (wave & 4) {
+            next();
+            __builtin_amdgcn_sched_barrier(0);
+            consume();
+        } else {
+            consume();
+            __builtin_amdgcn_sched_barrier(0);
+            next();
+        }
+    }
+
+    // epilogue: this lane's ray is column lr of ray block nb; the 16 registers of an accumulator
+    // block are c = (e&3) + 8(e>>2) + 4·lh of c block cb; a wave covers two 64-wide partial blocks
+    const int JB = (R + 63) / 64;
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+        const int n = n0 + wj + 32 * nb + lr;
+        float4 h = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n < N) h = reinterpret_cast<const float4*>(rays)[(long)b * N + n];
+        const float hshift = PASS == 0 ? h.y : h.x;
+        const float hcc = PASS == 0 ? 0.0f : h.w;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            float m0 = 0.f, m1 = 0.f, m2 = 0.f;
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc) {
+                const int cb = 2 * half + cc;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int cl = wi + 32 * cb + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                    const float s = sCc[cl] + hshift;
+                    const float w = __builtin_amdgcn_exp2f(-(__builtin_fmaf(s, s, hcc) * h.z)) * acc[cb][nb][e];
+                    m0 += w;
+                    m1 = __builtin_fmaf(s, w, m1);
+                    m2 = __builtin_fmaf(s * s, w, m2);
+                }
+            }
+            m0 += __shfl_xor(m0, 32); m1 += __shfl_xor(m1, 32); m2 += __shfl_xor(m2, 32);
+            const int cstart = c0 + wi + 64 * half;
+            if (lh == 0 && n < N && cstart < R) {
+                float* o = moments + (((long)b * JB + cstart / 64) * N + n) * HELIO_MOMENT_STRIDE;
+                if (PASS == 0) { o[0] = m0; o[2] = m1; o[4] = m2; }
+                else { o[1] = m1; o[3] = m2; }
+            }
+        }
+    }
+}
+
+template <int PASS>
+static void launch_bwd_bf16x3(int B, int N, int R, const float* rays, const float* xs, const float* ys,
+                              const float* gimg, float* moments, hipStream_t st) {
+    const size_t lds = 2 * (2 * 3 * 2 * 256 * 16) + 256 * sizeof(float);
+    static bool configured = false;
+    if (!configured) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(splat_bwd_mfma_bf16x3<PASS>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        configured = true;
+    }
+    const int ct = (R + 255) / 256, nt = (N + 255) / 256;
+    hipLaunchKernelGGL(splat_bwd_mfma_bf16x3<PASS>, dim3(ct * nt, B), dim3(512), lds, st, B, N, R, rays, xs, ys, gimg, moments);
+}
+
 // Few rays per image (the reference's test-time-compute sweeps run ONE heliostat and 500 suns,
 // run_experiments.py:31-56): the 64-ray tiles of the kernels above would be ≥ 90 % padding and the
 // pass is bound by streaming grad_image once.  A workgroup owns 64 image columns of one sun
@@ -629,7 +841,7 @@ void launch_splat_bwd_fused_loss_raw(int B, int N, int R, const float* rays, con
 int splat_bwd_blocks(int R) { return (R + BW_JT - 1) / BW_JT; }
 
 // variant: 0 = by problem size, 1 = VALU kernel, 2 = MFMA kernels (256-tiles), 3 = MFMA small tiles,
-// 4 = few-ray streaming kernel
+// 4 = few-ray streaming kernel, 5 = split-bf16 MFMA kernels (opt-in)
 int launch_splat_bwd(int B, int N, int R, const float* rays, const float* xs, const float* ys,
                      const float* gimg, float* moments, int variant, hipStream_t st) {
     if (variant == 0) {
@@ -637,6 +849,11 @@ int launch_splat_bwd(int B, int N, int R, const float* rays, const float* xs, co
         // tools/sweep_bwd.py: the 256-wide tiles pay off only when the image is wider than 128
         // pixels (at R = 128 half of every tile is padding) and there are enough of them
         variant = splat_bwd_is_few(B, N) ? 4 : (R > 128 && N >= 96 && wgs >= 128) ? 2 : 3;
+    }
+    if (variant == 5) {
+        launch_bwd_bf16x3<0>(B, N, R, rays, xs, ys, gimg, moments, st);
+        launch_bwd_bf16x3<1>(B, N, R, rays, xs, ys, gimg, moments, st);
+        return HELIO_OK;
     }
     if (variant == 4) {
         if ((N + 3) / 4 > 65535) return HELIO_E_INVALID;          // grid.z; never chosen for that many rays

@@ -143,7 +143,9 @@ int helio_splat_bwd_blocks(int R);
  * only the sum over blocks is meaningful.
  * variant: 0 = by problem size, 1 = VALU kernel, 2 = f32 MFMA kernels (256-wide tiles, two
  * launches), 3 = f32 MFMA small-tile kernel (both passes in one launch), 4 = streaming VALU kernel
- * for a handful of rays per image (bound by reading grad_image once).
+ * for a handful of rays per image (bound by reading grad_image once), 5 = the split-bf16 MFMA
+ * kernels (opt-in, never chosen by 0: grad-image values and factors split exactly into three
+ * bf16 pieces, six partial products per product on the bf16 matrix pipe, f32 accumulation).
  */
 int helio_splat_bwd(int B, int N, int R,
                     const float *rays_d, const float *xs_d, const float *ys_d,

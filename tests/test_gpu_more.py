@@ -49,7 +49,7 @@ def test_odd_sizes_against_oracle(N, B, R, normal):
         assert np.array_equal(refl.detach().cpu().numpy(), refl_o.detach().numpy())
         np.testing.assert_allclose(img.detach().cpu().numpy(), img_o.detach().numpy(), rtol=1e-5, atol=1e-8)
     scale = grad_o.abs().max().item()
-    for bwd_variant in (1, 2, 3, 4):
+    for bwd_variant in (1, 2, 3, 4, 5):
         native.get_ops().bwd_variant = bwd_variant
         try:
             (grad,) = torch.autograd.grad((img * G.to(DEV)).sum() + (actual * H.to(DEV)).sum(), a_dev, retain_graph=True)
@@ -552,7 +552,7 @@ def test_kernel_variants_agree_on_random_shapes():
         G = torch.randn(B, R, R, device=DEV, generator=g)
         m1 = ops.splat_bwd(rays, xs, ys, G, variant=1).sum(1)
         scale = m1.abs().amax(dim=(0, 1)).clamp_min(1e-20)
-        for v in (2, 3, 4, 0):
+        for v in (2, 3, 4, 5, 0):
             mv = ops.splat_bwd(rays, xs, ys, G, variant=v).sum(1)
             assert ((mv - m1).abs().amax(dim=(0, 1)) / scale).max().item() <= 2e-5, (B, N, R, v)
 

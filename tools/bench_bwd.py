@@ -35,6 +35,12 @@ def main():
     t_s3 = time_kernel(lambda: ops.splat_bwd(rays, f._xs, f._ys, G, variant=3), iters)
     m3 = ops.splat_bwd(rays, f._xs, f._ys, G, variant=3).sum(1)
     print(f"   splat_bwd mfma-small {t_s3*1e6:9.1f} us; vs valu max|d|/max =", max((m1[..., k] - m3[..., k]).abs().max().item() / m1[..., k].abs().max().item() for k in range(5)))
+    if w.R >= 128:
+        t_s5 = time_kernel(lambda: ops.splat_bwd(rays, f._xs, f._ys, G, variant=5), iters)
+        m5 = ops.splat_bwd(rays, f._xs, f._ys, G, variant=5).sum(1)
+        print(f"   splat_bwd split-bf16 (opt-in, variant 5) {t_s5*1e6:9.1f} us ({2*2.0*B*w.N*w.R*w.R/t_s5/1e12:6.1f} TF f32-equivalent); "
+              f"vs valu max|d|/max =", max((m1[..., k] - m5[..., k]).abs().max().item() / m1[..., k].abs().max().item() for k in range(5)),
+              "| mfma vs valu:", max((m1[..., k] - m2[..., k]).abs().max().item() / m1[..., k].abs().max().item() for k in range(5)))
     mom = ops.splat_bwd(rays, f._xs, f._ys, G)
     t_gb = time_kernel(lambda: ops.geometry_bwd(f.heliostat_positions, suns_d, normals, trig, stride, f._plane, mom, H, None), iters)
     fl = 2.0 * B * w.N * w.R * w.R
