@@ -6,8 +6,14 @@
 A "step" is one ``HelioField.render`` forward over one batch of B synthetic sun
 positions (B frames), inputs resident in HBM.  With N>1 (launched by
 ``torch.distributed.run``, one rank per GPU) every rank renders its own B-row shard of
-a global batch of N·B suns and the ranks all-gather the images over RCCL (weak scaling);
-there is no other collective on the path.  Rank 0 prints ONE JSON line.
+a global batch of N·B suns (weak scaling).  The suns are independent, so the timed loop has
+no data-path collective: the images stay on the rank that rendered them, which is how a
+data-parallel training job consumes them.  The path's one collective — the RCCL all-gather
+of image shards, for a single consumer that wants the whole batch — is timed right after, on
+the same shards, and reported beside `value` as `with_all_gather_every_step` (at config 2 it
+is interconnect-bound by construction: DESIGN.md §5); `--gather-every-step` makes it the
+timed loop instead.  The config-5 shard leg always renders AND gathers (the configuration
+BASELINE names with the all-gather).  Rank 0 prints ONE JSON line.
 
 Extra objects in the line:
   roofline        the dominant kernel of the run by GPU time: the splat forward at BASELINE
@@ -156,6 +162,9 @@ def main():
                     help="run the all-gather on a side stream (pays for steps of milliseconds — the config-5 "
                          "shard leg uses it; at config 2 the cross-stream events cost more than they hide: "
                          "35 vs 14 µs per step measured with one rank)")
+    ap.add_argument("--gather-every-step", action="store_true",
+                    help="all-gather the images inside the timed loop (default: images stay on their rank; the "
+                         "gathered loop is timed afterwards and reported as with_all_gather_every_step)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed and all-gather even with one rank (testing)")
     args = ap.parse_args()
@@ -203,11 +212,12 @@ def main():
         else:
             img, actual = field.render(suns_d, action, None)
             torch.autograd.grad((img * G).sum() + actual.sum(), action)
-        if gather is not None:
+        if gather is not None and gather_now[0]:
             # stream-ordered behind the render by default; --overlap puts it on a side stream
             gather.gather(img.detach(), gathered[stepno[0] & 1], overlap=args.overlap)
             stepno[0] += 1
 
+    gather_now = [bool(args.gather_every_step)]
     for _ in range(args.warmup):
         step()
 
@@ -229,25 +239,23 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
 
-    # beyond one GPU the config-2 step is bound by delivering 7 x 1.64 MB to every rank (DESIGN.md
-    # §5); the same loop without the all-gather separates the renderers' scaling from the
-    # interconnect's (reported beside `value`, never instead of it)
-    el_local = None
+    # the same shards with the other treatment of the images (gathered every step / left on their
+    # rank): at config 2 the gathered loop is bound by delivering (N-1) x 1.64 MB to every rank per
+    # step, DESIGN.md §5 — reported beside `value`, never instead of it
+    el_other = None
     if gather is not None and (world > 1 or args.force_dist):
-        saved, gather = gather, None
+        gather_now[0] = not gather_now[0]
         for _ in range(min(args.warmup, 50)):
             step()
-        dist.barrier()
-        torch.cuda.synchronize()
+        fence()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
-        dist.barrier()
-        torch.cuda.synchronize()
+        fence()
         t = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el_local = float(t.item())
-        gather = saved
+        el_other = float(t.item())
+        gather_now[0] = not gather_now[0]
 
     # secondary weak-scaling point on EVERY rank (collective): a config-5-like shard, where
     # compute (ms) dominates the all-gather — see DESIGN.md §5
@@ -269,14 +277,16 @@ def main():
                                    f"HelioField.render, sigma_scale={w.sigma_scale}, err={w.error_scale_mrad} mrad, "
                                    f"{w.B} suns per GPU",
                        "global_batch": world * w.B, "parallelism": f"sun-batch sharded x{world}"
-                       + (f", RCCL all-gather of images ({gather.transport} transport, "
-                          f"{'side stream' if args.overlap else 'stream-ordered'})"
-                          if gather is not None else "")},
+                       + ((f", RCCL all-gather of images every step ({gather.transport} transport, "
+                           f"{'side stream' if args.overlap else 'stream-ordered'})") if (gather is not None and args.gather_every_step)
+                          else (", no data-path collective (images stay on the rank that rendered them)" if world > 1 else ""))},
         }
-        if el_local is not None:
-            out["without_all_gather"] = {"frames_per_s": round(frames / el_local, 1),
-                                         "ms_per_step": round(el_local / args.steps * 1e3, 5),
-                                         "note": "same shards, images left on the rank that rendered them"}
+        if el_other is not None:
+            key = "without_all_gather" if args.gather_every_step else "with_all_gather_every_step"
+            out[key] = {"frames_per_s": round(frames / el_other, 1), "ms_per_step": round(el_other / args.steps * 1e3, 5),
+                        "note": ("same shards, images left on the rank that rendered them" if args.gather_every_step else
+                                 f"same shards, every image delivered to every rank each step ({gather.transport} transport): "
+                                 "interconnect-bound at this frame size, DESIGN.md §5")}
         if shard is not None:
             out["weak_scaling_config5_shard"] = shard
         iters = 200 if w.B * w.N * w.R * w.R < 1e10 else 10
