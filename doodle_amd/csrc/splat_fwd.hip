@@ -644,7 +644,7 @@ static void launch_tile(int B, int N, int R, const float* rays, const float* xs,
 // cycles, so the factor evaluation of the NEXT chunk hides under the MFMAs of the current one.
 //
 // Measured at config 4 (N=2000, B=512, R=512), against 3.96 ms for splat_fwd_mfma_tile<4>:
-//   variant 7 (two-level sums, below): 2.39 ms; against fp64 (tools/accuracy_splat.py) worst per-pixel
+//   variant 7 (two-level sums, below): 2.24 ms; against fp64 (tools/accuracy_splat.py) worst per-pixel
 //     relative error 8.6e-7, rms 1.6e-7 — tighter than tile<4>'s one-level f32 chain (1.2e-6 / 2.1e-7);
 //   variant 8 (one level): 1.95 ms; worst pixel 2.5e-6, mean -6e-7 (the pipe's truncation, see below).
 // The chip runs these kernels at 2.06 GHz (2.34 under the f32 MFMA); in variant 8 the bf16 pipe is
@@ -796,7 +796,7 @@ splat_fwd_mfma_bf16x3(int B, int N, int R, const float* __restrict__ rays, const
                 // fresh accumulator and the partial sum is added to the running total on the vector ALU,
                 // round-to-nearest — under the MFMAs of the next row block.  Measured against fp64: worst
                 // pixel 8.6e-7, rms 1.6e-7 — tighter than the one-level f32 chain of splat_fwd_mfma_tile<4>
-                // (1.2e-6 / 2.1e-7); the adds cost vector issue slots: 2.39 ms instead of 1.95.
+                // (1.2e-6 / 2.1e-7); the adds cost vector issue slots: 2.24 ms instead of 1.95.
                 bf16x8 ep[3][2];
 #pragma unroll
                 for (int P = 0; P < 3; ++P)
@@ -824,6 +824,12 @@ splat_fwd_mfma_bf16x3(int B, int N, int R, const float* __restrict__ rays, const
                         // the adds stay HERE: left alone they are sunk into the next trip and eight partial
                         // sums stay live (256 VGPRs + spills)
                         asm volatile("" : "+v"(acc[rb - 1][0]), "+v"(acc[rb - 1][1]));
+                        // ... and go between this row block's MFMAs, two per MFMA slot, not after them
+#pragma unroll
+                        for (int i = 0; i < 12; ++i) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                        }
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }

@@ -105,7 +105,7 @@ int helio_geometry_fwd(int B, int N,
  * accumulation; the dropped partial products are below 2^-23 of each product.  7 sums in two
  * levels (16 rays on the pipe, then a round-to-nearest vector add): against fp64 at N = 2000 its
  * worst per-pixel relative error is 8.6e-7, tighter than the exact-f32 MFMA kernel's one-level
- * chain (1.2e-6), at 1.66x its speed; 8 sums in one level: 2.5e-6, 2.03x.
+ * chain (1.2e-6), at 1.77x its speed; 8 sums in one level: 2.5e-6, 2.03x.
  */
 int helio_splat_fwd(int B, int N, int R,
                     const float *rays_d, const float *xs_d, const float *ys_d,
