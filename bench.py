@@ -195,11 +195,21 @@ def main():
     field = build_field(w, helios, errs, dev)
     suns_d = suns.to(dev)
     action = make_action(field, suns_d, noise)
-    gather, gathered = None, None
+    gather, gathered, gather_error = None, None, None
     if dist is not None:
-        from doodle_amd.comm import ImageGather
-        gather = ImageGather()                 # RCCL all-gather (libhelio_comm.so)
-        gathered = [torch.empty((world * w.B, w.R, w.R), dtype=torch.float32, device=dev) for _ in range(2)]
+        # the timed loop does not need the collective; if the communicator cannot be created the
+        # gathered legs are skipped and said so, the headline is still measured
+        try:
+            from doodle_amd.comm import ImageGather
+            gather = ImageGather()             # RCCL all-gather (libhelio_comm.so)
+            gathered = [torch.empty((world * w.B, w.R, w.R), dtype=torch.float32, device=dev) for _ in range(2)]
+        except Exception as e:  # noqa: BLE001
+            gather, gather_error = None, repr(e)
+        flag = torch.tensor([0 if gather is not None else 1], device=dev)
+        dist.all_reduce(flag)                  # all ranks gather, or none does
+        if int(flag.item()) != 0 and gather is not None:
+            gather.close()
+            gather, gather_error = None, "another rank could not create the communicator"
     stepno = [0]
     if args.mode == "fwdbwd":
         action.requires_grad_(True)
@@ -287,6 +297,8 @@ def main():
                         "note": ("same shards, images left on the rank that rendered them" if args.gather_every_step else
                                  f"same shards, every image delivered to every rank each step ({gather.transport} transport): "
                                  "interconnect-bound at this frame size, DESIGN.md §5")}
+        if gather_error is not None:
+            out["all_gather_error"] = gather_error
         if shard is not None:
             out["weak_scaling_config5_shard"] = shard
         iters = 200 if w.B * w.N * w.R * w.R < 1e10 else 10
