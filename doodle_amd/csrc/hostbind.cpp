@@ -67,11 +67,32 @@ py::tuple render_fwd(int64_t plane, const at::Tensor& helios, const at::Tensor& 
 py::tuple render_any(int64_t plane, const at::Tensor& helios, const at::Tensor& sun_in, const at::Tensor& action_in,
                      const at::Tensor& trig, int64_t trig_b_stride, const at::Tensor& xs, const at::Tensor& ys,
                      c10::optional<at::Tensor> rays_ws, bool want_refl, int64_t variant) {
+    const int64_t N = helios.size(0), R = xs.size(0);
+    // the common call needs no fix-up at all: float32, on the field's device, contiguous, [B,3] and
+    // [B,3N] (or [B,N,3]) — the kernels only see pointers, so no reshaped view is built either
+    if (sun_in.dim() == 2 && sun_in.scalar_type() == at::kFloat && action_in.scalar_type() == at::kFloat &&
+        sun_in.device() == helios.device() && action_in.device() == helios.device() && sun_in.is_contiguous() &&
+        action_in.is_contiguous() && action_in.numel() == sun_in.size(0) * N * 3) {
+        const int64_t B = sun_in.size(0);
+        const auto opt = helios.options();
+        at::Tensor actual = at::empty({B, N, 3}, opt);
+        at::Tensor refl = want_refl ? at::empty({B, N, 3}, opt) : at::Tensor();
+        at::Tensor rays = (rays_ws.has_value() && rays_ws->size(0) == B && rays_ws->device() == helios.device())
+                              ? *rays_ws : at::empty({B, N, HELIO_RAY_STRIDE}, opt);
+        at::Tensor image = at::empty({B, R, R}, opt);
+        check(helio_render_fwd((int)B, (int)N, (int)R, helios.data_ptr<float>(), sun_in.data_ptr<float>(),
+                               action_in.data_ptr<float>(), fp(trig, "trig"), (long)trig_b_stride,
+                               reinterpret_cast<const helio_plane*>(plane), xs.data_ptr<float>(), ys.data_ptr<float>(),
+                               actual.data_ptr<float>(), want_refl ? refl.data_ptr<float>() : nullptr,
+                               rays.data_ptr<float>(), image.data_ptr<float>(), (int)variant, cur_stream(helios)));
+        if (want_refl) return py::make_tuple(image, actual, refl, rays);
+        return py::make_tuple(image, actual, py::none(), rays);
+    }
     const auto opt = helios.options();
     at::Tensor sun = sun_in.to(opt, /*non_blocking=*/false, /*copy=*/false);
     if (sun.dim() == 1) sun = sun.unsqueeze(0);
     sun = sun.contiguous();
-    const int64_t B = sun.size(0), N = helios.size(0);
+    const int64_t B = sun.size(0);
     at::Tensor normals = action_in.to(opt, false, false).reshape({B, N, 3}).contiguous();
     if (rays_ws.has_value() && (rays_ws->size(0) != B || rays_ws->device() != normals.device())) rays_ws.reset();
     return render_fwd(plane, helios, sun, normals, trig, trig_b_stride, xs, ys, rays_ws, want_refl, variant);

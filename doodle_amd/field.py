@@ -104,6 +104,7 @@ class HelioField:
 
         self._trig_cache = {}
         self._ray_ws = None
+        self._fast_render = None      # ops.render_nograd once resolved (False: compiled binding absent)
         self.reset_errors()
         self.initial_action = None
 
@@ -144,8 +145,11 @@ class HelioField:
         return t.to(self.device).contiguous()
 
     def _cached_trig(self, slot: str, errs: torch.Tensor) -> torch.Tensor:
-        key = (errs.data_ptr(), errs._version, tuple(errs.shape), errs.device)
         hit = self._trig_cache.get(slot)
+        # same tensor object, not written to since: the cheap test first (this runs on every render)
+        if hit is not None and hit[2] is errs and hit[0][1] == errs._version:
+            return hit[1]
+        key = (errs.data_ptr(), errs._version, tuple(errs.shape), errs.device)
         if hit is None or hit[0] != key:
             hit = (key, self._trig_of(errs), errs)     # keep errs alive: its data_ptr is the key
             self._trig_cache[slot] = hit
@@ -202,16 +206,26 @@ class HelioField:
         """
         if (type(sun_position) is torch.Tensor and type(action) is torch.Tensor
                 and not (action.requires_grad and torch.is_grad_enabled())):
-            # launch-bound fast path: everything below happens inside the compiled binding
-            ops = _get_ops()
-            fast = getattr(ops, "render_nograd", None)
-            if fast is not None:
+            # launch-bound fast path (config 2 is ≈5.3 µs of GPU per call: every host microsecond shows):
+            # dtype / device / shape fix-ups, allocation and the launch happen inside the compiled binding
+            fast = self._fast_render
+            if fast is None:
+                fast = self._fast_render = getattr(_get_ops(), "render_nograd", False)
+            if fast:
                 batched = sun_position.dim() > 1
-                trig, stride = self._select_trig(sun_position.shape[0] if batched else 1)
+                B = sun_position.shape[0] if batched else 1
+                batch = self.batch_error_angles_mrad
+                hit = self._trig_cache.get("batch") if B > 1 else None
+                if hit is not None and hit[2] is batch and hit[0][1] == batch._version and B <= batch.shape[0]:
+                    trig, stride = hit[1], 4 * self.num_heliostats      # the common case of _select_trig, inlined
+                else:
+                    trig, stride = self._select_trig(B)
                 out = fast(self, sun_position, action, trig, stride, monitor)
                 if out is not None:
+                    if not monitor:
+                        return (out[0], out[1]) if batched else (out[0][0], out[1])
                     img = out[0] if batched else out[0][0]
-                    return (img, out[1], out[2].view(-1, 3)) if monitor else (img, out[1])
+                    return img, out[1], out[2].view(-1, 3)
         sun = torch.as_tensor(sun_position, dtype=torch.float32, device=self.device)
         batched = sun.dim() > 1
         if not batched:

@@ -193,10 +193,13 @@ class HipOps:
         """Fast path of HelioField.render without autograd for torch.Tensor inputs: dtype /
         device / shape fix-ups, allocation and the launch all happen in the compiled binding.
         Returns None when that binding is not built (the caller then takes the general path)."""
-        if self.hb is None:
+        hb = self.hb
+        if hb is None:
             return None
-        out = self.hb.render_any(_plane_handle(self.hb, field._plane), field.heliostat_positions, sun, action, trig,
-                                 trig_b_stride, field._xs, field._ys, field._ray_ws, want_refl, self.splat_variant)
+        plane = field._plane
+        handle = getattr(plane, "_hb_handle", None) or _plane_handle(hb, plane)
+        out = hb.render_any(handle, field.heliostat_positions, sun, action, trig, trig_b_stride, field._xs, field._ys,
+                            field._ray_ws, want_refl, self.splat_variant)
         field._ray_ws = out[3]
         return out
 
