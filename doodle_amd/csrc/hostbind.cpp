@@ -193,9 +193,20 @@ StepOut step_core(int64_t plane, const at::Tensor& helios, const at::Tensor& sun
     o.refl = at::empty_like(normals);
     o.rays = rays_ws.has_value() ? *rays_ws : at::empty({B, N, HELIO_RAY_STRIDE}, opt);
     o.image = at::empty({B, R, R}, opt);
-    at::Tensor ws = at::empty({helio_env_step_workspace((int)B, (int)N, (int)R)}, opt);
-    o.out = at::empty({5}, opt); o.mae = at::empty({B}, opt); o.keep = at::empty({B}, opt);
-    o.align = at::empty({B, N}, opt); o.allb = at::empty({B, N}, opt);
+    // the six small buffers (workspace, 5 scalars, per-image and per-ray vectors) are slices of ONE
+    // allocation: a caching-allocator round trip costs about twice what a view does, and this call sits
+    // in front of a launch the caller then waits for
+    const int64_t nws = helio_env_step_workspace((int)B, (int)N, (int)R);
+    auto up4 = [](int64_t n) { return (n + 3) & ~int64_t(3); };          // keep every slice 16-byte aligned
+    const int64_t o_out = up4(nws), o_mae = o_out + 8, o_keep = o_mae + up4(B), o_align = o_keep + up4(B),
+                  o_allb = o_align + up4(B * N), total = o_allb + up4(B * N);
+    at::Tensor flat = at::empty({total}, opt);
+    at::Tensor ws = flat;                                                  // the first nws floats
+    o.out = flat.narrow(0, o_out, 5);
+    o.mae = flat.narrow(0, o_mae, B);
+    o.keep = flat.narrow(0, o_keep, B);
+    o.align = at::as_strided(flat, {B, N}, {N, 1}, o_align);
+    o.allb = at::as_strided(flat, {B, N}, {N, 1}, o_allb);
     if (want_aux) o.aux = at::empty({B, 3 + 3 * N}, opt);
     check(helio_env_step_fwd((int)B, (int)N, (int)R, fp(helios, "heliostat_positions"), fp(sun, "sun"), pn,
                              fp(trig, "trig"), (long)trig_b_stride, reinterpret_cast<const helio_plane*>(plane),
@@ -232,8 +243,12 @@ py::tuple env_step_fwd(int64_t plane, const at::Tensor& helios, const at::Tensor
                        const std::vector<double>& tp, const std::vector<double>& tn, double W, double H,
                        bool exp_risk, double mask_ratio, int64_t notify, int64_t ticket) {
     const int64_t B = sun.size(0), N = helios.size(0);
-    at::Tensor action = action_in.to(helios.options(), false, false);
-    at::Tensor normals = action.reshape({B, N, 3}).contiguous();
+    at::Tensor normals;
+    if (action_in.scalar_type() == at::kFloat && action_in.device() == helios.device() && action_in.is_contiguous() &&
+        action_in.numel() == B * N * 3)
+        normals = action_in.dim() == 3 ? action_in : action_in.view({B, N, 3});      // nothing to fix up
+    else
+        normals = action_in.to(helios.options(), false, false).reshape({B, N, 3}).contiguous();
     if (rays_ws.has_value() && (rays_ws->size(0) != B || rays_ws->device() != normals.device())) rays_ws.reset();
     const StepOut r = step_core(plane, helios, sun, normals, trig, trig_b_stride, xs, ys, rays_ws, variant, target, tx, dmaps,
                                 ideal, tp, tn, W, H, exp_risk, mask_ratio, true, notify, ticket);

@@ -116,6 +116,7 @@ class HelioEnv(_EnvBase):
         # the NaN/Inf asserts of :495-501, one host sync per step (False skips it; measured: the step
         # is then bound by its three-kernel GPU chain, 34 µs instead of 48 µs at config 2)
         self.check_finite = True
+        self._consts_cache = None
         self._ref_cache = None
         f3 = ctypes.c_float * 3
         self._tp3 = f3(*[float(x) for x in targ_pos.detach().cpu().tolist()])
@@ -158,6 +159,13 @@ class HelioEnv(_EnvBase):
         cached until either changes."""
         errs = self.ref_field.batch_error_angles_mrad
         single = self.ref_field.error_angles_mrad
+        hit = self._ref_cache
+        if hit is not None:
+            # the same tensor objects, not written to since (this runs on every step): cheap test first
+            sun0, sv, e0, ev, s0, ssv, sig = hit[6]
+            if (sun0 is self.sun_pos and sv == sun0._version and e0 is errs and (errs is None or ev == errs._version)
+                    and s0 is single and ssv == single._version and sig == self.ref_field.sigma_scale):
+                return hit[1:5]
         key = (self.sun_pos.data_ptr(), self.sun_pos._version,
                None if errs is None else (errs.data_ptr(), errs._version), single.data_ptr(), single._version,
                self.ref_field.sigma_scale)
@@ -166,7 +174,10 @@ class HelioEnv(_EnvBase):
                 ideal = self.ref_field.calculate_ideal_normals(self.sun_pos)
                 target, _ = self.ref_field.render(self.sun_pos, ideal.flatten(1), ideal)
                 tx = target.amax((1, 2)).clamp_min(1e-6)
-            self._ref_cache = (key, ideal, target, tx, ideal.view([-1, 3]), (errs, single))
+            self._ref_cache = (key, ideal, target, tx, ideal.view([-1, 3]), (errs, single), None)
+        self._ref_cache = self._ref_cache[:6] + ((self.sun_pos, self.sun_pos._version, errs,
+                                                  None if errs is None else errs._version, single, single._version,
+                                                  self.ref_field.sigma_scale),)
         return self._ref_cache[1:5]
 
     def set_sun_pos(self, sun_positions: torch.Tensor):
@@ -209,10 +220,16 @@ class HelioEnv(_EnvBase):
         if self.use_error_mask and self.batch_size > 4096:
             raise NotImplementedError("use_error_mask: the fused quantile covers batch_size <= 4096")
         ideal, target, tx, ideal_flat = self._reference()
-        consts = StepConstants(target, tx, self.distance_maps, ideal, self.noisy_field.heliostat_positions,
-                               self._tp3, self._tn3, float(self.targ_area[0]), float(self.targ_area[1]),
-                               bool(self.exponential_risk),
-                               float(self.error_mask_ratio) if self.use_error_mask else -1.0)
+        mask_ratio = float(self.error_mask_ratio) if self.use_error_mask else -1.0
+        cc = self._consts_cache
+        if (cc is not None and cc[0] is target and cc[1] is self.distance_maps and cc[2] == self.exponential_risk
+                and cc[3] == mask_ratio):
+            consts = cc[4]                                               # nothing the loss block reads has changed
+        else:
+            consts = StepConstants(target, tx, self.distance_maps, ideal, self.noisy_field.heliostat_positions,
+                                   self._tp3, self._tn3, float(self.targ_area[0]), float(self.targ_area[1]),
+                                   bool(self.exponential_risk), mask_ratio)
+            self._consts_cache = (target, self.distance_maps, self.exponential_risk, mask_ratio, consts)
         fast, ticket = None, 0
         differentiate = torch.is_grad_enabled() and action.requires_grad
         if not differentiate and type(action) is torch.Tensor:

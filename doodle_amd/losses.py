@@ -31,6 +31,11 @@ class StepConstants:
     exp_risk: bool
     mask_ratio: float = -1.0  # use_error_mask: fraction of worst images kept (< 0: no mask)
 
+    def __post_init__(self):
+        # what the compiled binding takes, converted once (the constants object is reused across steps)
+        self.tp_l, self.tn_l = list(self.tp), list(self.tn)
+        self.exp_risk, self.mask_ratio = bool(self.exp_risk), float(self.mask_ratio)
+
 
 class _StepLosses(torch.autograd.Function):
     @staticmethod

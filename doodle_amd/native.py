@@ -233,7 +233,7 @@ class HipOps:
         if self.hb is not None:
             return (*self.hb.env_step_core(_plane_handle(self.hb, plane), helios, sun, normals, trig, trig_b_stride,
                                            xs, ys, rays, self.splat_variant, c.target, c.tx, c.dmaps, c.ideal,
-                                           list(c.tp), list(c.tn), c.W, c.H, bool(c.exp_risk), float(c.mask_ratio),
+                                           c.tp_l, c.tn_l, c.W, c.H, c.exp_risk, c.mask_ratio,
                                            bool(want_aux), rec, ticket), ticket)
         B, N, R = normals.shape[0], normals.shape[1], xs.shape[0]
         dev = normals.device
@@ -248,7 +248,7 @@ class HipOps:
             B, N, R, _dev(helios), _dev(sun), _dev(normals), _dev(trig), trig_b_stride, plane, _dev(xs), _dev(ys),
             actual.data_ptr(), refl.data_ptr(), rays.data_ptr(), image.data_ptr(), self.splat_variant,
             _dev(c.target), _dev(c.tx), _dev(c.dmaps), _dev(c.ideal), c.tp, c.tn, c.W, c.H, int(c.exp_risk),
-            float(c.mask_ratio), ws.data_ptr(), out.data_ptr(), mae.data_ptr(), keep.data_ptr(), align.data_ptr(),
+            c.mask_ratio, ws.data_ptr(), out.data_ptr(), mae.data_ptr(), keep.data_ptr(), align.data_ptr(),
             allb.data_ptr(), aux.data_ptr() if want_aux else None, rec or None, ticket, _stream()))
         return image, actual, refl, rays, out, mae, align, allb, keep, aux, ticket
 
@@ -258,8 +258,8 @@ class HipOps:
         every cotangent may be None.  → grad_action [B,N,3]."""
         if self.hb is not None:
             return self.hb.env_step_bwd(_plane_handle(self.hb, plane), helios, sun, normals, trig, trig_b_stride, rays,
-                                        xs, ys, image, c.target, c.tx, c.dmaps, c.ideal, list(c.tp), list(c.tn), c.W,
-                                        c.H, bool(c.exp_risk), g_mse, g_dist, g_bound, g_align, keep, g_actual, g_refl,
+                                        xs, ys, image, c.target, c.tx, c.dmaps, c.ideal, c.tp_l, c.tn_l, c.W,
+                                        c.H, c.exp_risk, g_mse, g_dist, g_bound, g_align, keep, g_actual, g_refl,
                                         self.bwd_variant)
         B, N, R = normals.shape[0], normals.shape[1], xs.shape[0]
         grad = torch.empty_like(normals)
@@ -293,8 +293,8 @@ class HipOps:
         rec, ticket = self._next_ticket() if notify else (0, 0)
         out = self.hb.env_step_autograd(_plane_handle(self.hb, field._plane), field.heliostat_positions, sun, normals,
                                         trig, trig_b_stride, field._xs, field._ys, self.splat_variant, self.bwd_variant,
-                                        c.target, c.tx, c.dmaps, c.ideal, list(c.tp), list(c.tn), c.W, c.H,
-                                        bool(c.exp_risk), float(c.mask_ratio), rec, ticket)
+                                        c.target, c.tx, c.dmaps, c.ideal, c.tp_l, c.tn_l, c.W, c.H,
+                                        c.exp_risk, c.mask_ratio, rec, ticket)
         return (*out, ticket)
 
     def env_step_nograd(self, field, sun, action, trig, trig_b_stride, c, notify=False):
@@ -307,8 +307,8 @@ class HipOps:
         rec, ticket = self._next_ticket() if notify else (0, 0)
         r = self.hb.env_step_fwd(_plane_handle(self.hb, field._plane), field.heliostat_positions, sun, action, trig,
                                  trig_b_stride, field._xs, field._ys, field._ray_ws, self.splat_variant, c.target,
-                                 c.tx, c.dmaps, c.ideal, list(c.tp), list(c.tn), c.W, c.H, bool(c.exp_risk),
-                                 float(c.mask_ratio), rec, ticket)
+                                 c.tx, c.dmaps, c.ideal, c.tp_l, c.tn_l, c.W, c.H, c.exp_risk,
+                                 c.mask_ratio, rec, ticket)
         field._ray_ws = r[3]
         return (*r[:3], *r[4:], ticket)
 
@@ -388,7 +388,7 @@ class HipOps:
         alignment errors [B,N] (mrad), boundary terms [B,N], keep [B] (the 0/1 error mask)."""
         if self.hb is not None:
             return self.hb.step_losses_fwd(img, c.target, c.tx, c.dmaps, c.ideal, actual, action, c.helios,
-                                           list(c.tp), list(c.tn), c.W, c.H, bool(c.exp_risk), float(c.mask_ratio))
+                                           c.tp_l, c.tn_l, c.W, c.H, c.exp_risk, c.mask_ratio)
         B, N, R = action.shape[0], action.shape[1], img.shape[-1]
         dev = img.device
         ws = torch.empty(self.lib.helio_step_losses_workspace(B, N, R), dtype=torch.float32, device=dev)
@@ -399,7 +399,7 @@ class HipOps:
         allb = torch.empty((B, N), dtype=torch.float32, device=dev)
         _check(self.lib, self.lib.helio_step_losses_fwd(
             B, N, R, _dev(img), _dev(c.target), _dev(c.tx), _dev(c.dmaps), _dev(c.ideal), _dev(actual),
-            _dev(action), _dev(c.helios), c.tp, c.tn, c.W, c.H, int(c.exp_risk), float(c.mask_ratio),
+            _dev(action), _dev(c.helios), c.tp, c.tn, c.W, c.H, int(c.exp_risk), c.mask_ratio,
             ws.data_ptr(), out.data_ptr(), mae.data_ptr(), keep.data_ptr(), align.data_ptr(), allb.data_ptr(),
             None, None, _stream()))
         return out, mae, align, allb, keep
@@ -408,7 +408,7 @@ class HipOps:
                         want_action):
         if self.hb is not None:
             return self.hb.step_losses_bwd(img, c.target, c.tx, c.dmaps, c.ideal, actual, action, c.helios,
-                                           list(c.tp), list(c.tn), c.W, c.H, bool(c.exp_risk), g_mse, g_dist,
+                                           c.tp_l, c.tn_l, c.W, c.H, c.exp_risk, g_mse, g_dist,
                                            g_bound, g_align, keep, bool(want_img), bool(want_actual),
                                            bool(want_action))
         B, N, R = action.shape[0], action.shape[1], img.shape[-1]
