@@ -98,6 +98,45 @@ py::tuple render_any(int64_t plane, const at::Tensor& helios, const at::Tensor& 
     return render_fwd(plane, helios, sun, normals, trig, trig_b_stride, xs, ys, rays_ws, want_refl, variant);
 }
 
+// A field's render context: everything of HelioField.render's no-autograd call that does not change
+// from call to call (plane, heliostats, pixel coordinates, the trig table of the current errors),
+// bound once — the per-call binding then converts two tensor arguments instead of eleven.  At
+// config 2 the GPU needs ≈5.3 µs per call, so each of those conversions is visible.
+struct RenderCtx {
+    int64_t plane;
+    at::Tensor helios, xs, ys, trig, rays_ws;
+    int64_t trig_b_stride, variant;
+    RenderCtx(int64_t plane_, at::Tensor helios_, at::Tensor xs_, at::Tensor ys_, at::Tensor trig_, int64_t stride_,
+              int64_t variant_)
+        : plane(plane_), helios(std::move(helios_)), xs(std::move(xs_)), ys(std::move(ys_)), trig(std::move(trig_)),
+          trig_b_stride(stride_), variant(variant_) {
+        fp(helios, "heliostat_positions"); fp(xs, "xs"); fp(ys, "ys"); fp(trig, "trig");
+    }
+    // → (image [B,R,R], actual [B,N,3]) or, with want_refl, (image, actual, refl [B,N,3]); None when the
+    // tensors need a dtype / device / layout fix-up (the caller then takes the general path)
+    py::object render(const at::Tensor& sun, const at::Tensor& action, bool want_refl) {
+        const int64_t N = helios.size(0), R = xs.size(0);
+        if (!(sun.dim() == 2 && sun.scalar_type() == at::kFloat && action.scalar_type() == at::kFloat &&
+              sun.device() == helios.device() && action.device() == helios.device() && sun.is_contiguous() &&
+              action.is_contiguous() && action.numel() == sun.size(0) * N * 3))
+            return py::none();
+        const int64_t B = sun.size(0);
+        if (trig_b_stride != 0 && trig.numel() < B * N * 4) return py::none();
+        const auto opt = helios.options();
+        at::Tensor actual = at::empty({B, N, 3}, opt);
+        at::Tensor refl = want_refl ? at::empty({B, N, 3}, opt) : at::Tensor();
+        if (!rays_ws.defined() || rays_ws.size(0) != B) rays_ws = at::empty({B, N, HELIO_RAY_STRIDE}, opt);
+        at::Tensor image = at::empty({B, R, R}, opt);
+        check(helio_render_fwd((int)B, (int)N, (int)R, helios.data_ptr<float>(), sun.data_ptr<float>(),
+                               action.data_ptr<float>(), trig.data_ptr<float>(), (long)trig_b_stride,
+                               reinterpret_cast<const helio_plane*>(plane), xs.data_ptr<float>(), ys.data_ptr<float>(),
+                               actual.data_ptr<float>(), want_refl ? refl.data_ptr<float>() : nullptr,
+                               rays_ws.data_ptr<float>(), image.data_ptr<float>(), (int)variant, cur_stream(helios)));
+        if (want_refl) return py::make_tuple(image, actual, refl);
+        return py::make_tuple(image, actual);
+    }
+};
+
 at::Tensor render_bwd(int64_t plane, const at::Tensor& helios, const at::Tensor& sun, const at::Tensor& normals,
                       const at::Tensor& trig, int64_t trig_b_stride, const at::Tensor& rays, const at::Tensor& xs,
                       const at::Tensor& ys, c10::optional<at::Tensor> g_image, c10::optional<at::Tensor> g_actual,
@@ -445,6 +484,11 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("render_fwd", &render_fwd);
     m.def("render_any", &render_any);
     m.def("render_bwd", &render_bwd);
+    py::class_<RenderCtx>(m, "RenderCtx")
+        .def(py::init<int64_t, at::Tensor, at::Tensor, at::Tensor, at::Tensor, int64_t, int64_t>())
+        .def("render", &RenderCtx::render)
+        .def_readonly("trig", &RenderCtx::trig)
+        .def_readonly("variant", &RenderCtx::variant);
     m.def("step_losses_fwd", &step_losses_fwd, py::arg("img"), py::arg("target"), py::arg("tx"), py::arg("dmaps"),
           py::arg("ideal"), py::arg("actual"), py::arg("action"), py::arg("helios"), py::arg("tp"), py::arg("tn"),
           py::arg("W"), py::arg("H"), py::arg("exp_risk"), py::arg("mask_ratio"), py::arg("sun") = py::none(),

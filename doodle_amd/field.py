@@ -104,7 +104,8 @@ class HelioField:
 
         self._trig_cache = {}
         self._ray_ws = None
-        self._fast_render = None      # ops.render_nograd once resolved (False: compiled binding absent)
+        self._fast_render = None      # ops.render_context once resolved (False: compiled binding absent)
+        self._render_ctx, self._ctx_key, self._ops = None, None, None
         self.reset_errors()
         self.initial_action = None
 
@@ -210,7 +211,8 @@ class HelioField:
             # dtype / device / shape fix-ups, allocation and the launch happen inside the compiled binding
             fast = self._fast_render
             if fast is None:
-                fast = self._fast_render = getattr(_get_ops(), "render_nograd", False)
+                self._ops = _get_ops()
+                fast = self._fast_render = getattr(self._ops, "render_context", False)
             if fast:
                 batched = sun_position.dim() > 1
                 B = sun_position.shape[0] if batched else 1
@@ -220,12 +222,20 @@ class HelioField:
                     trig, stride = hit[1], 4 * self.num_heliostats      # the common case of _select_trig, inlined
                 else:
                     trig, stride = self._select_trig(B)
-                out = fast(self, sun_position, action, trig, stride, monitor)
-                if out is not None:
-                    if not monitor:
-                        return (out[0], out[1]) if batched else (out[0][0], out[1])
-                    img = out[0] if batched else out[0][0]
-                    return img, out[1], out[2].view(-1, 3)
+                ops = self._ops
+                key = self._ctx_key
+                if key is None or key[0] is not trig or key[1] != stride or key[2] != ops.splat_variant or key[3] is not ops.hb:
+                    # rebuilt when the errors, the forced variant or the binding change
+                    self._render_ctx = fast(self, trig, stride)
+                    self._ctx_key = (trig, stride, ops.splat_variant, ops.hb)
+                ctx = self._render_ctx
+                if ctx is not None:
+                    out = ctx.render(sun_position if batched else sun_position.unsqueeze(0), action, monitor)
+                    if out is not None:
+                        if not monitor:
+                            return out if batched else (out[0][0], out[1])
+                        img = out[0] if batched else out[0][0]
+                        return img, out[1], out[2].view(-1, 3)
         sun = torch.as_tensor(sun_position, dtype=torch.float32, device=self.device)
         batched = sun.dim() > 1
         if not batched:

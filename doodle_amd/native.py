@@ -189,6 +189,16 @@ class HipOps:
             rays.data_ptr(), image.data_ptr(), self.splat_variant, _stream()))
         return image, actual, refl, rays
 
+    def render_context(self, field, trig, trig_b_stride):
+        """A compiled render context of ``field`` for the trig table ``trig`` (csrc/hostbind.cpp
+        RenderCtx): ``ctx.render(sun, action, want_refl)`` is HelioField.render's no-autograd call with
+        two tensor arguments.  None when the compiled binding is not built."""
+        hb = self.hb
+        if hb is None:
+            return None
+        return hb.RenderCtx(_plane_handle(hb, field._plane), field.heliostat_positions, field._xs, field._ys, trig,
+                            trig_b_stride, self.splat_variant)
+
     def render_nograd(self, field, sun, action, trig, trig_b_stride, want_refl):
         """Fast path of HelioField.render without autograd for torch.Tensor inputs: dtype /
         device / shape fix-ups, allocation and the launch all happen in the compiled binding.
