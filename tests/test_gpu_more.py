@@ -1010,3 +1010,30 @@ def test_random_scenes_against_oracle():
         worst_grad = max(worst_grad, dev)
         assert dev <= 5e-4, (tag, dev)
     print(f"worst image deviation {worst_img:.2e} of peak, worst gradient deviation {worst_grad:.2e} of max")
+
+
+def test_render_input_tolerance_around_the_fast_path():
+    """HelioField.render accepts what the reference's as_tensor(..., float32, device) accepts (:326-337):
+    other dtypes, CPU tensors, lists / ndarrays, non-contiguous views, [B,N,3] actions, a 1-D sun.  Only
+    conforming device tensors take the compiled render context; everything else falls back to the
+    general path — same numbers either way."""
+    f, _, suns, _, act = make_case(N=9, B=4, R=40, seed=4)
+    sun_d, act_d = suns.to(DEV), act.to(DEV)
+    want_img, want_actual = f.render(sun_d, act_d, None)
+    variants = {
+        "float64 action": (sun_d, act_d.double()),
+        "cpu tensors": (suns, act),
+        "numpy / list": (suns.numpy(), act.tolist()),
+        "[B,N,3] action": (sun_d, act_d.reshape(4, 9, 3)),
+        "non-contiguous action": (sun_d, act_d.reshape(4, 9, 3).transpose(1, 2).contiguous().transpose(1, 2)),
+        "non-contiguous sun": (torch.stack([sun_d, sun_d], dim=2)[:, :, 0], act_d),
+    }
+    for name, (s, a) in variants.items():
+        img, actual = f.render(s, a, None)
+        assert torch.equal(img, want_img) and torch.equal(actual, want_actual), name
+    img1, actual1 = f.render(sun_d[2], act_d[2], None)             # a 1-D sun uses the single-error tensor
+    assert img1.shape == (40, 40) and actual1.shape == (1, 9, 3)
+    img1b, _ = f.render(sun_d[2].tolist(), act_d[2].cpu().numpy(), None)
+    assert torch.equal(img1, img1b)
+    _, _, refl = f.render(sun_d, act_d, None, monitor=True)
+    assert refl.shape == (36, 3)
