@@ -297,6 +297,44 @@ py::tuple env_step_fwd(int64_t plane, const at::Tensor& helios, const at::Tensor
                           r.mae.view({B, 1}), r.align.view({B * N}), r.allb, r.aux, normals);
 }
 
+// HelioEnv.step's no-autograd call with everything that does not change between steps bound once
+// (fields' geometry, trig table, reference image / peaks / distance maps / ideal normals, loss
+// constants, completion record): per step the binding converts two tensors and a ticket.  The host
+// side of a step is what bounds it at small sizes (two launches, ≈14 µs of GPU).
+struct EnvStepCtx {
+    int64_t plane, trig_b_stride, variant, notify;
+    at::Tensor helios, xs, ys, trig, target, tx, dmaps, ideal, rays_ws;
+    std::vector<double> tp, tn;
+    double W, H, mask_ratio;
+    bool exp_risk;
+    EnvStepCtx(int64_t plane_, at::Tensor helios_, at::Tensor xs_, at::Tensor ys_, at::Tensor trig_, int64_t stride_,
+               int64_t variant_, at::Tensor target_, at::Tensor tx_, at::Tensor dmaps_, at::Tensor ideal_,
+               std::vector<double> tp_, std::vector<double> tn_, double W_, double H_, bool exp_risk_, double mask_ratio_,
+               int64_t notify_)
+        : plane(plane_), trig_b_stride(stride_), variant(variant_), notify(notify_), helios(std::move(helios_)),
+          xs(std::move(xs_)), ys(std::move(ys_)), trig(std::move(trig_)), target(std::move(target_)), tx(std::move(tx_)),
+          dmaps(std::move(dmaps_)), ideal(std::move(ideal_)), tp(std::move(tp_)), tn(std::move(tn_)), W(W_), H(H_),
+          mask_ratio(mask_ratio_), exp_risk(exp_risk_) {}
+    // → the tuple of env_step_fwd (outputs already in the shapes step() returns), or None when the
+    // action needs a dtype / device / layout fix-up
+    py::object step(const at::Tensor& sun, const at::Tensor& action_in, int64_t ticket) {
+        const int64_t B = sun.size(0), N = helios.size(0);
+        if (!(action_in.scalar_type() == at::kFloat && action_in.device() == helios.device() && action_in.is_contiguous() &&
+              action_in.numel() == B * N * 3 && sun.scalar_type() == at::kFloat && sun.is_contiguous() &&
+              sun.device() == helios.device()))
+            return py::none();
+        at::Tensor normals = action_in.dim() == 3 ? action_in : action_in.view({B, N, 3});
+        c10::optional<at::Tensor> ws;
+        if (rays_ws.defined() && rays_ws.size(0) == B) ws = rays_ws;
+        const StepOut r = step_core(plane, helios, sun, normals, trig, trig_b_stride, xs, ys, ws, variant, target, tx, dmaps,
+                                    ideal, tp, tn, W, H, exp_risk, mask_ratio, true, ticket != 0 ? notify : 0, ticket);
+        rays_ws = r.rays;
+        return py::make_tuple(r.image, r.actual, r.refl.view({B * N, 3}), r.out.select(0, 0), r.out.select(0, 1),
+                              r.out.select(0, 2), r.out.select(0, 3), r.out.select(0, 4), r.mae.view({B, 1}),
+                              r.align.view({B * N}), r.allb, r.aux, normals);
+    }
+};
+
 // Backward of the env step in one call (helio_env_step_bwd): cotangents of the four scalars (0-d
 // device tensors or None) and of actual / refl (or None) → grad_action [B,N,3]
 at::Tensor env_step_bwd(int64_t plane, const at::Tensor& helios, const at::Tensor& sun, const at::Tensor& normals,
@@ -484,6 +522,11 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("render_fwd", &render_fwd);
     m.def("render_any", &render_any);
     m.def("render_bwd", &render_bwd);
+    py::class_<EnvStepCtx>(m, "EnvStepCtx")
+        .def(py::init<int64_t, at::Tensor, at::Tensor, at::Tensor, at::Tensor, int64_t, int64_t, at::Tensor, at::Tensor,
+                      at::Tensor, at::Tensor, std::vector<double>, std::vector<double>, double, double, bool, double,
+                      int64_t>())
+        .def("step", &EnvStepCtx::step);
     py::class_<RenderCtx>(m, "RenderCtx")
         .def(py::init<int64_t, at::Tensor, at::Tensor, at::Tensor, at::Tensor, int64_t, int64_t>())
         .def("render", &RenderCtx::render)

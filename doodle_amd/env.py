@@ -115,8 +115,12 @@ class HelioEnv(_EnvBase):
         self.exponential_risk = exponential_risk
         # the NaN/Inf asserts of :495-501, one host sync per step (False skips it; measured: the step
         # is then bound by its three-kernel GPU chain, 34 µs instead of 48 µs at config 2)
+        # True: the reference's NaN/Inf asserts after every step (:495-501); False: none; "deferred": the
+        # same asserts one step late (finish_checks() for the last one) — the host never waits for the GPU
         self.check_finite = True
+        self._pending_check = None
         self._consts_cache = None
+        self._step_ctx, self._step_ctx_key = None, None
         self._ref_cache = None
         f3 = ctypes.c_float * 3
         self._tp3 = f3(*[float(x) for x in targ_pos.detach().cpu().tolist()])
@@ -233,14 +237,31 @@ class HelioEnv(_EnvBase):
         fast, ticket = None, 0
         differentiate = torch.is_grad_enabled() and action.requires_grad
         if not differentiate and type(action) is torch.Tensor:
-            step_fn = getattr(_field._get_ops(), "env_step_nograd", None)
-            if step_fn is not None:      # everything in one call of the compiled binding
+            ops = _field._get_ops()
+            make_ctx = getattr(ops, "env_step_context", None)
+            if make_ctx is not None:     # everything in one call of the compiled binding
                 trig, stride = self.noisy_field._select_trig(self.batch_size)
-                fast = step_fn(self.noisy_field, self.sun_pos, action, trig, stride, consts,
-                               notify=self.check_finite)
+                key = self._step_ctx_key
+                if (key is None or key[0] is not consts or key[1] is not trig or key[2] != ops.splat_variant
+                        or key[3] is not ops.hb):
+                    # constants, errors, forced kernel variant or binding changed: rebind the step context
+                    self._step_ctx = make_ctx(self.noisy_field, trig, stride, consts)
+                    self._step_ctx_key = (consts, trig, ops.splat_variant, ops.hb)
+                ctx = self._step_ctx
+                if ctx is not None:
+                    ticket = ops.next_ticket() if self.check_finite else 0
+                    fast = ctx.step(self.sun_pos, action, ticket)
+                if fast is None:         # (the action needs a dtype / device / layout fix-up)
+                    ticket = 0
+                    step_fn = getattr(ops, "env_step_nograd", None)
+                    if step_fn is not None:
+                        fast = step_fn(self.noisy_field, self.sun_pos, action, trig, stride, consts,
+                                       notify=self.check_finite)
+                        if fast is not None:
+                            ticket, fast = fast[-1], fast[:-1]
         if fast is not None:
             (img, actual, reflected, mse, dist_l, bound, alignment_loss, flag, mae, angles, all_bounds, aux,
-             normals, ticket) = fast
+             normals) = fast
         else:
             normals = action.view(self.batch_size, -1, 3)                # :460
             if differentiate:
@@ -267,10 +288,27 @@ class HelioEnv(_EnvBase):
         if self.check_finite:                                          # :495-501, one wait instead of six syncs;
             # last, so that the dictionaries above are built while the GPU finishes the step.  The
             # finishing workgroup publishes the flag to pinned host memory (helio_notify_*)
-            bad = _field._get_ops().notify_wait(ticket) if ticket else None
-            if bool(flag) if bad is None else bad:
-                raise AssertionError("MSE, distance loss or boundary loss is NaN or Inf")
+            if self.check_finite == "deferred":
+                # rollouts: this step's flag is looked at when the NEXT step (or finish_checks()) comes,
+                # by which time it has long been published — the host never waits for the GPU, and a
+                # NaN/Inf is reported one step late
+                pending, self._pending_check = self._pending_check, (ticket, flag)
+                if pending is not None:
+                    self._raise_if_nonfinite(*pending)
+            else:
+                self._raise_if_nonfinite(ticket, flag)
         return obs, metrics, monitor
+
+    def _raise_if_nonfinite(self, ticket, flag):
+        bad = _field._get_ops().notify_wait(ticket) if ticket else None
+        if bool(flag) if bad is None else bad:
+            raise AssertionError("MSE, distance loss or boundary loss is NaN or Inf")
+
+    def finish_checks(self):
+        """With ``check_finite = "deferred"``: look at the flag of the last step now."""
+        pending, self._pending_check = self._pending_check, None
+        if pending is not None:
+            self._raise_if_nonfinite(*pending)
 
     def seed(self, seed=None):
         """Seed torch and numpy (:518-525)."""

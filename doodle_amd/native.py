@@ -307,6 +307,23 @@ class HipOps:
                                         c.exp_risk, c.mask_ratio, rec, ticket)
         return (*out, ticket)
 
+    def env_step_context(self, field, trig, trig_b_stride, c):
+        """A compiled step context (csrc/hostbind.cpp EnvStepCtx) for ``field``, the trig table ``trig`` and
+        the loss constants ``c``: ``ctx.step(sun, action, ticket)`` is HelioEnv.step's no-autograd call with
+        three arguments (ticket 0: no completion record).  None when the compiled binding is not built."""
+        hb = self.hb
+        if hb is None:
+            return None
+        if self._notify is None:
+            self._next_ticket()
+        return hb.EnvStepCtx(_plane_handle(hb, field._plane), field.heliostat_positions, field._xs, field._ys, trig,
+                             trig_b_stride, self.splat_variant, c.target, c.tx, c.dmaps, c.ideal, c.tp_l, c.tn_l, c.W, c.H,
+                             c.exp_risk, c.mask_ratio, self._notify)
+
+    def next_ticket(self):
+        self._ticket = self._ticket % 0x7FFFFFFF + 1
+        return self._ticket
+
     def env_step_nograd(self, field, sun, action, trig, trig_b_stride, c, notify=False):
         """HelioEnv.step without autograd in one call of the compiled binding (render + loss block +
         aux, outputs already in the shapes step() returns).  None when that binding is not built.

@@ -1037,3 +1037,30 @@ def test_render_input_tolerance_around_the_fast_path():
     assert torch.equal(img1, img1b)
     _, _, refl = f.render(sun_d, act_d, None, monitor=True)
     assert refl.shape == (36, 3)
+
+
+def test_deferred_finite_check_reports_one_step_late():
+    from doodle_amd.env import HelioEnv
+    torch.manual_seed(2)
+    N, B, R = 5, 6, 32
+    hp = torch.rand(N, 3, device=DEV) * 10 + 80
+    hp[:, 2] = 0
+    env = HelioEnv(hp, torch.tensor([0., -5., 0.], device=DEV), (15., 15.), torch.tensor([0., 1., 0.], device=DEV),
+                   sigma_scale=0.05, error_scale_mrad=3.0, resolution=R, batch_size=B, device=DEV)
+    env.reset()
+    good = env.ideal_normals.reshape(B, -1).clone()
+    bad = good.clone()
+    bad[0, 0] = float("nan")
+    env.check_finite = "deferred"
+    with torch.no_grad():
+        env.step(good)
+        env.step(bad)                      # published, not looked at yet
+        with pytest.raises(AssertionError):
+            env.step(good)                 # the previous step's flag
+        env.finish_checks()                # the good step's: nothing
+        env.step(bad)
+        with pytest.raises(AssertionError):
+            env.finish_checks()
+    env.check_finite = True
+    with torch.no_grad(), pytest.raises(AssertionError):
+        env.step(bad)

@@ -29,6 +29,14 @@ def timeit(fn, n=300, repeats=5):
 
 with torch.no_grad():
     t_fwd = timeit(lambda: env.step(act))
+env.check_finite = "deferred"
+with torch.no_grad():
+    t_def = timeit(lambda: env.step(act))
+    env.finish_checks()
+env.check_finite = False
+with torch.no_grad():
+    t_off = timeit(lambda: env.step(act))
+env.check_finite = True
 a = act.clone().requires_grad_(True)
 def fb(key):
     _, m, _ = env.step(a)
@@ -45,6 +53,7 @@ if "--ab" in sys.argv:      # A/B, interleaved: helio_env_step_bwd vs the compos
         two = (timeit(lambda: fb("alignment_loss")), timeit(lambda: fb("dist")))
         del ops.env_step_bwd
         print(f"round {rnd}: one call {one[0]:7.1f} / {one[1]:7.1f} us   composed {two[0]:7.1f} / {two[1]:7.1f} us   (alignment / dist)")
+print(f"env.step forward-only, finite check deferred by one step {t_def:8.1f} us | no check {t_off:8.1f} us")
 print(f"env.step forward-only {t_fwd:8.1f} us = {B/t_fwd*1e6:10.0f} frames/s | step+backward(alignment) {t_align:8.1f} us | step+backward(dist) {t_dist:8.1f} us")
 from doodle_amd.graphed import GraphedEnvStep
 gs = GraphedEnvStep(env, like=act.reshape(B, -1, 3), objective="dist")
