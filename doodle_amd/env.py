@@ -227,7 +227,7 @@ class HelioEnv(_EnvBase):
         mask_ratio = float(self.error_mask_ratio) if self.use_error_mask else -1.0
         cc = self._consts_cache
         if (cc is not None and cc[0] is target and cc[1] is self.distance_maps and cc[2] == self.exponential_risk
-                and cc[3] == mask_ratio):
+                and cc[3] == mask_ratio and cc[4].helios is self.noisy_field.heliostat_positions):
             consts = cc[4]                                               # nothing the loss block reads has changed
         else:
             consts = StepConstants(target, tx, self.distance_maps, ideal, self.noisy_field.heliostat_positions,
@@ -242,11 +242,13 @@ class HelioEnv(_EnvBase):
             if make_ctx is not None:     # everything in one call of the compiled binding
                 trig, stride = self.noisy_field._select_trig(self.batch_size)
                 key = self._step_ctx_key
+                nf = self.noisy_field
                 if (key is None or key[0] is not consts or key[1] is not trig or key[2] != ops.splat_variant
-                        or key[3] is not ops.hb):
-                    # constants, errors, forced kernel variant or binding changed: rebind the step context
-                    self._step_ctx = make_ctx(self.noisy_field, trig, stride, consts)
-                    self._step_ctx_key = (consts, trig, ops.splat_variant, ops.hb)
+                        or key[3] is not ops.hb or key[4] is not nf._plane or key[5] is not nf.heliostat_positions):
+                    # constants, errors, forced kernel variant, binding, sigma_scale (a new plane record) or
+                    # the heliostat tensor changed: rebind the step context
+                    self._step_ctx = make_ctx(nf, trig, stride, consts)
+                    self._step_ctx_key = (consts, trig, ops.splat_variant, ops.hb, nf._plane, nf.heliostat_positions)
                 ctx = self._step_ctx
                 if ctx is not None:
                     ticket = ops.next_ticket() if self.check_finite else 0

@@ -224,10 +224,12 @@ class HelioField:
                     trig, stride = self._select_trig(B)
                 ops = self._ops
                 key = self._ctx_key
-                if key is None or key[0] is not trig or key[1] != stride or key[2] != ops.splat_variant or key[3] is not ops.hb:
-                    # rebuilt when the errors, the forced variant or the binding change
+                if (key is None or key[0] is not trig or key[1] != stride or key[2] != ops.splat_variant
+                        or key[3] is not ops.hb or key[4] is not self._plane or key[5] is not self.heliostat_positions):
+                    # rebuilt when the errors, the forced variant, the binding, sigma_scale (a new plane
+                    # record) or the heliostat tensor change
                     self._render_ctx = fast(self, trig, stride)
-                    self._ctx_key = (trig, stride, ops.splat_variant, ops.hb)
+                    self._ctx_key = (trig, stride, ops.splat_variant, ops.hb, self._plane, self.heliostat_positions)
                 ctx = self._render_ctx
                 if ctx is not None:
                     out = ctx.render(sun_position if batched else sun_position.unsqueeze(0), action, monitor)

@@ -1064,3 +1064,43 @@ def test_deferred_finite_check_reports_one_step_late():
     env.check_finite = True
     with torch.no_grad(), pytest.raises(AssertionError):
         env.step(bad)
+
+
+def test_attribute_assignments_reach_the_compiled_contexts():
+    """sigma_scale, the error tensors and heliostat_positions are plain attributes in the reference,
+    read at every render (:340-353, :400): assigning them after a render must take effect although the
+    fast paths bind a compiled context."""
+    from doodle_amd import HelioField, synthetic
+    from doodle_amd.env import HelioEnv
+    f, _, suns, _, act = make_case(N=9, B=4, R=40, seed=6, sigma=0.02)
+    sun_d, act_d = suns.to(DEV), act.to(DEV)
+    first, _ = f.render(sun_d, act_d, None)
+    f.sigma_scale = 0.05
+    second, _ = f.render(sun_d, act_d, None)
+    g, _, _, _, _ = make_case(N=9, B=4, R=40, seed=6, sigma=0.05)
+    want, _ = g.render(sun_d, act_d, None)
+    assert torch.equal(second, want) and not torch.equal(second, first)
+    f.batch_error_angles_mrad = torch.zeros_like(f.batch_error_angles_mrad)
+    g.batch_error_angles_mrad = torch.zeros_like(g.batch_error_angles_mrad)
+    third, _ = f.render(sun_d, act_d, None)
+    assert torch.equal(third, g.render(sun_d, act_d, None)[0]) and not torch.equal(third, second)
+    moved = f.heliostat_positions + torch.tensor([3.0, 0.0, 0.0], device=DEV)
+    f.heliostat_positions = moved
+    g.heliostat_positions = moved.clone()
+    assert torch.equal(f.render(sun_d, act_d, None)[0], g.render(sun_d, act_d, None)[0])
+    # the env: sigma_scale of the noisy field changed between two steps
+    torch.manual_seed(1)
+    hp = torch.rand(5, 3, device=DEV) * 10 + 80
+    hp[:, 2] = 0
+    env = HelioEnv(hp, torch.tensor([0., -5., 0.], device=DEV), (15., 15.), torch.tensor([0., 1., 0.], device=DEV),
+                   sigma_scale=0.05, error_scale_mrad=3.0, resolution=32, batch_size=6, device=DEV)
+    env.reset()
+    a = env.ideal_normals.reshape(6, -1).clone()
+    with torch.no_grad():
+        o1, m1, _ = env.step(a)
+        env.noisy_field.sigma_scale = 0.1
+        o2, m2, _ = env.step(a)
+    assert not torch.equal(o1["img"], o2["img"]) and m1["mse"].item() != m2["mse"].item()
+    a2 = a.clone().requires_grad_(True)
+    o3, m3, _ = env.step(a2)                     # the autograd path reads the field directly
+    assert torch.equal(o3["img"].detach(), o2["img"]) and torch.equal(m3["mse"].detach(), m2["mse"])
