@@ -166,13 +166,14 @@ class HelioEnv(_EnvBase):
         hit = self._ref_cache
         if hit is not None:
             # the same tensor objects, not written to since (this runs on every step): cheap test first
-            sun0, sv, e0, ev, s0, ssv, sig = hit[6]
+            sun0, sv, e0, ev, s0, ssv, sig, h0 = hit[6]
             if (sun0 is self.sun_pos and sv == sun0._version and e0 is errs and (errs is None or ev == errs._version)
-                    and s0 is single and ssv == single._version and sig == self.ref_field.sigma_scale):
+                    and s0 is single and ssv == single._version and sig == self.ref_field.sigma_scale
+                    and h0 is self.ref_field.heliostat_positions):
                 return hit[1:5]
         key = (self.sun_pos.data_ptr(), self.sun_pos._version,
                None if errs is None else (errs.data_ptr(), errs._version), single.data_ptr(), single._version,
-               self.ref_field.sigma_scale)
+               self.ref_field.sigma_scale, self.ref_field.heliostat_positions.data_ptr())
         if self._ref_cache is None or self._ref_cache[0] != key:
             with torch.no_grad():
                 ideal = self.ref_field.calculate_ideal_normals(self.sun_pos)
@@ -181,7 +182,7 @@ class HelioEnv(_EnvBase):
             self._ref_cache = (key, ideal, target, tx, ideal.view([-1, 3]), (errs, single), None)
         self._ref_cache = self._ref_cache[:6] + ((self.sun_pos, self.sun_pos._version, errs,
                                                   None if errs is None else errs._version, single, single._version,
-                                                  self.ref_field.sigma_scale),)
+                                                  self.ref_field.sigma_scale, self.ref_field.heliostat_positions),)
         return self._ref_cache[1:5]
 
     def set_sun_pos(self, sun_positions: torch.Tensor):
