@@ -148,8 +148,10 @@ def cpu_baseline(w, seed, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20000)       # ≈0.13 s at config 2: a 2000-step sample is 13 ms and
-    ap.add_argument("--warmup", type=int, default=2000)       # reads 5-10 % slower (host jitter on a 6 µs step)
+    ap.add_argument("--steps", type=int, default=None,
+                    help="timed steps (default: 20000 at the microsecond-scale configs — a 2000-step sample is 13 ms "
+                         "and reads 5-10 %% slower from host jitter — 50 at cfg4, 10 at cfg5)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed steps first (default: a tenth of --steps)")
     ap.add_argument("--workload", default="cfg2", choices=sorted(synthetic.CONFIGS))
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
@@ -168,6 +170,10 @@ def main():
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed and all-gather even with one rank (testing)")
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = {"cfg4": 50, "cfg5": 10}.get(args.workload, 20000)
+    if args.warmup is None:
+        args.warmup = max(2, args.steps // 10)
 
     # stdout carries the ONE JSON line and nothing else: libraries that print to fd 1 (RCCL's
     # version banner at communicator creation) are sent to stderr for the whole run
