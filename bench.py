@@ -3,30 +3,46 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg4] [--no-cpu]
 
-A "step" is one ``HelioField.render`` forward over one batch of B synthetic sun
-positions (B frames), inputs resident in HBM.  With N>1 (launched by
-``torch.distributed.run``, one rank per GPU) every rank renders its own B-row shard of
-a global batch of N·B suns (weak scaling).  The suns are independent, so the timed loop has
-no data-path collective: the images stay on the rank that rendered them, which is how a
-data-parallel training job consumes them.  The path's one collective — the RCCL all-gather
-of image shards, for a single consumer that wants the whole batch — is timed right after, on
-the same shards, and reported beside `value` as `with_all_gather_every_step` (at config 2 it
-is interconnect-bound by construction: DESIGN.md §5); `--gather-every-step` makes it the
-timed loop instead.  The config-5 shard leg always renders AND gathers (the configuration
-BASELINE names with the all-gather).  Rank 0 prints ONE JSON line.
+A "step" is one ``HelioField.render`` forward over one batch of B synthetic sun positions
+(B frames), inputs resident in HBM.  After the W warm-up steps a time-based preheat runs
+(``--preheat`` seconds of the same call, default 0.5 — disclosed in the line as ``preheat_s``):
+a fresh host path and a GPU coming out of idle run slow for their first ~0.1 s, and a K = 20
+sample is only ≈0.13 ms long.  Then EXACTLY K steps are timed between barrier + synchronize
+fences, MAX over ranks.
 
-Extra objects in the line:
+With N > 1 (``torch.distributed.run``, one rank per GPU) every rank renders its own B-row shard
+of a global batch of N·B suns (weak scaling).  The suns are independent, so the timed loop has no
+data-path collective (``value``); the same loop with the path's one collective — the RCCL
+all-gather of image shards — is timed right after and always reported beside it
+(``with_all_gather_every_step``; at config 2 it is interconnect-bound by construction, DESIGN.md
+§5).  The multi-GPU figure of record of the path AS THE NORTH STAR STATES IT (shard B, all-gather
+the images over xGMI) is ``multi_gpu_of_record``: every rank renders its 512-sun shard of
+BASELINE config 5 (N=5000, R=256, 4096 suns on 8 GPUs) and all ranks gather all images every
+step, the gather of step k overlapping the render of step k+1 on a side stream.  It runs
+unchanged with one rank.  ``collective`` records the transport and the number of ranks RCCL
+itself counts (ncclCommCount).  Rank 0 prints ONE JSON line.
+
+Extra objects in the line (N = 1):
   roofline        the dominant kernel of the run by GPU time: the splat forward at BASELINE
                   config 4 (N=2000, B=512, R=512), timed live with HIP events on the launch
-                  stream (f32 MFMA roofline; the HBM view is given beside it)
+                  stream, ≥ 20 launches (f32 MFMA roofline; the HBM view is given beside it).
+                  ``traffic`` comes from the committed PMC passes (profiles/*_traffic.json) and is
+                  tied to the kernel by name AND by the hash of its source file: a stale entry
+                  is refused (null).
   roofline_bench_workload
                   the (launch-latency-bound) kernel of the timed config-2 loop, same method
+  hbm_bound_kernels
+                  the stages of the path that ARE HBM-bound (the loss block of HelioEnv.step and
+                  the few-ray footprint backward), timed live at B=512, R=512: GB/s and fraction
+                  of the 8 TB/s spec
   cpu_baseline    the oracle (oracle/torch_oracle.py, a CPU PyTorch restatement of the
-                  reference that is bit-identical with it) timed on this host's cores
+                  reference that is bit-identical with it) timed on this host's cores, at the
+                  best thread count of a short sweep
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -42,6 +58,8 @@ from doodle_amd import native, synthetic  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 F32_MFMA_PEAK_TF = 157.3     # dense f32 MFMA = f32 vector peak (spec)
+TRAFFIC_FILES = ("r02_traffic.json", "r01_traffic.json")     # newest first
+KERNEL_SOURCE = {"splat_fwd_mfma_tile": "splat_fwd.hip", "render_fwd_fused_small": "splat_fwd.hip"}
 
 
 def build_field(w, helios, errs, device, max_batch=None):
@@ -76,6 +94,39 @@ def time_kernel(fn, iters, warm=3):
     return e0.elapsed_time(e1) * 1e-3 / iters
 
 
+def preheat(fn, seconds):
+    """Run ``fn`` for ``seconds`` of wall time (at least once when seconds > 0)."""
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        fn()
+
+
+def source_sha16(name):
+    with open(os.path.join(ROOT, "doodle_amd", "csrc", name), "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
+
+
+def measured_traffic(kernel, N, B, R):
+    """→ (HBM bytes per launch, note).  From the committed PMC passes, but only an entry taken
+    for THIS kernel (by name) built from THIS source (hash of its .hip file, recorded with the
+    pass by tools/pmc_traffic.py): bench.py cannot profile itself, and a number measured on other
+    code is not evidence."""
+    key = f"{kernel}@N={N},B={B},R={R}"
+    for name in TRAFFIC_FILES:
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                entry = json.load(f).get(key)
+        except OSError:
+            continue
+        if entry is None:
+            continue
+        want = source_sha16(KERNEL_SOURCE[kernel])
+        if entry.get("source_sha16") != want:
+            return None, f"profiles/{name} holds {key} for source {entry.get('source_sha16')}, the library is built from {want}: stale, refused"
+        return entry.get("hbm_bytes"), f"profiles/{name}, source {want}"
+    return None, "no PMC pass committed for this kernel at this size"
+
+
 def splat_roofline(field, suns, action, iters, variant=None):
     """Roofline entry for the dominant kernel of one render on (field, suns): the fused
     render kernel when the problem takes the single-launch path, else the splat-forward
@@ -94,7 +145,7 @@ def splat_roofline(field, suns, action, iters, variant=None):
         args = (B, N, R, field.heliostat_positions.data_ptr(), suns.data_ptr(), normals.data_ptr(), trig.data_ptr(),
                 stride, field._plane, field._xs.data_ptr(), field._ys.data_ptr(), actual.data_ptr(), None,
                 rays.data_ptr(), image.data_ptr(), var, st)
-        t = time_kernel(lambda: lib.helio_render_fwd(*args), iters)
+        t = time_kernel(lambda: lib.helio_render_fwd(*args), iters, warm=max(3, iters // 10))
         bytes_alg = 4.0 * B * R * R + 32.0 * B * N + 16.0 * B * N + 12.0 * N + 12.0 * B + 8.0 * R
     else:
         kernel = "splat_fwd"
@@ -102,28 +153,21 @@ def splat_roofline(field, suns, action, iters, variant=None):
         t = time_kernel(lambda: lib.helio_splat_fwd(*args), iters)
         bytes_alg = 4.0 * B * R * R + 16.0 * B * N + 8.0 * R   # image store + ray parameters + xs/ys
     flops = 2.0 * B * N * R * R                       # one FMA per (ray, pixel)
+    traffic, note = measured_traffic(kernel if fused else "splat_fwd_mfma_tile", N, B, R)
     return {
         "bound": "mfma", "kernel": kernel, "achieved": round(flops / t / 1e12, 3),
         "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": round(flops / t / 1e12 / F32_MFMA_PEAK_TF, 4),
-        "traffic": measured_traffic(kernel if fused else "splat_fwd_mfma_tile", N, B, R),
-        "kernel_us": round(t * 1e6, 2),
+        "traffic": traffic, "traffic_source": note,
+        "kernel_us": round(t * 1e6, 2), "kernel_launches_timed": iters,
         "hbm_achieved_GBs": round(bytes_alg / t / 1e9, 1), "hbm_frac": round(bytes_alg / t / 1e9 / HBM_PEAK_GBS, 4),
         "algorithmic_bytes": bytes_alg, "algorithmic_flops": flops,
     }
 
 
-def measured_traffic(kernel, N, B, R):
-    """HBM bytes per launch from the committed PMC passes (profiles/r01_traffic.json), or None
-    when no pass was taken for this kernel at this size (bench.py cannot profile itself)."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
-            return json.load(f).get(f"{kernel}@N={N},B={B},R={R}", {}).get("hbm_bytes")
-    except OSError:
-        return None
-
-
-def cpu_baseline(w, seed, budget_s=12.0):
-    """The oracle timed on this host: forward render of the bench workload."""
+def cpu_baseline(w, seed, budget_s=10.0):
+    """The oracle timed on this host: forward render of the bench workload, at the best thread
+    count of a short sweep (a 256-thread host is slower with all its threads than with a few:
+    the reference's ATen kernels are bound by the [M,R,R,3] temporaries, not by arithmetic)."""
     from oracle import torch_oracle as to
     helios, suns, errs, noise = synthetic.make_inputs(w, seed)
     sc = to.Scene.build(helios, synthetic.TARGET_POSITION, synthetic.TARGET_AREA, synthetic.TARGET_NORMAL,
@@ -131,44 +175,61 @@ def cpu_baseline(w, seed, budget_s=12.0):
     ideal = to.ideal_normals(helios, sc.target_position, suns)
     a = ideal + noise
     a = (a / a.norm(dim=2, keepdim=True)).reshape(w.B, -1)
-    with torch.no_grad():
-        to.render(sc, suns, a, errs)                     # warm-up
-        n, t0 = 0, time.perf_counter()
-        while True:
+    threads0 = torch.get_num_threads()
+    ncpu = os.cpu_count() or threads0
+    sweep = {}
+    try:
+        with torch.no_grad():
+            for t in sorted({t for t in (8, 16, 32, 64, 128, threads0) if t <= ncpu}):
+                torch.set_num_threads(t)
+                to.render(sc, suns, a, errs)                     # warm-up at this thread count
+                t0 = time.perf_counter()
+                for _ in range(2):
+                    to.render(sc, suns, a, errs)
+                sweep[t] = round(2 * w.B / (time.perf_counter() - t0), 2)
+            best = max(sweep, key=sweep.get)
+            torch.set_num_threads(best)
             to.render(sc, suns, a, errs)
-            n += 1
-            el = time.perf_counter() - t0
-            if el > budget_s or n >= 40:
-                break
-    return {"value": round(w.B * n / el, 2), "unit": "frames/s", "cores": torch.get_num_threads(),
-            "kind": "port", "host_cpus": os.cpu_count(),
-            "sample": f"{n} forward renders of {w.name} (all {w.B} suns, whole workload), {el:.1f} s"}
+            n, t0 = 0, time.perf_counter()
+            while True:
+                to.render(sc, suns, a, errs)
+                n += 1
+                el = time.perf_counter() - t0
+                if el > budget_s or n >= 60:
+                    break
+    finally:
+        torch.set_num_threads(threads0)
+    return {"value": round(w.B * n / el, 2), "unit": "frames/s", "cores": best,
+            "kind": "port", "host_cpus": ncpu, "thread_sweep_frames_per_s": {str(k): v for k, v in sweep.items()},
+            "sample": f"{n} forward renders of {w.name} (all {w.B} suns, whole workload) at {best} threads, {el:.1f} s"}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None,
-                    help="timed steps (default: 20000 at the microsecond-scale configs — a 2000-step sample is 13 ms "
-                         "and reads 5-10 %% slower from host jitter — 50 at cfg4, 10 at cfg5)")
+                    help="timed steps (default: 20000 at the microsecond-scale configs, 50 at cfg4, 10 at cfg5)")
     ap.add_argument("--warmup", type=int, default=None, help="untimed steps first (default: a tenth of --steps)")
+    ap.add_argument("--preheat", type=float, default=0.5,
+                    help="seconds of untimed calls between the warm-up steps and the timed steps (disclosed as preheat_s)")
     ap.add_argument("--workload", default="cfg2", choices=sorted(synthetic.CONFIGS))
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-large", action="store_true", help="skip the config-4 roofline leg")
     ap.add_argument("--no-extras", action="store_true",
-                    help="skip the secondary legs (fwd+bwd, env.step, config-5 shard): used for profiling runs "
-                         "so that every kernel in the trace belongs to one workload")
+                    help="skip the secondary legs (fwd+bwd, env.step, HBM-bound kernels, config-5 shard): used for "
+                         "profiling runs so that every kernel in the trace belongs to one workload")
     ap.add_argument("--mode", default="fwd", choices=["fwd", "fwdbwd"])
     ap.add_argument("--overlap", action="store_true",
-                    help="run the all-gather on a side stream (pays for steps of milliseconds — the config-5 "
-                         "shard leg uses it; at config 2 the cross-stream events cost more than they hide: "
-                         "35 vs 14 µs per step measured with one rank)")
+                    help="config-2 loops: run the all-gather on a side stream (pays for steps of milliseconds; at "
+                         "config 2 the cross-stream events cost more than they hide)")
     ap.add_argument("--gather-every-step", action="store_true",
                     help="all-gather the images inside the timed loop (default: images stay on their rank; the "
                          "gathered loop is timed afterwards and reported as with_all_gather_every_step)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed and all-gather even with one rank (testing)")
+    ap.add_argument("--cfg5-suns", type=int, default=512, help="suns per GPU of the config-5 leg (BASELINE: 4096 / 8)")
+    ap.add_argument("--cfg5-steps", type=int, default=20)
     args = ap.parse_args()
     if args.steps is None:
         args.steps = {"cfg4": 50, "cfg5": 10}.get(args.workload, 20000)
@@ -233,10 +294,6 @@ def main():
             gather.gather(img.detach(), gathered[stepno[0] & 1], overlap=args.overlap)
             stepno[0] += 1
 
-    gather_now = [bool(args.gather_every_step)]
-    for _ in range(args.warmup):
-        step()
-
     def fence():
         if gather is not None:
             gather.wait()
@@ -244,9 +301,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    gather_now = [bool(args.gather_every_step)]
+    for _ in range(args.warmup):
+        step()
+    preheat(step, args.preheat)            # disclosed (preheat_s): host path and GPU clocks at steady state
     fence()
     if args.mode == "fwd" and not gather_now[0]:
-        # the timed loop proper: K calls of HelioField.render and nothing else (config 2 is ≈5.3 µs of
+        # the timed loop proper: K calls of HelioField.render and nothing else (config 2 is ≈5 µs of
         # GPU per call, so a closure call and a no_grad() enter/exit per step would be ≈15 % of it)
         import gc
         render, K = field.render, args.steps
@@ -275,12 +336,13 @@ def main():
 
     # the same shards with the other treatment of the images (gathered every step / left on their
     # rank): at config 2 the gathered loop is bound by delivering (N-1) x 1.64 MB to every rank per
-    # step, DESIGN.md §5 — reported beside `value`, never instead of it
+    # step, DESIGN.md §5 — always reported beside `value`, never instead of it
     el_other = None
-    if gather is not None and (world > 1 or args.force_dist):
+    if gather is not None:
         gather_now[0] = not gather_now[0]
         for _ in range(min(args.warmup, 50)):
             step()
+        preheat(step, min(args.preheat, 0.2))
         fence()
         t0 = time.perf_counter()
         for _ in range(args.steps):
@@ -291,12 +353,12 @@ def main():
         el_other = float(t.item())
         gather_now[0] = not gather_now[0]
 
-    # secondary weak-scaling point on EVERY rank (collective): a config-5-like shard, where
-    # compute (ms) dominates the all-gather — see DESIGN.md §5
+    # the multi-GPU figure of record, on EVERY rank (collective): the real per-GPU shard of BASELINE
+    # config 5, rendered AND all-gathered every step — see DESIGN.md §5
     shard = None
     if not args.no_large and not args.no_extras:
         try:
-            shard = cfg5_shard_leg(dev, rank, world, gather, dist, args.seed)
+            shard = cfg5_shard_leg(dev, rank, world, gather, dist, args.seed, args.cfg5_suns, args.cfg5_steps)
         except Exception as e:  # noqa: BLE001
             shard = {"error": repr(e)}
 
@@ -304,7 +366,7 @@ def main():
         frames = world * w.B * args.steps
         out = {
             "metric": "HelioField.render frames/sec", "value": round(frames / el, 1), "unit": "frames/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "preheat_s": args.preheat,
             "ms_per_step": round(el / args.steps * 1e3, 5), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{w.name} {'forward' if args.mode == 'fwd' else 'forward+backward'} "
@@ -313,19 +375,27 @@ def main():
                        "global_batch": world * w.B, "parallelism": f"sun-batch sharded x{world}"
                        + ((f", RCCL all-gather of images every step ({gather.transport} transport, "
                            f"{'side stream' if args.overlap else 'stream-ordered'})") if (gather is not None and args.gather_every_step)
-                          else (", no data-path collective (images stay on the rank that rendered them)" if world > 1 else ""))},
+                          else (", no data-path collective (images stay on the rank that rendered them)" if world > 1 else "")),
+                       "timing": f"{args.warmup} warm-up steps, {args.preheat} s time-based preheat (untimed), then "
+                                 f"{args.steps} timed steps between barrier + synchronize fences, max over ranks"},
         }
+        if dist is not None:
+            out["collective"] = {
+                "transport": gather.transport if gather is not None else None,
+                "rccl_ranks": gather.rccl_ranks if gather is not None else None,       # ncclCommCount of the communicator
+                "torch_distributed_backend": dist.get_backend(), "world_size": dist.get_world_size()}
         if el_other is not None:
             key = "without_all_gather" if args.gather_every_step else "with_all_gather_every_step"
             out[key] = {"frames_per_s": round(frames / el_other, 1), "ms_per_step": round(el_other / args.steps * 1e3, 5),
+                        "MB_received_per_rank_and_step": round((world - 1) * w.B * w.R * w.R * 4 / 1e6, 2),
                         "note": ("same shards, images left on the rank that rendered them" if args.gather_every_step else
                                  f"same shards, every image delivered to every rank each step ({gather.transport} transport): "
                                  "interconnect-bound at this frame size, DESIGN.md §5")}
         if gather_error is not None:
             out["all_gather_error"] = gather_error
         if shard is not None:
-            out["weak_scaling_config5_shard"] = shard
-        iters = 200 if w.B * w.N * w.R * w.R < 1e10 else 10
+            out["multi_gpu_of_record"] = shard
+        iters = 2000 if w.B * w.N * w.R * w.R < 1e10 else 20
         small = splat_roofline(field, suns_d, action.detach(), iters)
         small["workload"] = w.name
         out["roofline"] = small
@@ -344,6 +414,10 @@ def main():
                     out["extras"] = extras_leg(field, suns_d, action.detach(), w, dev)
                 except Exception as e:  # noqa: BLE001
                     out["extras"] = {"error": repr(e)}
+                try:
+                    out["hbm_bound_kernels"] = hbm_leg(dev)
+                except Exception as e:  # noqa: BLE001
+                    out["hbm_bound_kernels"] = {"error": repr(e)}
             if not args.no_cpu:
                 out["cpu_baseline"] = cpu_baseline(w, args.seed)
                 out["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
@@ -362,9 +436,7 @@ def extras_leg(field, suns_d, action, w, dev):
     from doodle_amd.env import HelioEnv
 
     def wall(fn, n, repeats=3):
-        t0 = time.perf_counter()
-        while time.perf_counter() - t0 < 0.2:      # a fresh Python path runs slow for its first ~0.1 s
-            fn()
+        preheat(fn, 0.2)                            # a fresh Python path runs slow for its first ~0.1 s
         best = float("inf")
         for _ in range(repeats):
             torch.cuda.synchronize()
@@ -383,6 +455,15 @@ def extras_leg(field, suns_d, action, w, dev):
         torch.autograd.grad((img * G).sum() + actual.sum(), a)
 
     t_fb = wall(fwdbwd, 300)
+    out = {"render_fwd_bwd_frames_per_s": round(w.B / t_fb, 1), "render_fwd_bwd_us": round(t_fb * 1e6, 1)}
+    vg = getattr(field, "render_value_and_grad", None)
+    if vg is not None:
+        # config 3 without the autograd engine: render + the gradient for GIVEN cotangents of (image,
+        # actual) in one binding call (two C-ABI calls) — what an optimiser that supplies dL/dimage needs
+        ones = torch.ones((w.B, w.N, 3), device=dev)
+        t_vg = wall(lambda: vg(suns_d, action, G, ones), 300)
+        out["render_value_and_grad_us"] = round(t_vg * 1e6, 1)
+        out["render_value_and_grad_frames_per_s"] = round(w.B / t_vg, 1)
     env = HelioEnv(field.heliostat_positions, torch.tensor(synthetic.TARGET_POSITION, device=dev), synthetic.TARGET_AREA,
                    torch.tensor(synthetic.TARGET_NORMAL, device=dev), sigma_scale=w.sigma_scale,
                    error_scale_mrad=w.error_scale_mrad, resolution=w.R, batch_size=w.B, device=dev)
@@ -397,79 +478,152 @@ def extras_leg(field, suns_d, action, w, dev):
         a.grad = None
 
     t_sb = wall(step_bwd, 300)
-    return {"render_fwd_bwd_frames_per_s": round(w.B / t_fb, 1), "render_fwd_bwd_us": round(t_fb * 1e6, 1),
-            "env_step_fwd_frames_per_s": round(w.B / t_step, 1), "env_step_fwd_us": round(t_step * 1e6, 1),
-            "env_step_fwd_bwd_us": round(t_sb * 1e6, 1),
-            "note": "config 3 = render + autograd.grad of (img*G).sum()+actual.sum(); env.step = render + loss "
-                    "block (2 launches) + NaN/Inf check (one wait on a pinned host record); fwd_bwd adds "
-                    "metrics['dist'].backward(); best of 3 wall-clock loops through the Python surface"}
+    out.update({
+        "env_step_fwd_frames_per_s": round(w.B / t_step, 1), "env_step_fwd_us": round(t_step * 1e6, 1),
+        "env_step_fwd_bwd_us": round(t_sb * 1e6, 1),
+        "note": "config 3 = render + autograd.grad of (img*G).sum()+actual.sum(); env.step = render + loss "
+                "block (2 launches) + NaN/Inf check (one wait on a pinned host record); fwd_bwd adds "
+                "metrics['dist'].backward(); best of 3 wall-clock loops through the Python surface"})
+    return out
 
 
-def cfg5_shard_leg(dev, rank, world, gather, dist, seed, b_local=256, steps=8):
-    """Every rank renders its own ``b_local``-sun shard of BASELINE config 5 (N=5000, R=256) and the
-    ranks all-gather the images; whole-job frames/s.  Compute per step ≈ ms, so this is the
-    regime in which the sun-batch sharding scales; config 2 (the headline) is gather-bound."""
+def hbm_leg(dev, B=512, N=2000, R=512, iters=20):
+    """The stages of the path that ARE HBM-bound, timed live (HIP events, ``iters`` launches each):
+    the loss block of HelioEnv.step (test_environment.py:436-457: 12 B per pixel read once) forward
+    and backward, and the few-ray footprint backward (the reference's TTT sweeps run N = 1) alone and
+    with the loss adjoint formed on the fly.  GB/s of algorithmic bytes against the 8 TB/s spec."""
+    import ctypes
+    from doodle_amd.losses import StepConstants
+    g = torch.Generator(device=dev).manual_seed(0)
+    img, target, dm = (torch.rand(B, R, R, device=dev, generator=g) for _ in range(3))
+    unit = lambda t: t / t.norm(dim=-1, keepdim=True)  # noqa: E731
+    ideal = unit(torch.rand(B, N, 3, device=dev, generator=g))
+    actual = unit(ideal + 0.01 * torch.rand(B, N, 3, device=dev, generator=g))
+    action = unit(ideal + 0.1 * torch.rand(B, N, 3, device=dev, generator=g))
+    helios = torch.rand(N, 3, device=dev, generator=g) * 10 + 80
+    f3 = ctypes.c_float * 3
+    c = StepConstants(target, target.amax((1, 2)).clamp_min(1e-6), dm, ideal, helios, f3(0, -5, 0), f3(0, 1, 0), 15.0, 15.0, False)
+    ops = native.get_ops()
+    one = torch.ones((), device=dev)
+
+    def entry(t, nbytes, what):
+        return {"us": round(t * 1e6, 1), "GBs": round(nbytes / t / 1e9, 1), "frac": round(nbytes / t / 1e9 / HBM_PEAK_GBS, 4),
+                "algorithmic_bytes": nbytes, "bytes": what}
+
+    out = {"workload": f"B={B}, N={N}, R={R}", "peak_GBs": HBM_PEAK_GBS, "launches_timed": iters}
+    t = time_kernel(lambda: ops.step_losses_fwd(img, actual, action, c), iters)
+    out["step_losses_fwd"] = entry(t, 12.0 * B * R * R + 48.0 * B * N, "img + target + distance map read once, 48 B per ray")
+    t = time_kernel(lambda: ops.step_losses_bwd(img, actual, action, c, one, one, one, one, None, True, True, True), iters)
+    out["step_losses_bwd"] = entry(t, 16.0 * B * R * R + 60.0 * B * N, "the same + the image cotangent written")
+    Nf = 1
+    rays = (torch.rand(B, Nf, 4, device=dev, generator=g) * torch.tensor([10., 10., 0.5, 0.01], device=dev)
+            - torch.tensor([5., 5., 0., 0.], device=dev))
+    xs = torch.linspace(-7.5, 7.5, R, device=dev)
+    ys = xs.clone()
+    Gi = torch.randn(B, R, R, device=dev, generator=g)
+    t = time_kernel(lambda: ops.splat_bwd(rays, xs, ys, Gi, variant=4), iters)
+    out["splat_bwd_few(N=1)"] = entry(t, 4.0 * B * R * R, "the image cotangent read once")
+    lib = ops.lib
+    mom = torch.empty(B, lib.helio_splat_bwd_blocks(R), Nf, 5, device=dev)
+    grad = torch.empty(B, Nf, 3, device=dev)
+    plane = native.Plane()
+    plane.origin[:], plane.normal[:], plane.u[:], plane.v[:], plane.w[:] = (0, -5, 0), (0, 1, 0), (1, 0, 0), (0, 0, 1), (0, -1, 0)
+    plane.sigma_scale = 0.01
+    sun = torch.rand(B, 3, device=dev, generator=g) * 1e4
+    act1 = unit(torch.rand(B, Nf, 3, device=dev, generator=g))
+    trig = torch.tensor([1., 0., 1., 0.], device=dev).repeat(B, Nf, 1).contiguous()
+    ideal1 = unit(torch.rand(B, Nf, 3, device=dev, generator=g))
+    h1 = helios[:Nf].contiguous()
+
+    def fused():
+        native._check(lib, lib.helio_env_step_bwd(
+            B, Nf, R, h1.data_ptr(), sun.data_ptr(), act1.data_ptr(), trig.data_ptr(), 4 * Nf, plane, rays.data_ptr(),
+            xs.data_ptr(), ys.data_ptr(), img.data_ptr(), target.data_ptr(), c.tx.data_ptr(), dm.data_ptr(),
+            ideal1.data_ptr(), c.tp, c.tn, 15.0, 15.0, 0, None, one.data_ptr(), None, None, None, None, None, None,
+            mom.data_ptr(), grad.data_ptr(), 0, native._stream()))
+
+    t = time_kernel(fused, iters)
+    out["env_step_bwd_few_ray(N=1)"] = entry(t, 12.0 * B * R * R, "img + target + distance map read once (2 launches)")
+    return out
+
+
+def cfg5_shard_leg(dev, rank, world, gather, dist, seed, b_local=512, steps=20):
+    """Every rank renders its own ``b_local``-sun shard of BASELINE config 5 (N=5000, R=256; 512 per
+    GPU = 4096 over 8 GPUs) and ALL ranks gather ALL images every step; whole-job frames/s.  The
+    gather of step k runs on a side stream and overlaps the render of step k+1 (two output buffers,
+    two-deep back-pressure).  Compute per step ≈ 2.6 ms against 134 MB sent per rank."""
     w5 = synthetic.CONFIGS["cfg5"]
     w = synthetic.Workload(w5.name, w5.N, b_local, w5.R, w5.sigma_scale, w5.error_scale_mrad, w5.span)
     helios, suns, errs, noise = synthetic.make_inputs(w, seed, b_offset=rank * b_local, b_count=b_local)
     field = build_field(w, helios, errs, dev)
     suns_d = suns.to(dev)
     action = make_action(field, suns_d, noise)
-    out = torch.empty((world * b_local, w.R, w.R), dtype=torch.float32, device=dev) if gather is not None else None
+    if gather is None and dist is None:
+        # one process, no process group: the gather degenerates to what an all-gather over one rank
+        # does, a device copy of the shard into the output buffer — the leg runs unchanged
+        from doodle_amd.comm import ImageGather
+        gather = ImageGather()
+    out = None
+    if gather is not None:
+        out = [torch.empty((world * b_local, w.R, w.R), dtype=torch.float32, device=dev) for _ in range(2)]
+    overlap = gather is not None and gather.transport == "rccl"
 
     def step():
         with torch.no_grad():
             img, _ = field.render(suns_d, action, None)
         if gather is not None:
-            # side stream: the gather of this step's images (67 MB per rank) overlaps the next render
-            gather.gather(img, out[step.k & 1], overlap=gather.transport == "rccl")
+            gather.gather(img, out[step.k & 1], overlap=overlap)
             step.k += 1
 
     step.k = 0
-    if gather is not None:
-        out = [out, torch.empty_like(out)]
+
+    def fence():
+        if gather is not None:
+            gather.wait()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
     for _ in range(3):
         step()
-    if gather is not None:
-        gather.wait()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
+    fence()
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
-    if gather is not None:
-        gather.wait()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
+    fence()
     el = time.perf_counter() - t0
     if dist is not None:
         t = torch.tensor([el], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
-    return {"workload": f"N={w.N}, R={w.R}, {b_local} suns per GPU", "n_gpus": world,
+    return {"workload": f"BASELINE config 5 shard: N={w.N}, R={w.R}, {b_local} suns per GPU "
+                        f"(global batch {world * b_local}), render + all-gather of all images every step",
+            "n_gpus": world, "steps": steps, "warmup": 3,
             "frames_per_s": round(world * b_local * steps / el, 1), "ms_per_step": round(el / steps * 1e3, 3),
-            "gathered_MB_per_rank_and_step": round(world * b_local * w.R * w.R * 4 / 1e6, 1)}
+            "collective": (f"{gather.transport} all-gather, {'side stream, overlapped with the next render' if overlap else 'stream-ordered'}"
+                           if gather is not None else "none (the communicator could not be created)"),
+            "rccl_ranks": gather.rccl_ranks if gather is not None else None,
+            "MB_sent_per_rank_and_step": round(b_local * w.R * w.R * 4 / 1e6, 1),
+            "MB_received_per_rank_and_step": round((world - 1) * b_local * w.R * w.R * 4 / 1e6, 1)}
 
 
-def large_leg(dev, seed):
+def large_leg(dev, seed, iters=20):
     """Splat-forward roofline and whole-render rate at BASELINE config 4."""
     w = synthetic.CONFIGS["cfg4"]
     helios, suns, errs, noise = synthetic.make_inputs(w, seed)
     field = build_field(w, helios, errs, dev)
     suns_d = suns.to(dev)
     action = make_action(field, suns_d, noise)
-    r = splat_roofline(field, suns_d, action, iters=5)
+    r = splat_roofline(field, suns_d, action, iters=iters)
     with torch.no_grad():
-        for _ in range(2):
+        for _ in range(3):
             field.render(suns_d, action, None)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(5):
+        for _ in range(iters):
             field.render(suns_d, action, None)
         torch.cuda.synchronize()
-        el = (time.perf_counter() - t0) / 5
+        el = (time.perf_counter() - t0) / iters
     # the opt-in split-bf16 kernel (HELIO_SPLAT_VARIANT=7) on the same rays, beside the exact-f32 default:
     # never the roofline entry above, reported so that its speed and its accuracy can be judged together
     try:
@@ -487,7 +641,7 @@ def large_leg(dev, seed):
         for v, name in ((7, "two_level"), (8, "one_level")):
             args = (w.B, w.N, w.R, rays.data_ptr(), field._xs.data_ptr(), field._ys.data_ptr(), split.data_ptr(), v,
                     native._stream())
-            t7 = time_kernel(lambda: ops.lib.helio_splat_fwd(*args), 5)
+            t7 = time_kernel(lambda: ops.lib.helio_splat_fwd(*args), iters)
             rel = ((split - exact).abs() / exact.clamp_min(1e-6 * exact.max())).max().item()
             r["split_bf16_kernel"][name] = {
                 "variant": v, "kernel_us": round(t7 * 1e6, 2),
@@ -500,6 +654,7 @@ def large_leg(dev, seed):
     r["workload"] = w.name + f", span={w.span} m, sigma_scale={w.sigma_scale}"
     r["render_frames_per_s"] = round(w.B / el, 1)
     r["render_ms"] = round(el * 1e3, 3)
+    r["render_calls_timed"] = iters
     fwd_bytes = 4.0 * w.B * w.R * w.R + 32.0 * w.B * w.N + 12.0 * w.N + 12.0 * w.B
     r["render_hbm_GBs"] = round(fwd_bytes / el / 1e9, 1)
     r["render_hbm_frac"] = round(fwd_bytes / el / 1e9 / HBM_PEAK_GBS, 4)

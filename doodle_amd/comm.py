@@ -21,7 +21,8 @@ import torch.distributed as dist
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 COMM_LIB_PATH = os.path.join(_HERE, "libhelio_comm.so")
-COMM_EXPORTS = ("helio_comm_unique_id", "helio_comm_init", "helio_comm_allgather_f32", "helio_comm_destroy")
+COMM_EXPORTS = ("helio_comm_unique_id", "helio_comm_init", "helio_comm_allgather_f32", "helio_comm_count",
+                "helio_comm_destroy")
 _ID_BYTES = 128
 _lib = None
 
@@ -37,6 +38,8 @@ def load_comm_library(path: str = COMM_LIB_PATH) -> ctypes.CDLL:
         lib.helio_comm_init.argtypes, lib.helio_comm_init.restype = [ctypes.POINTER(vp), i, i, ctypes.c_char_p, i], i
         lib.helio_comm_allgather_f32.argtypes, lib.helio_comm_allgather_f32.restype = [vp, vp, vp, l, vp], i
         lib.helio_comm_destroy.argtypes, lib.helio_comm_destroy.restype = [vp], i
+        lib.helio_comm_count.argtypes = [vp, ctypes.POINTER(i), ctypes.POINTER(i)]
+        lib.helio_comm_count.restype = i
         _lib = lib
     return _lib
 
@@ -126,6 +129,18 @@ class ImageGather:
         self._done[k].record(self.stream)
         self._issued += 1
         return out
+
+    @property
+    def rccl_ranks(self):
+        """Ranks in the RCCL communicator as RCCL itself counts them (ncclCommCount); None on the
+        torch.distributed transport."""
+        if self.comm is None:
+            return None
+        n, r = ctypes.c_int(), ctypes.c_int()
+        if self._libc.helio_comm_count(self.comm, ctypes.byref(n), ctypes.byref(r)) != 0:
+            raise RuntimeError("ncclCommCount failed")
+        assert r.value == self.rank
+        return n.value
 
     def wait(self):
         """Make the current stream wait for every gather enqueued with ``overlap=True``."""

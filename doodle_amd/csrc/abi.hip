@@ -17,6 +17,7 @@ void launch_geometry_bwd(int, int, int, const float*, const float*, const float*
                          const helio_plane*, const float*, const float*, const float*, float*, hipStream_t);
 void launch_ideal_normals(int, int, const float*, const float*, const float*, float*, hipStream_t);
 void launch_error_trig(long, const float*, float*, hipStream_t);
+void launch_init_actions(long, const float*, const float*, float, float*, hipStream_t);
 int launch_splat_fwd(int, int, int, const float*, const float*, const float*, float*, int, hipStream_t);
 int launch_splat_bwd(int, int, int, const float*, const float*, const float*, const float*, float*, int, hipStream_t);
 int splat_bwd_blocks(int);
@@ -208,6 +209,14 @@ int helio_ideal_normals(int B, int N, const float* helios_d, const float* sun_d,
     if (!helios_d || !sun_d || !target_position || !out_d) return fail(HELIO_E_INVALID, "ideal_normals: null pointer");
     helio::launch_ideal_normals(B, N, helios_d, sun_d, target_position, out_d, static_cast<hipStream_t>(stream));
     return after_launch("ideal_normals");
+}
+
+int helio_init_actions(long M, const float* ideal_d, const float* noise_d, float noise_scale, float* out_d,
+                       void* stream) {
+    if (M < 1 || M > (1l << 31) / 4) return fail(HELIO_E_INVALID, "init_actions: bad size M=%ld", M);
+    if (!ideal_d || !noise_d || !out_d) return fail(HELIO_E_INVALID, "init_actions: null pointer");
+    helio::launch_init_actions(M, ideal_d, noise_d, noise_scale, out_d, static_cast<hipStream_t>(stream));
+    return after_launch("init_actions");
 }
 
 long helio_distance_maps_workspace(int B, int R) {

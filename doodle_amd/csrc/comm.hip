@@ -42,6 +42,13 @@ int helio_comm_allgather_f32(void* comm, const float* send_d, float* recv_d, lon
     return r == ncclSuccess ? HELIO_OK : HELIO_E_LAUNCH;
 }
 
+int helio_comm_count(void* comm, int* nranks, int* rank) {
+    if (!comm || !nranks || !rank) return HELIO_E_INVALID;
+    ncclComm_t c = static_cast<ncclComm_t>(comm);
+    if (ncclCommCount(c, nranks) != ncclSuccess || ncclCommUserRank(c, rank) != ncclSuccess) return HELIO_E_LAUNCH;
+    return HELIO_OK;
+}
+
 int helio_comm_destroy(void* comm) {
     if (!comm) return HELIO_E_INVALID;
     return ncclCommDestroy(static_cast<ncclComm_t>(comm)) == ncclSuccess ? HELIO_OK : HELIO_E_LAUNCH;

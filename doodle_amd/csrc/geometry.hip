@@ -134,6 +134,16 @@ ideal_normals_kernel(int B, int N, const float* __restrict__ helios, const float
     }
 }
 
+// init_actions, :293-303: noisy = ideal + randn_like(ideal) * noise (multiply, then add, each rounded),
+// then noisy / norm(noisy).clamp_min(1e-9)
+__global__ void __launch_bounds__(256)
+init_actions_kernel(long M, const float* ideal, const float* noise, float scale, float* out) {
+    for (long m = (long)blockIdx.x * blockDim.x + threadIdx.x; m < M; m += (long)gridDim.x * blockDim.x) {
+        const vec3 v = add3(ld3(ideal + 3 * m), scale3(scale, ld3(noise + 3 * m)));
+        st3(out + 3 * m, unit3(v));
+    }
+}
+
 // (cos_e, sin_e, cos_u, sin_u) of the error angles, :87-91: angle = err_mrad * 1e-3 (fp32), then
 // the precise ocml sinf/cosf — the same device functions torch's own cos/sin kernels call.
 __global__ void __launch_bounds__(256)
@@ -183,6 +193,10 @@ void launch_geometry_bwd_losses(int B, int N, int n_blocks, const float* helios,
 
 void launch_error_trig(long M, const float* errs, float* trig, hipStream_t st) {
     hipLaunchKernelGGL(error_trig_kernel, dim3(ray_grid(M)), dim3(256), 0, st, M, errs, trig);
+}
+
+void launch_init_actions(long M, const float* ideal, const float* noise, float scale, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(init_actions_kernel, dim3(ray_grid(M)), dim3(256), 0, st, M, ideal, noise, scale, out);
 }
 
 void launch_ideal_normals(int B, int N, const float* helios, const float* sun, const float* target,

@@ -36,6 +36,47 @@ namespace helio {
 
 __device__ __forceinline__ float exp2_fast(float x) { return __builtin_amdgcn_exp2f(x); }
 
+// In-kernel stamps of the fused small-problem kernel: ONLY in the diagnostic library
+// (tools/build_diag.py compiles this file with -DHELIO_STAMPS into libhelio_diag.so, never into
+// libhelio.so).  A stamp is s_memtime (shader cycles) kept in scalar registers; lane 0 of every wave
+// writes its stamps once, at the end, to a buffer nothing else reads (cdna_hip_programming.md §7).
+#ifdef HELIO_STAMPS
+__device__ unsigned long long* g_stamps = nullptr;        // [workgroup][wave][HELIO_NSTAMP]
+#define HELIO_NSTAMP 10
+#define HSTAMP_DECL unsigned long long stamp_[HELIO_NSTAMP] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define HSTAMP(k)                                                                                   \
+    do {                                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                          \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_[k]) :: "memory");       \
+        __builtin_amdgcn_sched_barrier(0);                                                          \
+    } while (0)
+#define HSTAMP_VM(k)      /* the same after every outstanding vector-memory operation of the wave */ \
+    do {                                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                          \
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_[k]) :: "memory"); \
+        __builtin_amdgcn_sched_barrier(0);                                                          \
+    } while (0)
+#define HSTAMP_REAL(k)                                                                              \
+    do {                                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                          \
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_[k]) :: "memory");   \
+        __builtin_amdgcn_sched_barrier(0);                                                          \
+    } while (0)
+#define HSTAMP_FLUSH()                                                                              \
+    do {                                                                                            \
+        if (g_stamps && (threadIdx.x & 63) == 0) {                                                  \
+            unsigned long long* o_ = g_stamps + (((long)blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6)) * HELIO_NSTAMP; \
+            for (int k_ = 0; k_ < HELIO_NSTAMP; ++k_) o_[k_] = stamp_[k_];                          \
+        }                                                                                           \
+    } while (0)
+#else
+#define HSTAMP_DECL
+#define HSTAMP(k)
+#define HSTAMP_VM(k)
+#define HSTAMP_REAL(k)
+#define HSTAMP_FLUSH()
+#endif
+
 // ----------------------------------------------------------------------------------------------
 // VALU variant
 // ----------------------------------------------------------------------------------------------
@@ -424,6 +465,9 @@ render_fwd_fused_small(int B, int N, int R, const float* __restrict__ helios, co
     const int tiles_j = (R + 63) / 64;
     const int b = blockIdx.y;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    HSTAMP_DECL;
+    HSTAMP_REAL(8);
+    HSTAMP(0);
     const vec3 s = ld3(sun + 3l * b);
 
     if constexpr (LOSS) {
@@ -467,6 +511,7 @@ render_fwd_fused_small(int B, int N, int R, const float* __restrict__ helios, co
     const bool writer = !LOSS && blockIdx.x == 0;
 
     const float xv = xs[min(i0 + lr, R - 1)], yv = ys[min(j0 + lr, R - 1)];
+    HSTAMP_VM(1);
     // LOSS: this lane's 16 target / distance-map pixels, in flight during the heliostat loop
     float tgt[16], dmp[16];
     if constexpr (LOSS) {
@@ -495,7 +540,9 @@ render_fwd_fused_small(int B, int N, int R, const float* __restrict__ helios, co
             if (tid < NC && n < N) {
                 const long m = (long)b * N + n;
                 const float4 tg = *reinterpret_cast<const float4*>(trig + (long)b * trig_b_stride + 4l * n);
-                const Ray q = trace(ld3(action + 3 * m), tg.x, tg.y, tg.z, tg.w, ld3(helios + 3l * n), s, P);
+                const vec3 av = ld3(action + 3 * m), hv = ld3(helios + 3l * n);
+                HSTAMP_VM(2);
+                const Ray q = trace(av, tg.x, tg.y, tg.z, tg.w, hv, s, P);
                 const float sk = __builtin_sqrtf(q.k2);
                 v = make_float4(q.a * sk, q.b * sk, sk, q.c2 * q.k2);   // LDS copy pre-scaled (2 VALU + exp per factor)
                 if (writer) {
@@ -505,8 +552,10 @@ render_fwd_fused_small(int B, int N, int R, const float* __restrict__ helios, co
                 }
             }
             sRay[tid] = v;
+            HSTAMP(3);
         }
         __syncthreads();
+        HSTAMP(4);
         const int cnt = min(NC, N - n0);
         float4 q0 = sRay[lh], q1 = sRay[2 + lh];
         for (int k = 0; k < cnt; k += 4) {
@@ -526,7 +575,12 @@ render_fwd_fused_small(int B, int N, int R, const float* __restrict__ helios, co
 #pragma unroll
         for (int e = 0; e < 16; ++e) { acc[e] = 0.0f; acc2[e] = 0.0f; }
     }
+    HSTAMP(5);
     store_block(image + (long)b * R * R, R, i0, j0, lr, lh, tot);
+    HSTAMP(6);
+    HSTAMP_VM(7);
+    HSTAMP_REAL(9);
+    HSTAMP_FLUSH();
     if constexpr (LOSS) {
         const float sc = L.tx[b];
         const int j = j0 + lr;
@@ -552,6 +606,16 @@ render_fwd_fused_small(int B, int N, int R, const float* __restrict__ helios, co
         }
     }
 }
+
+#ifdef HELIO_STAMPS
+}  // namespace helio
+// diagnostic library only: point the stamp buffer of the fused kernel at `stamps_d`
+// ([workgroups][4 waves][10] 64-bit words; NULL switches the flush off)
+extern "C" int helio_diag_set_stamps(unsigned long long* stamps_d) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(helio::g_stamps), &stamps_d, sizeof(stamps_d)) == hipSuccess ? 0 : -1;
+}
+namespace helio {
+#endif
 
 // true when launch_render_fwd() would take the single-launch path
 bool render_is_fused(int B, int N, int R) {

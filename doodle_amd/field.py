@@ -10,6 +10,8 @@ compute methods raise ``RuntimeError``.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import native
@@ -103,6 +105,7 @@ class HelioField:
         self._ys = torch.linspace(-self.target_height / 2, self.target_height / 2, self.resolution).to(self.device)
 
         self._trig_cache = {}
+        self._device_trig = os.environ.get("HELIO_DEVICE_TRIG", "0") == "1"
         self._ray_ws = None
         self._fast_render = None      # ops.render_context once resolved (False: compiled binding absent)
         self._render_ctx, self._ctx_key, self._ops = None, None, None
@@ -119,6 +122,15 @@ class HelioField:
         self._sigma_scale = float(value)
         self._plane = native.Plane(*self._plane_vectors, self._sigma_scale)
 
+    @property
+    def device_trig(self) -> bool:
+        return self._device_trig
+
+    @device_trig.setter
+    def device_trig(self, value: bool) -> None:
+        self._device_trig = bool(value)
+        self._trig_cache.clear()            # tables of the other kind are not reused
+
     # ------------------------------------------------------------------ errors
     def reset_errors(self) -> None:
         """Re-draw both error tensors (:220-239); same RNG call order as the reference."""
@@ -128,19 +140,27 @@ class HelioField:
             self.batch_error_angles_mrad = self._sample_error_angles(self.max_batch_size)
         else:
             self.batch_error_angles_mrad = None
+        # the trig tables of the new errors, now: the one host round trip of device-sampled errors
+        # belongs to reset_errors(), not to the first render after it (which may be under graph capture)
+        self._cached_trig("single", self.error_angles_mrad)
+        if self.batch_error_angles_mrad is not None:
+            self._cached_trig("batch", self.batch_error_angles_mrad)
 
     def _sample_error_angles(self, batch_size: int) -> torch.Tensor:
         """[batch_size, N, 2] fresh error angles in mrad (:243-252)."""
         return torch.randn(batch_size, self.num_heliostats, 2, device=self.device) * self.error_scale_mrad
 
     def _trig_of(self, errs: torch.Tensor) -> torch.Tensor:
-        """(cos_e, sin_e, cos_u, sin_u) of errs·1e-3 (:87-91), computed ON THE DEVICE WHERE
-        ``errs`` LIVES: the HIP kernel of ``helio_error_trig`` for device tensors (what
-        ``reset_errors`` draws); torch's CPU trig for CPU tensors assigned by a script, i.e. the
-        reference's bits, then moved to the field's device."""
-        if errs.is_cuda:
+        """(cos_e, sin_e, cos_u, sin_u) of errs·1e-3 (:87-91) WITH TORCH'S CPU BITS, wherever ``errs``
+        lives: the 1e-5 image tolerance at sigma_scale = 0.01 leaves no room for a 1-ulp-different
+        trig table, so device-sampled errors make one round trip per
+        ``reset_errors()`` — download, torch's CPU ``cos``/``sin`` (the kernels the reference's CPU
+        path runs), upload — and the table is cached until the tensor changes.  ``device_trig =
+        True`` (or HELIO_DEVICE_TRIG=1) keeps everything on the device instead
+        (``helio_error_trig``: ≤ 1 ulp from these values, no host synchronisation)."""
+        if errs.is_cuda and self.device_trig:
             return _get_ops().error_trig(errs).to(self.device)
-        ang = errs.detach().to(torch.float32) * 1e-3
+        ang = errs.detach().to(device="cpu", dtype=torch.float32) * 1e-3
         e, u = ang[..., 0], ang[..., 1]
         t = torch.stack([e.cos(), e.sin(), u.cos(), u.sin()], dim=-1)
         return t.to(self.device).contiguous()
@@ -188,13 +208,8 @@ class HelioField:
     def _init_actions_from(self, ideal: torch.Tensor) -> None:
         """``init_actions`` given the ideal normals of the sun position(s) (HelioEnv.reset has them
         cached: they depend only on geometry the two fields share)."""
-        noisy = ideal + torch.randn_like(ideal) * self.initial_action_noise
-        if ideal.dim() == 2:
-            noisy = noisy / noisy.norm(dim=1, keepdim=True).clamp_min(_TINY)
-            self.initial_action = noisy.flatten()
-        else:
-            noisy = noisy / noisy.norm(dim=2, keepdim=True).clamp_min(_TINY)
-            self.initial_action = noisy.view(ideal.shape[0], -1)
+        noisy = _get_ops().init_actions(ideal, torch.randn_like(ideal), self.initial_action_noise)
+        self.initial_action = noisy.flatten() if ideal.dim() == 2 else noisy.view(ideal.shape[0], -1)
 
     def render(self, sun_position, action, ideal_normals=None, show_spillage: bool = False,
                monitor: bool = False):

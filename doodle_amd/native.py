@@ -21,7 +21,7 @@ MOMENT_STRIDE = 5
 EXPORTS = (
     "helio_abi_version", "helio_last_error_string", "helio_device_arch", "helio_error_trig", "helio_geometry_fwd",
     "helio_splat_fwd", "helio_render_fwd", "helio_render_bwd", "helio_render_fwd_launches", "helio_splat_bwd_blocks", "helio_splat_bwd", "helio_geometry_bwd",
-    "helio_ideal_normals", "helio_step_losses_workspace", "helio_step_losses_fwd", "helio_step_losses_bwd",
+    "helio_ideal_normals", "helio_init_actions", "helio_step_losses_workspace", "helio_step_losses_fwd", "helio_step_losses_bwd",
     "helio_distance_maps_workspace", "helio_distance_maps",
     "helio_env_step_workspace", "helio_env_step_launches", "helio_env_step_fwd",
     "helio_notify_create", "helio_notify_destroy", "helio_notify_wait",
@@ -66,6 +66,7 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
         "helio_splat_bwd": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
         "helio_geometry_bwd": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _l, pp, _vp, _vp, _vp, _vp, _vp]),
         "helio_ideal_normals": (_i, [_i, _i, _vp, _vp, ctypes.c_float * 3, _vp, _vp]),
+        "helio_init_actions": (_i, [_l, _vp, _vp, _f, _vp, _vp]),
         "helio_distance_maps_workspace": (_l, [_i, _i]),
         "helio_distance_maps": (_i, [_i, _i, _vp, _f, _vp, _vp, _vp]),
         "helio_step_losses_workspace": (_l, [_i, _i, _i]),
@@ -398,6 +399,13 @@ class HipOps:
             B, N, _dev(helios), _dev(sun), (ctypes.c_float * 3)(*target_xyz), out.data_ptr(), _stream()))
         return out
 
+    def init_actions(self, ideal, noise, scale):
+        """unit(ideal + noise·scale) row by row with the reference's roundings (helio_init_actions)."""
+        ideal, noise = ideal.contiguous(), noise.contiguous()
+        out = torch.empty_like(ideal)
+        _check(self.lib, self.lib.helio_init_actions(ideal.numel() // 3, _dev(ideal), _dev(noise), float(scale),
+                                                     out.data_ptr(), _stream()))
+        return out
 
     # -- distance maps -----------------------------------------------------------------------
     def distance_maps(self, imgs, thr=0.5):

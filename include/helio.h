@@ -188,6 +188,17 @@ int helio_ideal_normals(int B, int N, const float *helios_d, const float *sun_d,
                         const float target_position[3], float *out_d, void *stream);
 
 /*
+ * Replaces the arithmetic of init_actions, :291-304 (the random draw stays with the caller:
+ * `noise_d` is the reference's torch.randn_like(ideal), M = B*N rows of 3):
+ *   out[m,:] = unit( ideal[m,:] + noise[m,:] * noise_scale ),  unit(v) = v / max(|v|, 1e-9),
+ * every operation rounded as the reference's CPU fp32 ops round (multiply, add, norm =
+ * sqrt(fma(z,z,fma(y,y,x*x))), IEEE division): bit-identical with the reference on the same draw.
+ * `out_d` may alias `ideal_d` or `noise_d`.
+ */
+int helio_init_actions(long M, const float *ideal_d, const float *noise_d, float noise_scale,
+                       float *out_d, void *stream);
+
+/*
  * ---- HelioEnv.step loss block (SURVEY.md §8 f) -------------------------------------------
  * Replaces test_environment.py :436-457 (peak-normalised MSE, EDT-weighted distance loss,
  * per-image mean error), :101-130 + :460-488 (boundary loss with the axes step() passes:

@@ -24,6 +24,10 @@ int helio_comm_unique_id(char *out, int len);
 int helio_comm_init(void **comm, int nranks, int rank, const char *id_bytes, int len);
 /* recv_d[r*count : (r+1)*count] = send_d of rank r, for every r (ncclAllGather, fp32). */
 int helio_comm_allgather_f32(void *comm, const float *send_d, float *recv_d, long count, void *stream);
+/* The size of the communicator and this process's rank in it, as RCCL reports them
+ * (ncclCommCount / ncclCommUserRank): what a benchmark records to show how many ranks the
+ * collective really spanned. */
+int helio_comm_count(void *comm, int *nranks, int *rank);
 int helio_comm_destroy(void *comm);
 
 #ifdef __cplusplus

@@ -176,6 +176,31 @@ def render_chunked(scene: Scene, sun, action, errs, b_chunk: int = 1, n_chunk: i
     return images, actual
 
 
+def grad_action_chunked(scene: Scene, sun, action, errs, G, H=None, n_chunk: int = 25):
+    """d/d(action) of ``(images·G).sum() + (actual·H).sum()`` by the reference's own fp32 autograd
+    for configurations whose ``[M,R,R,3]`` graph does not fit in memory.  The loss is additive over
+    heliostats (``images = Σ_n gauss_n``, :404-406, and ray n's Gaussian depends on action row n
+    only), so the gradient rows of a heliostat chunk come from a render of that chunk alone:
+    bit-identical with the unchunked autograd row by row."""
+    import dataclasses
+    sun = torch.as_tensor(sun, dtype=torch.float32).reshape(-1, 3)
+    B, N = sun.shape[0], scene.helios.shape[0]
+    normals = torch.as_tensor(action, dtype=torch.float32).reshape(B, N, 3)
+    grad = torch.empty(B, N, 3)
+    for b in range(B):
+        for n0 in range(0, N, n_chunk):
+            n1 = min(N, n0 + n_chunk)
+            sub = dataclasses.replace(scene, helios=scene.helios[n0:n1])
+            a = normals[b:b + 1, n0:n1].clone().requires_grad_(True)
+            img, actual = render(sub, sun[b:b + 1], a, errs[b:b + 1, n0:n1])
+            loss = (img * G[b:b + 1]).sum()
+            if H is not None:
+                loss = loss + (actual * H[b:b + 1, n0:n1]).sum()
+            (g,) = torch.autograd.grad(loss, a)
+            grad[b, n0:n1] = g[0]
+    return grad
+
+
 def pick_errors(single: torch.Tensor, batch: torch.Tensor | None, B: int):
     """The error-selection rule of render(), :340-353.  Returns None when the
     reference would draw a fresh sample (B > max_batch_size)."""

@@ -147,6 +147,11 @@ class OracleOps:
     def ideal_normals(self, helios, sun, target_xyz):
         return to.ideal_normals(helios, torch.tensor(list(target_xyz)), sun)
 
+    def init_actions(self, ideal, noise, scale):
+        """The reference's own ops (newenv_rl_test_multi_error.py:296-303)."""
+        noisy = ideal + noise * scale
+        return noisy / noisy.norm(dim=-1, keepdim=True).clamp_min(1e-9)
+
 
 def install(monkeypatch):
     """Route doodle_amd.field through the oracle-backed ops for this test."""

@@ -1,0 +1,97 @@
+#!/usr/bin/env python3
+"""Where the config-2 render kernel spends its cycles: s_memtime stamps of the fused small-problem
+kernel (diagnostic build, tools/build_diag.py → doodle_amd/libhelio_diag.so).
+
+    python tools/stamps_fused.py [cfg] > profiles/r02_fused_stamps.txt
+
+Per wave of every workgroup: cycles between stamps (median / p90 over the workgroups of the LAST of
+200 back-to-back launches), and — from s_memrealtime (100 MHz) — when workgroups start and end
+relative to the first start of the grid.  Shares are what to read, not the run time: the stamps'
+fences forbid overlaps the real kernel has."""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from doodle_amd import native, synthetic
+from bench import build_field, make_action, time_kernel
+
+cfg = sys.argv[1] if len(sys.argv) > 1 else "cfg2"
+w = synthetic.CONFIGS[cfg]
+dev = torch.device("cuda")
+path = os.path.join(os.path.dirname(native.LIB_PATH), "libhelio_diag.so")
+diag = ctypes.CDLL(path)
+vp, i, l = ctypes.c_void_p, ctypes.c_int, ctypes.c_long
+diag.helio_render_fwd.restype = i
+diag.helio_render_fwd.argtypes = [i, i, i, vp, vp, vp, vp, l, ctypes.POINTER(native.Plane), vp, vp, vp, vp, vp, vp, i, vp]
+diag.helio_diag_set_stamps.restype = i
+diag.helio_diag_set_stamps.argtypes = [vp]
+
+helios, suns, errs, noise = synthetic.make_inputs(w, 0)
+f = build_field(w, helios, errs, dev)
+suns_d = suns.to(dev)
+act = make_action(f, suns_d, noise)
+trig, stride = f._select_trig(w.B)
+normals = act.reshape(w.B, w.N, 3).contiguous()
+actual = torch.empty_like(normals)
+rays = torch.empty(w.B, w.N, 4, device=dev)
+img = torch.empty(w.B, w.R, w.R, device=dev)
+st = native._stream()
+args = (w.B, w.N, w.R, f.heliostat_positions.data_ptr(), suns_d.data_ptr(), normals.data_ptr(), trig.data_ptr(), stride,
+        f._plane, f._xs.data_ptr(), f._ys.data_ptr(), actual.data_ptr(), None, rays.data_ptr(), img.data_ptr(), 0, st)
+tiles = ((w.R + 63) // 64) ** 2
+NW, NS = 4, 10
+stamps = torch.zeros(w.B * tiles * NW * NS, dtype=torch.int64, device=dev)
+assert diag.helio_diag_set_stamps(stamps.data_ptr()) == 0
+t_diag = time_kernel(lambda: diag.helio_render_fwd(*args), 200, warm=50)
+torch.cuda.synchronize()
+s = stamps.cpu().numpy().reshape(w.B * tiles, NW, NS).astype(np.int64)
+# the product kernel on the same inputs, for the period the shares are to be applied to
+lib = native.get_ops().lib
+t_prod = time_kernel(lambda: lib.helio_render_fwd(*args), 2000, warm=200)
+ref = native.get_ops().splat_fwd(rays, f._xs, f._ys)
+assert torch.equal(ref, img), "diagnostic build and product kernel disagree"
+
+names = ["entry → sun/xs/ys loads landed", "… → trig/action/heliostat loads landed (tracing waves)",
+         "… → trace done, ray table in LDS", "… → barrier passed (heliostat loop starts)",
+         "heliostat loop (MFMA + factors)", "image stores issued", "image stores complete"]
+print(f"# {w.name}: fused kernel, grid {tiles} x {w.B} workgroups of 256 threads (4 waves)")
+print(f"# back-to-back period: product kernel {t_prod*1e6:.2f} us, stamped build {t_diag*1e6:.2f} us")
+clk = []
+for wg in range(s.shape[0]):
+    for wv in range(NW):
+        dt, dr = s[wg, wv, 7] - s[wg, wv, 0], s[wg, wv, 9] - s[wg, wv, 8]
+        if dr > 0:
+            clk.append(dt / (dr * 10e-9) / 1e9)
+ghz = float(np.median(clk))
+print(f"# shader clock inside the kernel: {ghz:.2f} GHz (s_memtime / s_memrealtime)")
+print(f"# cycles per phase, median [p10 … p90] over the {s.shape[0]} workgroups; wave 0 traces the rays (N <= 64)")
+print(f"{'phase':58s} " + " ".join(f"{'wave %d' % k:>22s}" for k in range(NW)))
+edges = [(0, 1), (1, 2), (2, 3), (3, 4), (4, 5), (5, 6), (6, 7)]
+for (a, b), name in zip(edges, names):
+    row = []
+    for wv in range(NW):
+        sa, sb = s[:, wv, a], s[:, wv, b]
+        if a == 1 and b == 2:            # stamps 2/3 exist only in tracing waves
+            ok = s[:, wv, 2] > 0
+        elif a == 2:
+            ok = s[:, wv, 3] > 0
+        elif b == 4 and a == 3:
+            ok = s[:, wv, 3] > 0
+        else:
+            ok = np.ones_like(sa, dtype=bool)
+        if a == 3 and not ok.any():      # non-tracing waves: from their own load stamp to the barrier
+            sa, ok = s[:, wv, 1], np.ones_like(sa, dtype=bool)
+        d = (sb - sa)[ok]
+        row.append(f"{np.median(d):7.0f} [{np.percentile(d, 10):5.0f}…{np.percentile(d, 90):5.0f}]" if d.size else f"{'-':>22s}")
+    print(f"{name:58s} " + " ".join(row))
+tot = s[:, :, 7] - s[:, :, 0]
+print(f"{'entry → stores complete (whole wave)':58s} " + " ".join(
+    f"{np.median(tot[:, k]):7.0f} [{np.percentile(tot[:, k], 10):5.0f}…{np.percentile(tot[:, k], 90):5.0f}]" for k in range(NW)))
+print(f"# = {np.median(tot)/ghz/1e3:.2f} us of the {t_prod*1e6:.2f} us period; the rest is dispatch: launch → first wave, ramp, "
+      f"end-of-kernel → next launch")
+r0 = s[:, :, 8].min()
+starts, ends = (s[:, :, 8] - r0) * 10.0, (s[:, :, 9] - r0) * 10.0          # ns
+print(f"# workgroup start after the first start of the grid (ns): median {np.median(starts):.0f}, p90 {np.percentile(starts, 90):.0f}, "
+      f"max {starts.max():.0f}")
+print(f"# workgroup end   after the first start of the grid (ns): median {np.median(ends):.0f}, p90 {np.percentile(ends, 90):.0f}, "
+      f"max {ends.max():.0f}   (grid span = {ends.max()/1e3:.2f} us)")
