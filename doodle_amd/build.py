@@ -22,8 +22,13 @@ HEADERS = [os.path.join(CSRC, "helio_math.h"), os.path.join(CSRC, "ray_trace.h")
 # -ffp-contract=off: the geometry stage is bit-faithful to the reference's fp32 CPU
 # arithmetic; FMAs appear only where written (helio_math.h).  Division and sqrt stay
 # correctly rounded (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt).
+# -amdgpu-kernarg-preload-count=14: the first 14 dwords of every kernel's arguments arrive in scalar
+# registers with the wave launch instead of through a load from the kernel-argument segment (≈0.8 µs
+# for the first touch in a freshly launched kernel, which is what the launch-bound small kernels wait
+# for first); kernels keep the compatibility prologue for firmware that does not preload.
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-std=c++17", "-ffp-contract=off",
-         "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wno-pass-failed"]
+         "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wno-pass-failed",
+         "-mllvm", "-amdgpu-kernarg-preload-count=14"]
 
 
 def hipcc() -> str:

@@ -5,6 +5,7 @@
 // renormalise), :376-383 (incident, reflection), :52-75 (intersection), :126-127,:146 (sigma).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <cmath>
 #include "helio.h"
 #include "helio_math.h"
 
@@ -12,6 +13,7 @@ namespace helio {
 
 struct PlaneK {  // helio_plane by value in kernel-argument space
     vec3 o, nrm, u, v, w;
+    vec3 phat;       // nrm / max(|nrm|, 1e-9), :60 — the same for every ray: divided once, on the host (to_k)
     float sigma_scale;
 };
 
@@ -34,9 +36,10 @@ struct Ray {
     vec3 d0;  float a, b, c, c2, k2;
 };
 
-__device__ __forceinline__ Ray trace(vec3 nin, float ce, float se, float cu, float su,
-                                     vec3 h, vec3 s, const PlaneK& P) {
-    Ray q;
+// trace() in two halves: everything up to the unit reflection needs no receiver-plane constant — the
+// fused small-problem kernel runs that half while its plane constants are still on their way from the
+// kernel-argument segment.  trace() = head + tail: the same operations in the same order.
+__device__ __forceinline__ void trace_head(Ray& q, vec3 nin, float ce, float se, float cu, float su, vec3 h, vec3 s) {
     // :96-102  rotate about Up (Z) then East (X); every op individually rounded
     float xu = __fsub_rn(__fmul_rn(cu, nin.x), __fmul_rn(su, nin.y));
     float yu = __fadd_rn(__fmul_rn(su, nin.x), __fmul_rn(cu, nin.y));
@@ -54,7 +57,10 @@ __device__ __forceinline__ Ray trace(vec3 nin, float ce, float se, float cu, flo
             __fsub_rn(-q.inc.y, __fmul_rn(two, q.nh.y)),
             __fsub_rn(-q.inc.z, __fmul_rn(two, q.nh.z))};
     q.r = unit3(q.r0, q.nr0);                                     // :383
-    q.phat = unit3(P.nrm);                                        // :60
+}
+
+__device__ __forceinline__ void trace_tail(Ray& q, vec3 h, const PlaneK& P) {
+    q.phat = P.phat;                                              // :60 (to_k: same roundings, once per launch)
     q.denom = dot3(q.r, q.phat);                                  // :62
     q.valid = fabsf(q.denom) > 1e-9f;                             // :63
     float safe = q.valid ? q.denom : 1e-9f;                       // :65
@@ -77,6 +83,13 @@ __device__ __forceinline__ Ray trace(vec3 nin, float ce, float se, float cu, flo
     q.c = dot3(q.d0, P.w);
     q.c2 = __fmul_rn(q.c, q.c);
     q.k2 = q.valid ? __fdiv_rn(1.44269504088896340736f, q.two_s2) : 0.0f;
+}
+
+__device__ __forceinline__ Ray trace(vec3 nin, float ce, float se, float cu, float su,
+                                     vec3 h, vec3 s, const PlaneK& P) {
+    Ray q;
+    trace_head(q, nin, ce, se, cu, su, h, s);
+    trace_tail(q, h, P);
     return q;
 }
 
@@ -84,6 +97,11 @@ static inline PlaneK to_k(const helio_plane* p) {
     PlaneK k;
     k.o = {p->origin[0], p->origin[1], p->origin[2]};
     k.nrm = {p->normal[0], p->normal[1], p->normal[2]};
+    {   // unit3() on the host: IEEE fmaf / sqrtf / division round exactly as the device's (-ffp-contract=off)
+        const float nn = sqrtf(fmaf(k.nrm.z, k.nrm.z, fmaf(k.nrm.y, k.nrm.y, k.nrm.x * k.nrm.x)));
+        const float n = nn != nn ? nn : fmaxf(nn, 1e-9f);
+        k.phat = {k.nrm.x / n, k.nrm.y / n, k.nrm.z / n};
+    }
     k.u = {p->u[0], p->u[1], p->u[2]};
     k.v = {p->v[0], p->v[1], p->v[2]};
     k.w = {p->w[0], p->w[1], p->w[2]};

@@ -28,6 +28,7 @@
 // then the running total); the throughput kernels in one level — fewer registers, more waves per
 // SIMD — measured 1.5e-6 of peak apart at N=2000 and inside the tolerance at N=5000.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "helio.h"
 #include "ray_trace.h"
 #include "step_loss_math.h"
@@ -42,8 +43,8 @@ __device__ __forceinline__ float exp2_fast(float x) { return __builtin_amdgcn_ex
 // writes its stamps once, at the end, to a buffer nothing else reads (cdna_hip_programming.md §7).
 #ifdef HELIO_STAMPS
 __device__ unsigned long long* g_stamps = nullptr;        // [workgroup][wave][HELIO_NSTAMP]
-#define HELIO_NSTAMP 10
-#define HSTAMP_DECL unsigned long long stamp_[HELIO_NSTAMP] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define HELIO_NSTAMP 12
+#define HSTAMP_DECL unsigned long long stamp_[HELIO_NSTAMP] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
 #define HSTAMP(k)                                                                                   \
     do {                                                                                            \
         __builtin_amdgcn_sched_barrier(0);                                                          \
@@ -65,7 +66,7 @@ __device__ unsigned long long* g_stamps = nullptr;        // [workgroup][wave][H
 #define HSTAMP_FLUSH()                                                                              \
     do {                                                                                            \
         if (g_stamps && (threadIdx.x & 63) == 0) {                                                  \
-            unsigned long long* o_ = g_stamps + (((long)blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6)) * HELIO_NSTAMP; \
+            unsigned long long* o_ = g_stamps + ((((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6)) * HELIO_NSTAMP; \
             for (int k_ = 0; k_ < HELIO_NSTAMP; ++k_) o_[k_] = stamp_[k_];                          \
         }                                                                                           \
     } while (0)
@@ -436,48 +437,126 @@ splat_fwd_mfma_tile(int B, int N, int R, const float* __restrict__ rays, const f
         store_block(img, R, ti0 + wi + 32 * (m >> 1), tj0 + wj + 32 * (m & 1), lr, lh, TWO_LEVEL ? tot[m] : acc[m]);
 }
 
-// Small problems are launch-latency bound (config 2 is 41 MFLOP ≈ 0.3 µs at peak): one
-// launch instead of two.  Every workgroup (64×64 pixel tile, 4 waves of one 32×32 MFMA block)
-// traces the rays of its own sun itself — threads 0..127 of a chunk run the bit-faithful
-// trace() of ray_trace.h straight into the LDS ray table — and the workgroup of tile 0 also
-// writes `actual`, `refl` and the `rays` work buffer.  The redundant geometry (once per tile
-// of an image) is a few hundred flops per ray.
+// Small problems are launch-latency bound (config 2 is 41 MFLOP ≈ 0.3 µs at peak): ONE launch for
+// the whole forward, shaped for the latency of a single wave rather than for throughput.  Stamps of
+// the round-1 form (64×64 tiles, 4 waves, one wave tracing every ray of the sun; profiles/
+// r02_a_fused_stamps_before.txt) showed a 9,700-cycle wave of which 3,800 were the heliostat loop,
+// 2,000 the trace and 1,300 sixteen bounds-checked stores per lane — every phase serial instruction
+// issue of one wave per SIMD, with 100 of the 256 CUs in use.  So here:
+//   * a workgroup is ONE 32×32 pixel block (one MFMA accumulator) and KG waves that split the
+//     heliostats between them (KG ∈ {1,2,4}: config 2 runs 400 workgroups of 2 or 4 waves);
+//   * the rays of the sun are traced by ONE wave per 64 rays (lane ↔ ray, the bit-faithful trace() of
+//     ray_trace.h) into an LDS table while the other waves wait at the barrier: a first form in which
+//     every wave traced the rays of its own k-pairs put 1,600 copies of that 350-instruction stream on
+//     1,024 SIMDs, and the workgroups that shared a CU finished 1 µs after the others;
+//   * the KG partial accumulators are exchanged through LDS so that every wave ends up OWNING 16/KG
+//     registers (8/KG·… rows) of the block, summed in fixed wave order (deterministic), and stores
+//     only those: the store phase is split KG ways too;
+//   * block 0 of an image also writes `actual`, `refl` and the `rays` work buffer (each wave its rays).
+// The geometry is redundant across the blocks of an image (a few hundred flops per ray and block): it
+// costs no time, the lanes are there.
 //
 // LOSS = true is HelioEnv.step's small-problem forward in the same launch (test_environment.py
-// :416-457): the tile's share of the three image sums is taken from the accumulator registers
+// :416-457): the block's share of the three image sums is taken from the owned accumulator registers
 // (the image is still written — it is an output of step() — but never re-read; the target and
 // distance-map pixels are fetched before the heliostat loop), and ONE EXTRA workgroup per image
-// (blockIdx.x == tiles) takes the per-ray side work off the tiles' critical path: it writes
-// `actual` / `refl` / `rays`, evaluates the two ray losses and fills the `aux` row.  Partials go
-// to the [B, chunks, 3] / [ray_wgs, 2] layout step_losses_final reduces (chunks = tiles per
-// image, ray_wgs = B); fixed order, no atomics.
-template <bool LOSS>
-__global__ void __launch_bounds__(256)
-render_fwd_fused_small(int B, int N, int R, const float* __restrict__ helios, const float* __restrict__ sun,
-                       const float* __restrict__ action, const float* __restrict__ trig, long trig_b_stride,
-                       PlaneK P, const float* __restrict__ xs, const float* __restrict__ ys,
-                       float* __restrict__ actual, float* __restrict__ refl, float* __restrict__ rays,
-                       float* __restrict__ image, StepLossArgs L) {
-    constexpr int NC = 128;
-    __shared__ float4 sRay[NC + 4];
-    __shared__ float scratch[12];
+// (blockIdx.x == blocks) does the per-ray side work: it writes `actual` / `refl` / `rays`, evaluates
+// the two ray losses and fills the `aux` row.  Partials go to the [B, chunks, 3] / [ray_wgs, 2] layout
+// step_losses_final reduces (chunks = blocks per image, ray_wgs = B); fixed order, no atomics.
+// The kernel arguments behind the 14 preloaded dwords.  A freshly launched kernel waits ≈1,900 cycles
+// (0.8 µs; stamps, profiles/r02_*) for its FIRST read of the kernel-argument segment, and hipcc puts
+// that wait wherever the first late argument is used — in practice in front of the first ray load.
+// The forward-only kernel therefore fetches this block ITSELF: three s_load instructions issued as its
+// first instructions, ONE wait placed after the half of the trace that needs none of it
+// (cdna_hip_programming.md §5.7, form (ii): "=s" loads, then a wait statement naming every destination
+// "+s").  No compiler-counted LDS or scalar-memory operation lies between issue and wait, the
+// destinations stay in the registers they were loaded into (audit: tools/audit_fused_late.py), and
+// the C++ side never names the `late` parameter, so hipcc emits no load of its own for it.
+struct FusedLate {
+    PlaneK P;                                          // 19 floats
+    float* actual; float* refl; float* rays; float* image;
+};
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+constexpr int FUSED_LATE_AT = 56;                      // bytes of N, R|flag and six pointers in front of it
+static_assert(sizeof(PlaneK) == 76 && offsetof(FusedLate, actual) == 80 && offsetof(FusedLate, image) == 104 &&
+              sizeof(FusedLate) == 112, "the s_load offsets below restate this layout");
 
-    const int tiles_j = (R + 63) / 64;
-    const int b = blockIdx.y;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+struct LateRegs { i32x16 a; i32x8 b; i32x4 c; };       // floats 0..15 of P | P[16..18], pad, actual, refl | rays, image
+
+__device__ __forceinline__ void late_issue(LateRegs& r) {
+    auto kp = __builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("s_load_dwordx16 %0, %3, 0x38\n\ts_load_dwordx8 %1, %3, 0x78\n\ts_load_dwordx4 %2, %3, 0x98"
+                 : "=s"(r.a), "=s"(r.b), "=s"(r.c) : "s"(kp));
+}
+__device__ __forceinline__ void late_wait(LateRegs& r) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(r.a), "+s"(r.b), "+s"(r.c) :: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ float* late_ptr(int lo, int hi) {
+    return reinterpret_cast<float*>(((unsigned long)(unsigned)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ PlaneK late_plane(const LateRegs& r) {
+    auto f = [](int v) { return __int_as_float(v); };
+    PlaneK P;
+    P.o = {f(r.a[0]), f(r.a[1]), f(r.a[2])};
+    P.nrm = {f(r.a[3]), f(r.a[4]), f(r.a[5])};
+    P.u = {f(r.a[6]), f(r.a[7]), f(r.a[8])};
+    P.v = {f(r.a[9]), f(r.a[10]), f(r.a[11])};
+    P.w = {f(r.a[12]), f(r.a[13]), f(r.a[14])};
+    P.phat = {f(r.a[15]), f(r.b[0]), f(r.b[1])};
+    P.sigma_scale = f(r.b[2]);
+    return P;
+}
+
+template <int KG, bool LOSS>
+__global__ void __launch_bounds__(64 * KG)
+render_fwd_fused_small(int N, int R_and_flag, const float* __restrict__ helios, const float* __restrict__ sun,
+                       const float* __restrict__ action, const float* __restrict__ trig,
+                       const float* __restrict__ xs, const float* __restrict__ ys, FusedLate late, StepLossArgs L) {
+    // Argument order: the first 14 dwords — N, R (with the per-sun flag of the trig table, stride 4N or 0,
+    // in bit 16) and the six pointers the ray loads and the pixel-coordinate loads need — are PRELOADED
+    // into scalar registers with the wave launch (-mllvm -amdgpu-kernarg-preload-count=14,
+    // doodle_amd/build.py).  N <= 64·KG: one wave-load of rays per wave, no loop around the trace.
+    const int R = R_and_flag & 0xFFFF;
+    const long trig_b_stride = (R_and_flag >> 16) ? 4l * N : 0l;
+    constexpr int OWN = 16 / KG;                       // accumulator registers a wave owns after the exchange
+    constexpr int Q4 = OWN / 4;                        // … as 16-byte groups
+    __shared__ float4 sRay[64 * KG + 4];
+    __shared__ float4 sRed[KG > 1 ? KG * KG * Q4 * 64 : 1];
+    __shared__ float scratch[3 * KG];
+
+    // grid = (column blocks, row blocks [+ 1 row of ray workgroups with LOSS], suns): the block's place
+    // comes with the launch — an integer division by a kernel argument would put a scalar-load round
+    // trip and 25 instructions in front of the first ray load
+    const int b = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     HSTAMP_DECL;
     HSTAMP_REAL(8);
     HSTAMP(0);
-    const vec3 s = ld3(sun + 3l * b);
+    LateRegs lr_;
+    if constexpr (!LOSS) late_issue(lr_);              // first instructions of the kernel; waited for after trace_head
+    // the sun through the VECTOR memory path (an opaque zero lane offset): as a scalar load its wait would
+    // be an lgkmcnt(0), which also waits for the late arguments just requested
+    int zoff = 0;
+    asm volatile("" : "+v"(zoff));
+    const vec3 s = ld3(sun + 3l * b + zoff);
 
     if constexpr (LOSS) {
-        if ((int)blockIdx.x == tiles_j * tiles_j) {          // the per-ray workgroup of image b
+        if (blockIdx.y == gridDim.y - 1) {               // the extra grid row: ONE per-ray workgroup per image
+            if (blockIdx.x != 0) return;
             float sa = 0.0f, sb = 0.0f;
-            for (int n = tid; n < N; n += 256) {
+            float* __restrict__ actual = late.actual;
+            float* __restrict__ refl = late.refl;
+            float* __restrict__ rays = late.rays;
+            const int n = tid;
+            if (n < N) {
                 const long m = (long)b * N + n;
                 const float4 tg = *reinterpret_cast<const float4*>(trig + (long)b * trig_b_stride + 4l * n);
                 const vec3 v = ld3(action + 3 * m);
-                const Ray q = trace(v, tg.x, tg.y, tg.z, tg.w, ld3(helios + 3l * n), s, P);
+                const Ray q = trace(v, tg.x, tg.y, tg.z, tg.w, ld3(helios + 3l * n), s, late.P);
                 st3(actual + 3 * m, q.act);
                 if (refl) st3(refl + 3 * m, q.r);
                 if (rays) *reinterpret_cast<float4*>(rays + 4 * m) = make_float4(q.a, q.b, q.k2, q.c2);
@@ -490,106 +569,192 @@ render_fwd_fused_small(int B, int N, int R, const float* __restrict__ helios, co
                     a[3 + 3 * n] = v.x; a[4 + 3 * n] = v.y; a[5 + 3 * n] = v.z;
                     if (n == 0) { a[0] = s.x; a[1] = s.y; a[2] = s.z; }
                 }
-                sa += r.ang;
-                sb += L.g.exponential_risk ? expf(r.out + 1e-6f) : r.out;
+                sa = r.ang;
+                sb = L.g.exponential_risk ? expf(r.out + 1e-6f) : r.out;
             }
 #pragma unroll
             for (int d = 32; d >= 1; d >>= 1) { sa += __shfl_xor(sa, d); sb += __shfl_xor(sb, d); }
             if (lane == 0) { scratch[2 * wave] = sa; scratch[2 * wave + 1] = sb; }
             __syncthreads();
             if (tid == 0) {
-                L.part_ray[2l * b] = (scratch[0] + scratch[2]) + (scratch[4] + scratch[6]);
-                L.part_ray[2l * b + 1] = (scratch[1] + scratch[3]) + (scratch[5] + scratch[7]);
+                float ta = scratch[0], tb = scratch[1];
+#pragma unroll
+                for (int w = 1; w < KG; ++w) { ta += scratch[2 * w]; tb += scratch[2 * w + 1]; }
+                L.part_ray[2l * b] = ta;
+                L.part_ray[2l * b + 1] = tb;
             }
             return;
         }
     }
 
     const int lr = lane & 31, lh = lane >> 5;
-    const int i0 = (blockIdx.x / tiles_j) * 64 + (wave >> 1) * 32;
-    const int j0 = (blockIdx.x % tiles_j) * 64 + (wave & 1) * 32;
-    const bool writer = !LOSS && blockIdx.x == 0;
+    const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
+    const bool writer = !LOSS && blockIdx.x == 0 && blockIdx.y == 0;
 
     const float xv = xs[min(i0 + lr, R - 1)], yv = ys[min(j0 + lr, R - 1)];
-    HSTAMP_VM(1);
-    // LOSS: this lane's 16 target / distance-map pixels, in flight during the heliostat loop
-    float tgt[16], dmp[16];
+    const int col = j0 + lr;
+
+    // wave w traces rays 64 w + lane (a wave with no ray — waves 1.. at N <= 64 — only fills its part of
+    // the table with padding and waits: ONE instruction stream per 64 rays, so that the trace never
+    // competes with itself for a SIMD), then the k-pairs are dealt evenly to the KG waves
+    const float4 pad = make_float4(0.f, 0.f, 0.f, 1e30f);   // pre-scaled form: A = exp2(-1e30) = 0 exactly
+    const int n = 64 * wave + lane;
+    const bool tracing = n < N;
+    const long m = (long)b * N + n;
+    Ray q;
+    vec3 hv = {0.f, 0.f, 0.f};
+    if (tracing) {
+        const float4 tg = *reinterpret_cast<const float4*>(trig + (long)b * trig_b_stride + 4l * n);
+        const vec3 av = ld3(action + 3 * m);
+        hv = ld3(helios + 3l * n);
+        trace_head(q, av, tg.x, tg.y, tg.z, tg.w, hv, s);
+    }
+    HSTAMP(1);
+    // the late arguments: ONE wait, on every path, in front of their first use
+    PlaneK P;
+    float* __restrict__ actual;
+    float* __restrict__ refl;
+    float* __restrict__ rays;
+    float* __restrict__ img;
+    if constexpr (!LOSS) {
+        late_wait(lr_);
+        P = late_plane(lr_);
+        actual = late_ptr(lr_.b[4], lr_.b[5]);
+        refl = late_ptr(lr_.b[6], lr_.b[7]);
+        rays = late_ptr(lr_.c[0], lr_.c[1]);
+        img = late_ptr(lr_.c[2], lr_.c[3]) + (long)b * R * R;
+    } else {
+        P = late.P;
+        actual = late.actual; refl = late.refl; rays = late.rays;
+        img = late.image + (long)b * R * R;
+    }
+    HSTAMP(7);
+    // LOSS: this lane's OWN target / distance-map pixels (the rows this wave owns after the exchange:
+    // accumulator registers wave·OWN + e, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)), in flight
+    // during the rest of the trace and the loop
+    float tgt[OWN], dmp[OWN];
     if constexpr (LOSS) {
         const long base = (long)b * R * R;
-        const int j = j0 + lr;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int i = i0 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-            const bool in = i < R && j < R;
-            tgt[e] = in ? L.target[base + (long)i * R + j] : 0.0f;
-            dmp[e] = in ? L.dmaps[base + (long)i * R + j] : 0.0f;
+        for (int e = 0; e < OWN; ++e) {
+            const int eg = wave * OWN + e;
+            const int i = i0 + (eg & 3) + 8 * (eg >> 2) + 4 * lh;
+            const bool in = i < R && col < R;
+            tgt[e] = in ? L.target[base + (long)i * R + col] : 0.0f;
+            dmp[e] = in ? L.dmaps[base + (long)i * R + col] : 0.0f;
         }
     }
-    // two accumulators (even / odd k-pairs): the two MFMAs of a trip do not depend on each other, so
-    // the latency-bound loop of a single wave per SIMD is one MFMA latency per trip, not two
-    f32x16 tot, acc, acc2;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) { tot[e] = 0.0f; acc[e] = 0.0f; acc2[e] = 0.0f; }
 
-    const float4 pad = make_float4(0.f, 0.f, 0.f, 1e30f);   // pre-scaled form: A = exp2(-1e30) = 0 exactly
-    for (int n0 = 0; n0 < N; n0 += NC) {
-        __syncthreads();
-        if (tid < NC + 4) {
-            float4 v = pad;
-            const int n = n0 + tid;
-            if (tid < NC && n < N) {
-                const long m = (long)b * N + n;
-                const float4 tg = *reinterpret_cast<const float4*>(trig + (long)b * trig_b_stride + 4l * n);
-                const vec3 av = ld3(action + 3 * m), hv = ld3(helios + 3l * n);
-                HSTAMP_VM(2);
-                const Ray q = trace(av, tg.x, tg.y, tg.z, tg.w, hv, s, P);
-                const float sk = __builtin_sqrtf(q.k2);
-                v = make_float4(q.a * sk, q.b * sk, sk, q.c2 * q.k2);   // LDS copy pre-scaled (2 VALU + exp per factor)
-                if (writer) {
-                    st3(actual + 3 * m, q.act);
-                    if (refl) st3(refl + 3 * m, q.r);
-                    if (rays) *reinterpret_cast<float4*>(rays + 4 * m) = make_float4(q.a, q.b, q.k2, q.c2);
-                }
-            }
-            sRay[tid] = v;
-            HSTAMP(3);
-        }
-        __syncthreads();
-        HSTAMP(4);
-        const int cnt = min(NC, N - n0);
-        float4 q0 = sRay[lh], q1 = sRay[2 + lh];
-        for (int k = 0; k < cnt; k += 4) {
-            const float4 p0 = q0, p1 = q1;
-            q0 = sRay[k + 4 + lh];
-            q1 = sRay[k + 6 + lh];
-            const float t0 = __builtin_fmaf(xv, p0.z, p0.x), t1 = __builtin_fmaf(xv, p1.z, p1.x);
-            const float u0 = __builtin_fmaf(yv, p0.z, p0.y), u1 = __builtin_fmaf(yv, p1.z, p1.y);
-            const float fa0 = exp2_fast(-__builtin_fmaf(t0, t0, p0.w));
-            const float fa1 = exp2_fast(-__builtin_fmaf(t1, t1, p1.w));
-            const float fe0 = exp2_fast(-(u0 * u0));
-            const float fe1 = exp2_fast(-(u1 * u1));
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0, fe0, acc, 0, 0, 0);
-            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1, fe1, acc2, 0, 0, 0);
-        }
-        tot += acc + acc2;
+    f32x16 acc;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) { acc[e] = 0.0f; acc2[e] = 0.0f; }
+    for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+
+    {
+        float4 v = pad;
+        if (tracing) {
+            trace_tail(q, hv, P);
+            const float sk = __builtin_sqrtf(q.k2);
+            v = make_float4(q.a * sk, q.b * sk, sk, q.c2 * q.k2);   // LDS copy pre-scaled (2 VALU + exp per factor)
+            if (writer) {
+                st3(actual + 3 * m, q.act);
+                if (refl) st3(refl + 3 * m, q.r);
+                if (rays) *reinterpret_cast<float4*>(rays + 4 * m) = make_float4(q.a, q.b, q.k2, q.c2);
+            }
+        }
+        sRay[64 * wave + lane] = v;
+        if (tid < 4) sRay[64 * KG + tid] = pad;
+        __syncthreads();
+        HSTAMP(2);
+        const int cnt = N;                                   // rays in the table (N <= 64·KG)
+        const int per = (((cnt + 1) >> 1) + KG - 1) / KG;    // k-pairs per wave
+        const int k_begin = min(cnt, 2 * per * wave), k_end = min(cnt, 2 * per * (wave + 1));
+        // groups of 8 k-pairs (16 rays): the group's eight operand fetches are issued together, ahead of
+        // its MFMAs (left in a rotating loop, hipcc re-forms "read, wait, use" and every trip pays an LDS
+        // latency); a uniform test per k-pair ends the group at the last ray
+        for (int k0 = k_begin; k0 < k_end; k0 += 16) {
+            float4 p[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) p[j] = sRay[min(k0 + 2 * j, 64 * KG) + lh];     // (64·KG …: padding rays)
+#pragma unroll
+            for (int j = 0; j < 8; ++j)            // pin the fetches here: hipcc otherwise sinks each into its k-pair
+                asm volatile("" :: "v"(p[j].x), "v"(p[j].y), "v"(p[j].z), "v"(p[j].w));
+            __builtin_amdgcn_sched_barrier(0);
+            // the group's 16 factors first (independent VALU work, issued back to back), then its MFMAs
+            // back to back: the f32 MFMA holds the SIMD's vector issue for its 64 cycles, so "factor, factor,
+            // MFMA" per k-pair pays every exponential's latency in front of every MFMA (190 cycles per k-pair
+            // measured, against 64 + 6 issue slots)
+            float fa[8], fe[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float t = __builtin_fmaf(xv, p[j].z, p[j].x), u = __builtin_fmaf(yv, p[j].z, p[j].y);
+                fa[j] = exp2_fast(-__builtin_fmaf(t, t, p[j].w));
+                fe[j] = exp2_fast(-(u * u));
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) asm volatile("" :: "v"(fa[j]), "v"(fe[j]));    // (pinned, as the fetches are)
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (k0 + 2 * j >= k_end) break;
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[j], fe[j], acc, 0, 0, 0);
+            }
+        }
+    }
+    HSTAMP(3);
+
+    // exchange: wave w writes its partial sums of the registers wave o owns to slot [w][o]; after the
+    // barrier wave o adds the KG partials of its registers in wave order
+    float own[OWN];
+    if constexpr (KG == 1) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) own[e] = acc[e];
+    } else {
+#pragma unroll
+        for (int o = 0; o < KG; ++o)
+#pragma unroll
+            for (int g4 = 0; g4 < Q4; ++g4)
+                sRed[((wave * KG + o) * Q4 + g4) * 64 + lane] =
+                    make_float4(acc[o * OWN + 4 * g4], acc[o * OWN + 4 * g4 + 1], acc[o * OWN + 4 * g4 + 2], acc[o * OWN + 4 * g4 + 3]);
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < KG; ++w)
+#pragma unroll
+            for (int g4 = 0; g4 < Q4; ++g4) {
+                const float4 v = sRed[((w * KG + wave) * Q4 + g4) * 64 + lane];
+                if (w == 0) { own[4 * g4] = v.x; own[4 * g4 + 1] = v.y; own[4 * g4 + 2] = v.z; own[4 * g4 + 3] = v.w; }
+                else { own[4 * g4] += v.x; own[4 * g4 + 1] += v.y; own[4 * g4 + 2] += v.z; own[4 * g4 + 3] += v.w; }
+            }
+    }
+    HSTAMP(4);
+
+    const int r0 = i0 + 4 * lh;                                  // + (reg & 3) + 8 (reg >> 2)
+    if (i0 + 32 <= R && j0 + 32 <= R) {                          // (uniform) the block is inside the image
+#pragma unroll
+        for (int e = 0; e < OWN; ++e) {
+            const int eg = wave * OWN + e;
+            img[(long)(r0 + (eg & 3) + 8 * (eg >> 2)) * R + col] = own[e];
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < OWN; ++e) {
+            const int eg = wave * OWN + e;
+            const int i = r0 + (eg & 3) + 8 * (eg >> 2);
+            if (i < R && col < R) img[(long)i * R + col] = own[e];
+        }
     }
     HSTAMP(5);
-    store_block(image + (long)b * R * R, R, i0, j0, lr, lh, tot);
-    HSTAMP(6);
-    HSTAMP_VM(7);
+    HSTAMP_VM(6);
     HSTAMP_REAL(9);
     HSTAMP_FLUSH();
     if constexpr (LOSS) {
         const float sc = L.tx[b];
-        const int j = j0 + lr;
         float sq = 0.f, ab = 0.f, ds = 0.f;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int i = i0 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-            if (i < R && j < R) {
-                const float d = tot[e] / sc - tgt[e] / sc;      // as the reference divides (:438-441)
+        for (int e = 0; e < OWN; ++e) {
+            const int eg = wave * OWN + e;
+            const int i = r0 + (eg & 3) + 8 * (eg >> 2);
+            if (i < R && col < R) {
+                const float d = own[e] / sc - tgt[e] / sc;      // as the reference divides (:438-441)
                 const float ad = fabsf(d);
                 sq = __builtin_fmaf(d, d, sq);
                 ab += ad;
@@ -601,8 +766,10 @@ render_fwd_fused_small(int B, int N, int R, const float* __restrict__ helios, co
         if (lane == 0) { scratch[3 * wave] = sq; scratch[3 * wave + 1] = ab; scratch[3 * wave + 2] = ds; }
         __syncthreads();
         if (tid < 3) {
-            float* o = L.part_img + 3l * ((long)b * (gridDim.x - 1) + blockIdx.x);
-            o[tid] = (scratch[tid] + scratch[3 + tid]) + (scratch[6 + tid] + scratch[9 + tid]);
+            float t = scratch[tid];
+#pragma unroll
+            for (int w = 1; w < KG; ++w) t += scratch[3 * w + tid];
+            L.part_img[3l * ((long)b * (gridDim.x * (gridDim.y - 1)) + blockIdx.y * gridDim.x + blockIdx.x) + tid] = t;
         }
     }
 }
@@ -610,7 +777,7 @@ render_fwd_fused_small(int B, int N, int R, const float* __restrict__ helios, co
 #ifdef HELIO_STAMPS
 }  // namespace helio
 // diagnostic library only: point the stamp buffer of the fused kernel at `stamps_d`
-// ([workgroups][4 waves][10] 64-bit words; NULL switches the flush off)
+// ([workgroups][KG waves][10] 64-bit words; NULL switches the flush off)
 extern "C" int helio_diag_set_stamps(unsigned long long* stamps_d) {
     return hipMemcpyToSymbol(HIP_SYMBOL(helio::g_stamps), &stamps_d, sizeof(stamps_d)) == hipSuccess ? 0 : -1;
 }
@@ -619,26 +786,65 @@ namespace helio {
 
 // true when launch_render_fwd() would take the single-launch path
 bool render_is_fused(int B, int N, int R) {
-    // the fused kernel is the 64²-tile kernel plus in-kernel ray tracing: right wherever that tile
-    // size is (few tiles), and for short heliostat sums where saving a launch beats a better tile
+    // one launch instead of two wherever the launch boundary (≈1.5–2 µs plus a second wait for kernel
+    // arguments) is a visible share of the render: up to 512 128²-tiles' worth of pixels and a heliostat
+    // sum that one workgroup traces in one go (N <= 256: four waves of 64 rays).  Every 32×32 block
+    // traces the rays of its sun itself, so longer sums go to the geometry + splat pair
     const long t128 = (long)B * ((R + 127) / 128) * ((R + 127) / 128);
-    return t128 < 192 || (t128 < 512 && N <= 256);
+    return N <= 256 && t128 < 512;
+}
+
+// waves per 32×32 block of the fused kernel (the heliostats are split between them; 64·KG >= N): as
+// many as keep the chip's 1024 SIMDs at about one wave each and leave every wave a few k-pairs.
+// HELIO_FUSED_KG (1, 2 or 4) forces one form where N allows it — tuning runs only
+int fused_kg(int B, int N, int R) {
+    static const int forced = [] { const char* e = getenv("HELIO_FUSED_KG"); return e ? atoi(e) : 0; }();
+    const int need = N > 128 ? 4 : (N > 64 ? 2 : 1);
+    if ((forced == 1 || forced == 2 || forced == 4) && forced >= need) return forced;
+    const long nb = (R + 31) / 32, blocks = (long)B * nb * nb;
+    const int pairs = (N + 1) / 2;
+    int kg = 1;
+    if (pairs >= 8 && blocks * 4 <= 2048) kg = 4;
+    else if (pairs >= 4 && blocks * 2 <= 2048) kg = 2;
+    return kg > need ? kg : need;
+}
+
+#ifdef HELIO_STAMPS
+}  // namespace helio
+extern "C" int helio_diag_fused_kg(int B, int N, int R) { return helio::fused_kg(B, N, R); }
+namespace helio {
+#endif
+
+template <int KG, bool LOSS>
+static void launch_fused(int B, int N, int R, const float* helios, const float* sun, const float* action,
+                         const float* trig, long trig_b_stride, const helio_plane* plane, const float* xs,
+                         const float* ys, float* actual, float* refl, float* rays, float* image,
+                         const StepLossArgs& L, hipStream_t st) {
+    const int nb = (R + 31) / 32;
+    FusedLate late;
+    late.P = to_k(plane);
+    late.actual = actual; late.refl = refl; late.rays = rays; late.image = image;
+    hipLaunchKernelGGL((render_fwd_fused_small<KG, LOSS>), dim3(nb, nb + (LOSS ? 1 : 0), B), dim3(64 * KG), 0, st, N,
+                       R | (trig_b_stride != 0 ? 1 << 16 : 0), helios, sun, action, trig, xs, ys, late, L);
 }
 
 void launch_render_fused(int B, int N, int R, const float* helios, const float* sun, const float* action,
                          const float* trig, long trig_b_stride, const helio_plane* plane, const float* xs,
                          const float* ys, float* actual, float* refl, float* rays, float* image, hipStream_t st) {
-    const int t = (R + 63) / 64;
-    hipLaunchKernelGGL(render_fwd_fused_small<false>, dim3(t * t, B), dim3(256), 0, st, B, N, R, helios, sun, action,
-                       trig, trig_b_stride, to_k(plane), xs, ys, actual, refl, rays, image, StepLossArgs{});
+    const StepLossArgs none{};
+    switch (fused_kg(B, N, R)) {
+    case 4: launch_fused<4, false>(B, N, R, helios, sun, action, trig, trig_b_stride, plane, xs, ys, actual, refl, rays, image, none, st); break;
+    case 2: launch_fused<2, false>(B, N, R, helios, sun, action, trig, trig_b_stride, plane, xs, ys, actual, refl, rays, image, none, st); break;
+    default: launch_fused<1, false>(B, N, R, helios, sun, action, trig, trig_b_stride, plane, xs, ys, actual, refl, rays, image, none, st); break;
+    }
 }
 
 void launch_step_losses_final(int, int, int, int, int, float, const float*, const float*, float*, float*, float*,
                               int*, int, hipStream_t);
 
-// workspace floats of the fused env step: [B, tiles, 3] image partials + [B, 2] ray partials
+// workspace floats of the fused env step: [B, blocks, 3] image partials + [B, 2] ray partials
 long env_step_fused_workspace(int B, int R) {
-    const long t = (R + 63) / 64;
+    const long t = (R + 31) / 32;
     return 3l * B * t * t + 2l * B;
 }
 
@@ -652,14 +858,17 @@ void launch_env_step_fused(int B, int N, int R, const float* helios, const float
                            float mask_ratio, float* workspace, float* out, float* mae, float* keep,
                            float* align_err, float* all_bounds, float* aux, int* notify, int ticket,
                            hipStream_t st) {
-    const int t = (R + 63) / 64;
+    const int t = (R + 31) / 32;
     StepLossArgs L;
     L.target = target; L.tx = tx; L.dmaps = dmaps; L.ideal = ideal;
     L.part_img = workspace; L.part_ray = workspace + 3l * B * t * t;
     L.align_err = align_err; L.all_bounds = all_bounds; L.aux = aux;
     L.g = make_geom(tp, tn, W, H, exponential_risk);
-    hipLaunchKernelGGL(render_fwd_fused_small<true>, dim3(t * t + 1, B), dim3(256), 0, st, B, N, R, helios, sun, action,
-                       trig, trig_b_stride, to_k(plane), xs, ys, actual, refl, rays, image, L);
+    switch (fused_kg(B, N, R)) {
+    case 4: launch_fused<4, true>(B, N, R, helios, sun, action, trig, trig_b_stride, plane, xs, ys, actual, refl, rays, image, L, st); break;
+    case 2: launch_fused<2, true>(B, N, R, helios, sun, action, trig, trig_b_stride, plane, xs, ys, actual, refl, rays, image, L, st); break;
+    default: launch_fused<1, true>(B, N, R, helios, sun, action, trig, trig_b_stride, plane, xs, ys, actual, refl, rays, image, L, st); break;
+    }
     launch_step_losses_final(B, N, R, t * t, B, mask_ratio, L.part_img, L.part_ray, out, mae, keep, notify, ticket, st);
 }
 
