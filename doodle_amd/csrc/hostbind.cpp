@@ -135,6 +135,53 @@ struct RenderCtx {
         if (want_refl) return py::make_tuple(image, actual, refl);
         return py::make_tuple(image, actual);
     }
+    // Forward AND the gradient w.r.t. the action for GIVEN cotangents of (image, actual, refl) in one binding
+    // call: helio_render_fwd + helio_render_bwd back to back on the current stream, no autograd graph, the
+    // ray and moment buffers are the context's own scratch.  What an optimiser that already holds dL/dimage
+    // needs per step (BASELINE config 3).  → (image [B,R,R], actual [B,N,3], grad_action [B,N,3]); None when
+    // a tensor needs a dtype / device / layout fix-up (the caller then takes the general path).
+    at::Tensor moments_ws;
+    py::object render_and_grad(const at::Tensor& sun, const at::Tensor& action, c10::optional<at::Tensor> g_image,
+                               c10::optional<at::Tensor> g_actual, c10::optional<at::Tensor> g_refl, int64_t bwd_variant) {
+        const int64_t N = helios.size(0), R = xs.size(0);
+        if (!(sun.dim() == 2 && sun.scalar_type() == at::kFloat && action.scalar_type() == at::kFloat &&
+              sun.device() == helios.device() && action.device() == helios.device() && sun.is_contiguous() &&
+              action.is_contiguous() && action.numel() == sun.size(0) * N * 3))
+            return py::none();
+        const int64_t B = sun.size(0);
+        if (trig_b_stride != 0 && trig.numel() < B * N * 4) return py::none();
+        auto conforms = [&](const c10::optional<at::Tensor>& g, int64_t numel) {
+            return !g.has_value() || (g->scalar_type() == at::kFloat && g->device() == helios.device() && g->is_contiguous() &&
+                                      g->numel() == numel);
+        };
+        if (!conforms(g_image, B * R * R) || !conforms(g_actual, B * N * 3) || !conforms(g_refl, B * N * 3)) return py::none();
+        const auto opt = helios.options();
+        at::Tensor actual = at::empty({B, N, 3}, opt);
+        if (!rays_ws.defined() || rays_ws.size(0) != B) rays_ws = at::empty({B, N, HELIO_RAY_STRIDE}, opt);
+        at::Tensor image = at::empty({B, R, R}, opt);
+        at::Tensor grad = at::empty({B, N, 3}, opt);
+        void* st = cur_stream(helios);
+        const helio_plane* pl = reinterpret_cast<const helio_plane*>(plane);
+        check(helio_render_fwd((int)B, (int)N, (int)R, helios.data_ptr<float>(), sun.data_ptr<float>(),
+                               action.data_ptr<float>(), trig.data_ptr<float>(), (long)trig_b_stride, pl,
+                               xs.data_ptr<float>(), ys.data_ptr<float>(), actual.data_ptr<float>(), nullptr,
+                               rays_ws.data_ptr<float>(), image.data_ptr<float>(), (int)variant, st));
+        float* mom = nullptr;
+        if (g_image.has_value()) {
+            const int64_t jb = helio_splat_bwd_blocks((int)R);
+            if (!moments_ws.defined() || moments_ws.size(0) != B || moments_ws.size(1) != jb)
+                moments_ws = at::empty({B, jb, N, HELIO_MOMENT_STRIDE}, opt);
+            mom = moments_ws.data_ptr<float>();
+        }
+        check(helio_render_bwd((int)B, (int)N, (int)R, helios.data_ptr<float>(), sun.data_ptr<float>(),
+                               action.data_ptr<float>(), trig.data_ptr<float>(), (long)trig_b_stride, pl,
+                               rays_ws.data_ptr<float>(), xs.data_ptr<float>(), ys.data_ptr<float>(),
+                               g_image.has_value() ? g_image->data_ptr<float>() : nullptr,
+                               g_actual.has_value() ? g_actual->data_ptr<float>() : nullptr,
+                               g_refl.has_value() ? g_refl->data_ptr<float>() : nullptr, mom, grad.data_ptr<float>(),
+                               (int)bwd_variant, st));
+        return py::make_tuple(image, actual, grad);
+    }
 };
 
 at::Tensor render_bwd(int64_t plane, const at::Tensor& helios, const at::Tensor& sun, const at::Tensor& normals,
@@ -530,6 +577,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     py::class_<RenderCtx>(m, "RenderCtx")
         .def(py::init<int64_t, at::Tensor, at::Tensor, at::Tensor, at::Tensor, int64_t, int64_t>())
         .def("render", &RenderCtx::render)
+        .def("render_and_grad", &RenderCtx::render_and_grad)
         .def_readonly("trig", &RenderCtx::trig)
         .def_readonly("variant", &RenderCtx::variant);
     m.def("step_losses_fwd", &step_losses_fwd, py::arg("img"), py::arg("target"), py::arg("tx"), py::arg("dmaps"),

@@ -14,6 +14,7 @@
 // (moments[b, jb, n, :]) that helio_geometry_bwd adds in fixed order: no atomics,
 // bit-reproducible.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "helio.h"
 #include "step_loss_math.h"
 
@@ -287,102 +288,187 @@ splat_bwd_mfma(int B, int N, int R, const float* __restrict__ rays, const float*
     }
 }
 
-// Small problems: the same two contractions in ONE launch (blockIdx.z = pass) with 64 c × 64
-// rays per 4-wave workgroup (each wave one 32×32 MFMA block), so config 3 (B=25, N=50, R=128)
-// spreads over 100 workgroups instead of 25.  The grad-image slab of a 128-deep k-chunk sits in
-// LDS; the factor operand is computed in registers by the lane that owns (k, ray); the two
-// waves that share a ray block combine their 32-c halves through LDS before writing.
-template <int PASS>
-__device__ __forceinline__ void splat_bwd_small_body(int B, int N, int R, const float* __restrict__ rays,
+// Small problems (config 3: B=25, N=50, R=128) are bound by the latency of ONE wave, not by the matrix
+// pipe: the round-1 form of this kernel (64 c × 64 rays per 4-wave workgroup, a 128-deep k-chunk staged
+// in LDS, every wave 64 dependent MFMAs) took 14.5–16 µs on 100 of the 256 CUs.  Same two contractions,
+// one launch (blockIdx.z = pass), reshaped like the fused forward kernel:
+//   * a workgroup is 64 c × 32 rays (one partial block of the moment buffer, one ray block) and KS waves
+//     that SPLIT THE CONTRACTED AXIS between them: config 3 runs 200 workgroups of 4 waves, 32 MFMAs each;
+//   * no LDS staging and no barrier in front of the MFMAs: the grad-image operand goes from global
+//     memory straight into the MFMA's A register (lane ↔ c: coalesced rows in pass 0; in pass 1 a lane
+//     reads its own image row, 16 bytes at a time where R % 4 == 0), the factor operand is computed in
+//     registers by the lane that owns (k, ray), and all loads of a group of 8 k-pairs are issued ahead of
+//     its MFMAs;
+//   * every wave weights its partial block with the other-axis factor and reduces it over c in
+//     registers, so that only three numbers per ray cross the workgroup (LDS, one barrier), summed in
+//     fixed wave order.
+template <int PASS, int KS>
+__device__ __forceinline__ void splat_bwd_small_body(int N, int R, const float* __restrict__ rays,
                                                      const float* __restrict__ xs, const float* __restrict__ ys,
                                                      const float* __restrict__ gimg, float* __restrict__ moments,
                                                      float* smem) {
-    constexpr int KC = 128, T = 64, LD = T + 1;
-    float* __restrict__ sG = smem;                 // [KC][LD]
-    float* __restrict__ sKc = smem + KC * LD;      // [KC]
-    float* __restrict__ sCc = sKc + KC;            // [T]
-    float* __restrict__ sRed = sCc + T;            // [2 ray blocks][32 rays][3]
+    float* __restrict__ sCc = smem;                // [KS][64] c coordinates, one private copy per wave
+    float* __restrict__ sRed = smem + KS * 64;     // [KS][32 rays][3]
 
-    const int c_tiles = (R + T - 1) / T;
+    const int JB = (R + 63) / 64;
     const int b = blockIdx.y;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 31, lh = lane >> 5;
-    const int c0 = (blockIdx.x % c_tiles) * T, n0 = (blockIdx.x / c_tiles) * T;
-    const int wc = (wave >> 1) * 32, wn = (wave & 1) * 32;
-    const float* __restrict__ ccoord = PASS == 0 ? ys : xs;
-    const float* __restrict__ kcoord = PASS == 0 ? xs : ys;
+    const int c0 = (blockIdx.x % JB) * 64, n0 = (blockIdx.x / JB) * 32;
+    const float* __restrict__ ccoord = PASS == 0 ? ys : xs;   // coordinates along c (the axis that survives)
+    const float* __restrict__ kcoord = PASS == 0 ? xs : ys;   // coordinates along k (the contracted axis)
     const float* __restrict__ G = gimg + (long)b * R * R;
 
-    if (tid < T) sCc[tid] = ccoord[min(c0 + tid, R - 1)];
-    const int n = n0 + wn + lr;                                    // this lane's ray (B operand and epilogue)
-    float4 q = make_float4(0.f, 0.f, 1.f, 1e30f);
-    if (n < N) q = reinterpret_cast<const float4*>(rays)[(long)b * N + n];
-    const float sk = __builtin_sqrtf(q.z);
-    const float fshift = (PASS == 0 ? q.x : q.y) * sk;
-    const float fcc = PASS == 0 ? q.w * q.z : 0.0f;
+    // this wave's part of the contracted axis: k-pairs dealt evenly, in multiples of 2 (so that a wave
+    // starts at a multiple of 4: 16-byte row segments in pass 1)
+    const int pairs = (R + 1) >> 1;
+    const int per = (((pairs + KS - 1) / KS) + 1) & ~1;
+    const int k_begin = min(R, 2 * per * wave), k_end = min(R, 2 * per * (wave + 1));
 
-    f32x16 acc;
+    // this lane's ray (B operand and epilogue) and its c coordinate: requested first, used only after the
+    // first group of grad-image loads has been issued — every first touch of memory in a freshly launched
+    // kernel costs ≈900 cycles, so none of them may wait for another
+    const int n = n0 + lr;
+    const float4 qraw = reinterpret_cast<const float4*>(rays)[(long)b * N + min(n, N - 1)];
+    const float ccv = ccoord[min(c0 + lane, R - 1)];
+
+    f32x16 acc0, acc1;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+    for (int e = 0; e < 16; ++e) { acc0[e] = 0.0f; acc1[e] = 0.0f; }
 
-    for (int k0 = 0; k0 < R; k0 += KC) {
-        __syncthreads();
-        // slab Gm[k][c]: pass 0 → G[k0+k][c0+c] (lanes ↔ c), pass 1 → G[c0+c][k0+k] (lanes ↔ k)
-        for (int idx = tid; idx < KC * T; idx += 256) {
-            const int k = PASS == 0 ? idx >> 6 : idx & (KC - 1), c = PASS == 0 ? idx & 63 : idx >> 7;
-            const int row = PASS == 0 ? k0 + k : c0 + c, col = PASS == 0 ? c0 + c : k0 + k;
-            sG[k * LD + c] = (row < R && col < R) ? G[(long)row * R + col] : 0.0f;
+    const int ca = c0 + lr, cb = c0 + 32 + lr;                  // this lane's two c (A operands of the two blocks)
+    const bool vec = PASS == 1 && (R & 3) == 0;                 // (uniform) pass 1 may read 16-byte row segments
+    for (int k0 = k_begin; k0 < k_end; k0 += 16) {              // groups of 8 k-pairs
+        float ga[8], gb[8], kc[8];
+        // every load is unconditional, from a clamped (valid) address; what lies outside the image or
+        // this wave's part is zeroed AFTER the whole group has been fetched (hipcc turns "in range ? load
+        // : 0" into a branch around each load, and then waits for each on its own)
+        const long rowa = (long)min(ca, R - 1) * R, rowb = (long)min(cb, R - 1) * R;
+        if (vec) {
+            // G[c][k0 .. k0+15]: lane (c, lh) uses elements lh and 2 + lh of every 16-byte segment
+            float4 va[4], vb[4];
+#pragma unroll
+            for (int j4 = 0; j4 < 4; ++j4) {
+                const int kk = min(k0 + 4 * j4, R - 4);       // (R % 4 == 0: a whole segment is in or out)
+                va[j4] = *reinterpret_cast<const float4*>(G + rowa + kk);
+                vb[j4] = *reinterpret_cast<const float4*>(G + rowb + kk);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) kc[j] = kcoord[min(k0 + 2 * j + lh, R - 1)];
+#pragma unroll
+            for (int j4 = 0; j4 < 4; ++j4)
+                asm volatile("" :: "v"(va[j4].x), "v"(va[j4].y), "v"(va[j4].z), "v"(va[j4].w), "v"(vb[j4].x), "v"(vb[j4].y),
+                             "v"(vb[j4].z), "v"(vb[j4].w), "v"(kc[2 * j4]), "v"(kc[2 * j4 + 1]));
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j4 = 0; j4 < 4; ++j4) {
+                const bool ok = k0 + 4 * j4 < k_end;
+                ga[2 * j4] = (ok && ca < R) ? (lh ? va[j4].y : va[j4].x) : 0.0f;
+                ga[2 * j4 + 1] = (ok && ca < R) ? (lh ? va[j4].w : va[j4].z) : 0.0f;
+                gb[2 * j4] = (ok && cb < R) ? (lh ? vb[j4].y : vb[j4].x) : 0.0f;
+                gb[2 * j4 + 1] = (ok && cb < R) ? (lh ? vb[j4].w : vb[j4].z) : 0.0f;
+            }
+        } else {
+            float ra[8], rb[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int kk = min(k0 + 2 * j + lh, R - 1);
+                ra[j] = PASS == 0 ? G[(long)kk * R + min(ca, R - 1)] : G[rowa + kk];
+                rb[j] = PASS == 0 ? G[(long)kk * R + min(cb, R - 1)] : G[rowb + kk];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) kc[j] = kcoord[min(k0 + 2 * j + lh, R - 1)];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) asm volatile("" :: "v"(ra[j]), "v"(rb[j]), "v"(kc[j]));
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const bool ok = k0 + 2 * j + lh < k_end;
+                ga[j] = (ok && ca < R) ? ra[j] : 0.0f;
+                gb[j] = (ok && cb < R) ? rb[j] : 0.0f;
+            }
         }
-        if (tid < KC) sKc[tid] = kcoord[min(k0 + tid, R - 1)];
-        __syncthreads();
-        const int kmax = min(KC, R - k0);
-#pragma unroll 4
-        for (int kp = 0; 2 * kp < kmax; ++kp) {
-            const int k = 2 * kp + lh;
-            const float g = sG[k * LD + wc + lr];
-            const float t = __builtin_fmaf(sKc[k], sk, fshift);
-            float f = __builtin_amdgcn_exp2f(-__builtin_fmaf(t, t, fcc));
-            if (k >= kmax) f = 0.0f;
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(g, f, acc, 0, 0, 0);
+        // (the ray's constants are derived HERE, behind the group's loads: computed in front of the loop
+        // they would put the ray's own load latency in front of every other load)
+        float4 q = qraw;
+        asm volatile("" : "+v"(q.x), "+v"(q.y), "+v"(q.z), "+v"(q.w));
+        if (n >= N) q = make_float4(0.f, 0.f, 1.f, 1e30f);      // padding ray: factor = exp2(-1e30) = 0
+        const float sk = __builtin_sqrtf(q.z);
+        const float fshift = (PASS == 0 ? q.x : q.y) * sk;
+        const float fcc = PASS == 0 ? q.w * q.z : 0.0f;
+        float f[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float t = __builtin_fmaf(kc[j], sk, fshift);
+            f[j] = (k0 + 2 * j + lh < k_end) ? __builtin_amdgcn_exp2f(-__builtin_fmaf(t, t, fcc)) : 0.0f;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) asm volatile("" :: "v"(f[j]));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (k0 + 2 * j >= k_end) break;
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[j], f[j], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(gb[j], f[j], acc1, 0, 0, 0);
         }
     }
 
-    // epilogue: lane = ray (column lr), registers = 16 values of c
-    const float hshift = PASS == 0 ? q.y : q.x;
-    const float hcc = PASS == 0 ? 0.0f : q.w;
-    const float hk = n < N ? q.z : 0.0f;
+    // epilogue: lane = ray (column lr), registers = 16 values of c per block; weight by the other-axis
+    // factor and reduce over this wave's 64 c
+    const float hshift = PASS == 0 ? qraw.y : qraw.x;
+    const float hcc = PASS == 0 ? 0.0f : qraw.w;
+    const float hk = n < N ? qraw.z : 0.0f;
     float m0 = 0.f, m1 = 0.f, m2 = 0.f;
+    sCc[wave * 64 + lane] = ccv;                                // wave-private: LDS is in order within a wave
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        const int cl = wc + (e & 3) + 8 * (e >> 2) + 4 * lh;
-        const float s = sCc[cl] + hshift;
-        const float w = __builtin_amdgcn_exp2f(-(__builtin_fmaf(s, s, hcc) * hk)) * acc[e];
-        m0 += w;
-        m1 = __builtin_fmaf(s, w, m1);
-        m2 = __builtin_fmaf(s * s, w, m2);
-    }
+    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int cl = 32 * blk + (e & 3) + 8 * (e >> 2) + 4 * lh;
+            const float s = sCc[wave * 64 + cl] + hshift;
+            const float w = __builtin_amdgcn_exp2f(-(__builtin_fmaf(s, s, hcc) * hk)) * (blk == 0 ? acc0[e] : acc1[e]);
+            m0 += w;
+            m1 = __builtin_fmaf(s, w, m1);
+            m2 = __builtin_fmaf(s * s, w, m2);
+        }
     m0 += __shfl_xor(m0, 32); m1 += __shfl_xor(m1, 32); m2 += __shfl_xor(m2, 32);
-    __syncthreads();
-    if (wave >= 2 && lh == 0) {                                    // c half 1 hands over to c half 0
-        float* r = sRed + ((wave & 1) * 32 + lr) * 3;
+    if (lh == 0) {
+        float* r = sRed + (wave * 32 + lr) * 3;
         r[0] = m0; r[1] = m1; r[2] = m2;
     }
     __syncthreads();
-    if (wave < 2 && lh == 0 && n < N) {
-        const float* r = sRed + ((wave & 1) * 32 + lr) * 3;
-        const int JB = (R + 63) / 64;
+    if (tid < 32 && n < N) {                                       // fixed order over the KS k-parts
+        float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < KS; ++w) {
+            const float* r = sRed + (w * 32 + lr) * 3;
+            if (w == 0) { t0 = r[0]; t1 = r[1]; t2 = r[2]; } else { t0 += r[0]; t1 += r[1]; t2 += r[2]; }
+        }
         float* o = moments + (((long)b * JB + c0 / 64) * N + n) * HELIO_MOMENT_STRIDE;
-        if (PASS == 0) { o[0] = m0 + r[0]; o[2] = m1 + r[1]; o[4] = m2 + r[2]; }
-        else { o[1] = m1 + r[1]; o[3] = m2 + r[2]; }
+        if (PASS == 0) { o[0] = t0; o[2] = t1; o[4] = t2; }
+        else { o[1] = t1; o[3] = t2; }
     }
 }
 
-__global__ void __launch_bounds__(256)
-splat_bwd_mfma_small(int B, int N, int R, const float* __restrict__ rays, const float* __restrict__ xs,
+template <int KS>
+__global__ void __launch_bounds__(64 * KS)
+splat_bwd_mfma_small(int N, int R, const float* __restrict__ rays, const float* __restrict__ xs,
                      const float* __restrict__ ys, const float* __restrict__ gimg, float* __restrict__ moments) {
-    __shared__ float smem[128 * 65 + 128 + 64 + 192];
-    if (blockIdx.z == 0) splat_bwd_small_body<0>(B, N, R, rays, xs, ys, gimg, moments, smem);
-    else splat_bwd_small_body<1>(B, N, R, rays, xs, ys, gimg, moments, smem);
+    __shared__ float smem[KS * 64 + KS * 32 * 3];
+    if (blockIdx.z == 0) splat_bwd_small_body<0, KS>(N, R, rays, xs, ys, gimg, moments, smem);
+    else splat_bwd_small_body<1, KS>(N, R, rays, xs, ys, gimg, moments, smem);
+}
+
+// waves per workgroup of the small backward kernel (they split the contracted axis): 8 while that keeps
+// the chip at about one wave per SIMD, else 4; HELIO_BWD_KS (4 or 8) forces one — tuning runs only
+static int bwd_small_ks(int B, int N, int R) {
+    static const int forced = [] { const char* e = getenv("HELIO_BWD_KS"); return e ? atoi(e) : 0; }();
+    if (forced == 4 || forced == 8) return forced;
+    const long wgs = 2l * B * ((R + 63) / 64) * ((N + 31) / 32);
+    return (wgs * 8 <= 1536 && R >= 64) ? 8 : 4;
 }
 
 template <int PASS>
@@ -861,8 +947,11 @@ int launch_splat_bwd(int B, int N, int R, const float* rays, const float* xs, co
         return HELIO_OK;
     }
     if (variant == 3) {
-        const int ct = (R + 63) / 64, nt = (N + 63) / 64;
-        hipLaunchKernelGGL(splat_bwd_mfma_small, dim3(ct * nt, B, 2), dim3(256), 0, st, B, N, R, rays, xs, ys, gimg, moments);
+        const int ct = (R + 63) / 64, nt = (N + 31) / 32;
+        if (bwd_small_ks(B, N, R) == 8)
+            hipLaunchKernelGGL(splat_bwd_mfma_small<8>, dim3(ct * nt, B, 2), dim3(512), 0, st, N, R, rays, xs, ys, gimg, moments);
+        else
+            hipLaunchKernelGGL(splat_bwd_mfma_small<4>, dim3(ct * nt, B, 2), dim3(256), 0, st, N, R, rays, xs, ys, gimg, moments);
         return HELIO_OK;
     }
     if (variant == 2) {

@@ -1237,3 +1237,39 @@ def test_attribute_assignments_reach_the_compiled_contexts():
     a2 = a.clone().requires_grad_(True)
     o3, m3, _ = env.step(a2)                     # the autograd path reads the field directly
     assert torch.equal(o3["img"].detach(), o2["img"]) and torch.equal(m3["mse"].detach(), m2["mse"])
+
+
+@pytest.mark.parametrize("N,B,R", [(50, 25, 128), (33, 3, 100), (300, 40, 256), (1, 500, 128)])
+def test_render_value_and_grad_equals_render_plus_autograd(N, B, R):
+    """HelioField.render_value_and_grad — forward and backward kernels enqueued back to back by one
+    binding call, no autograd graph (BASELINE config 3) — gives the image, `actual` and the gradient
+    of render + torch.autograd.grad bit for bit (same kernels on the same inputs), through the compiled
+    context and through the ctypes binding, for every subset of cotangents."""
+    from doodle_amd import native
+    f, _, suns, _, act = make_case(N, B, R, seed=N + R)
+    suns_d, a = suns.to(DEV), act.to(DEV)
+    g = torch.Generator(device=DEV).manual_seed(3)
+    G = torch.randn(B, R, R, device=DEV, generator=g)
+    H, Q = torch.randn(B, N, 3, device=DEV, generator=g), torch.randn(B * N, 3, device=DEV, generator=g)
+    ar = a.clone().requires_grad_(True)
+    img0, actual0, refl0 = f.render(suns_d, ar, None, monitor=True)
+    for cots in ((G, H, Q), (G, None, None), (None, H, None), (G, H, None)):
+        loss = sum(((o * c).sum() for o, c in zip((img0, actual0, refl0), cots) if c is not None))
+        (ref,) = torch.autograd.grad(loss, ar, retain_graph=True)
+        img, actual, grad = f.render_value_and_grad(suns_d, a, *cots)
+        assert torch.equal(img, img0.detach()) and torch.equal(actual, actual0.detach())
+        assert grad.shape == (B, 3 * N) and torch.equal(grad, ref.reshape(B, -1))
+    ops = native.get_ops()
+    hb, ops.hb = ops.hb, None                       # the ctypes binding of the same two C calls
+    f._fast_render, f._ctx_key = None, None
+    try:
+        img, actual, grad = f.render_value_and_grad(suns_d, a, G, H, Q)
+    finally:
+        ops.hb = hb
+        f._fast_render, f._ctx_key = None, None
+    (ref,) = torch.autograd.grad((img0 * G).sum() + (actual0 * H).sum() + (refl0 * Q).sum(), ar)
+    assert torch.equal(grad, ref.reshape(B, -1)) and torch.equal(img, img0.detach())
+    # lists / a 1-D sun / other dtypes, like render()
+    img1, actual1, grad1 = f.render_value_and_grad(suns[0].double().numpy(), act[0].tolist(), G[0].cpu().numpy())
+    assert img1.shape == (R, R) and actual1.shape == (1, N, 3) and grad1.shape == (1, 3 * N)
+    assert torch.isfinite(grad1).all()

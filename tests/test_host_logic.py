@@ -157,6 +157,31 @@ def test_decomposition_matches_reference(name, monkeypatch):
         assert np.abs(ga.numpy().reshape(ref.shape) - ref).max() <= 2e-4 * max(np.abs(ref).max(), 1e-30), key
 
 
+@pytest.mark.parametrize("name", ["g1_readme_n50_b25_r64", "g1_single_1d_n50_r64", "g8_ragged_n33_b3_r100"])
+def test_render_value_and_grad_matches_reference_gradients(name, monkeypatch):
+    """render_value_and_grad (forward + gradient for given cotangents, no autograd graph) against the
+    reference's own gradients, and against render + torch.autograd.grad of this package."""
+    oracle_backend.install(monkeypatch)
+    g = golden(name)
+    f = field_from(g)
+    sun, act = torch.from_numpy(g["sun"]), torch.from_numpy(g["action"])
+    G, H, Q = (torch.from_numpy(g[k]) for k in ("G", "H", "Q"))
+    img, actual, grad = f.render_value_and_grad(sun, act, G, H, Q)
+    assert tuple(img.shape) == g["image"].shape and np.array_equal(actual.numpy(), g["actual"])
+    np.testing.assert_allclose(img.numpy(), g["image"], rtol=1e-5, atol=1e-8)
+    ref = g["grad_all"]
+    assert grad.shape == (np.atleast_2d(g["sun"]).shape[0], 3 * f.num_heliostats)
+    assert np.abs(grad.numpy().reshape(ref.shape) - ref).max() <= 2e-4 * np.abs(ref).max()
+    a = act.clone().requires_grad_(True)
+    i2, a2, r2 = f.render(sun, a, None, monitor=True)
+    (g2,) = torch.autograd.grad((i2 * G.reshape(i2.shape)).sum() + (a2 * H).sum() + (r2 * Q).sum(), a)
+    assert torch.equal(grad.reshape(g2.shape), g2) and torch.equal(img, i2.detach())
+    # any subset of the cotangents
+    _, _, g_img_only = f.render_value_and_grad(sun, act, G)
+    ref = g["grad_from_image"]
+    assert np.abs(g_img_only.numpy().reshape(ref.shape) - ref).max() <= 2e-4 * np.abs(ref).max()
+
+
 def test_return_conventions_and_error_selection(monkeypatch):
     oracle_backend.install(monkeypatch)
     g = golden("g1_single_1d_n50_r64")

@@ -60,7 +60,14 @@ def main():
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for _ in range(n): f.render(suns_d, act, None)
         torch.cuda.synchronize(); elf = (time.perf_counter() - t0) / n
-    print(f"   render fwd {elf*1e6:9.1f} us/call = {B/elf:12.0f} frames/s | fwd+bwd {el*1e6:9.1f} us/call = {B/el:12.0f} frames/s")
+    print(f"   render fwd {elf*1e6:9.1f} us/call = {B/elf:12.0f} frames/s | fwd+bwd (autograd) {el*1e6:9.1f} us/call = {B/el:12.0f} frames/s")
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 0.3: f.render_value_and_grad(suns_d, act, G, H)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    n2 = 2000 if iters > 100 else 5
+    for _ in range(n2): f.render_value_and_grad(suns_d, act, G, H)
+    torch.cuda.synchronize(); elv = (time.perf_counter() - t0) / n2
+    print(f"   render_value_and_grad (fwd + bwd kernels back to back, one binding call) {elv*1e6:9.1f} us/call = {B/elv:12.0f} frames/s")
 
 if __name__ == "__main__":
     main()
