@@ -153,17 +153,25 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(3))) float lds_f;
 typedef __attribute__((address_space(3))) const float lds_cf;
 
-template <int PASS>
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <int PASS, bool VEC>
 __global__ void __launch_bounds__(1024)
 splat_bwd_mfma(int B, int N, int R, const float* __restrict__ rays, const float* __restrict__ xs,
                const float* __restrict__ ys, const float* __restrict__ gimg, float* __restrict__ moments) {
-    constexpr int KC = 64, T = 256, LD = T + 1;
+    static_assert(!(VEC && PASS == 1), "16-byte staging is pass 0's");
+    // Row pitch of the two LDS tables.  Pass 1 writes the slab transposed (lanes ↔ k at stride LD):
+    // an odd pitch keeps that conflict-free.  Pass 0 writes it along c and stages it 16 bytes at a time
+    // (global_load_dwordx4 + ds_write_b128 where R % 4 == 0): a pitch that is a multiple of 4 keeps
+    // every row 16-byte aligned; reads (lanes ↔ consecutive c or rays) are conflict-free either way.
+    constexpr int KC = 64, T = 256, LD = PASS == 0 ? T + 4 : T + 1;
     extern __shared__ __attribute__((aligned(16))) float smem[];   // sG[KC][LD] sF[KC][LD] ccoord[T]
     float* __restrict__ sCc = smem + 2 * KC * LD;
 
     const int c_tiles = (R + T - 1) / T;
     const int b = blockIdx.y;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // scalar: nothing of it is kept in (or spilled from) VGPRs
     const int lr = lane & 31, lh = lane >> 5;
     const int c0 = (blockIdx.x % c_tiles) * T, n0 = (blockIdx.x / c_tiles) * T;
     const int wc = (wave >> 2) * 64, wn = (wave & 3) * 64;
@@ -174,7 +182,7 @@ splat_bwd_mfma(int B, int N, int R, const float* __restrict__ rays, const float*
     if (tid < T) sCc[tid] = ccoord[min(c0 + tid, R - 1)];
 
     // producer role for the factor table: ray (wave&3)*64 + lane of the tile, 16 k of every chunk
-    const int pr = (wave & 3) * 64 + lane;
+    const int pr = wn + lane;
     const int pk0 = (wave >> 2) * 16;
     float4 q = make_float4(0.f, 0.f, 1.f, 1e30f);
     if (n0 + pr < N) q = reinterpret_cast<const float4*>(rays)[(long)b * N + n0 + pr];
@@ -183,28 +191,48 @@ splat_bwd_mfma(int B, int N, int R, const float* __restrict__ rays, const float*
     const float fcc = PASS == 0 ? q.w * q.z : 0.0f;
     lds_f* fdst = (lds_f*)smem + KC * LD + pk0 * LD + pr;
 
-    // loader role for the grad-image slab Gm[k][c]: 16 dwords per thread and chunk, element
-    // idx = tid + 1024·v.  Lanes run along the axis that is contiguous in G (coalesced 256-B
-    // wave loads) and the LDS image is written without bank conflicts:
-    //   pass 0: Gm[k][c] = G[k0+k][c0+c]:  k = idx>>8, c = idx&255  (lanes ↔ c, stride 1 in LDS)
-    //   pass 1: Gm[k][c] = G[c0+c][k0+k]:  k = idx&63, c = idx>>6   (lanes ↔ k, stride LD = 257)
+    // loader role for the grad-image slab Gm[k][c]: 16 dwords per thread and chunk.
+    //   pass 0: Gm[k][c] = G[k0+k][c0+c].  R % 4 == 0 (uniform): four 16-byte pieces per thread, piece
+    //           p = tid + 1024·v covers k = p>>6, c = 4(p&63)..+3 — a wave reads 1 KB of one image row and
+    //           writes 1 KB of one LDS row.  Otherwise dword by dword, lanes ↔ c.
+    //   pass 1: Gm[k][c] = G[c0+c][k0+k]:  k = idx&63, c = idx>>6   (lanes ↔ k, stride LD = 257 in LDS)
     float gv[16];
     auto load_slab = [&](int k0) {
+        if constexpr (VEC) {
 #pragma unroll
-        for (int v = 0; v < 16; ++v) {
-            const int idx = tid + 1024 * v;
-            const int k = PASS == 0 ? idx >> 8 : idx & 63, c = PASS == 0 ? idx & 255 : idx >> 6;
-            const int row = PASS == 0 ? k0 + k : c0 + c, col = PASS == 0 ? c0 + c : k0 + k;
-            gv[v] = (row < R && col < R) ? G[(long)row * R + col] : 0.0f;
+            for (int v = 0; v < 4; ++v) {
+                const int p = tid + 1024 * v;
+                const int row = k0 + (p >> 6), col = c0 + 4 * (p & 63);
+                float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (row < R && col < R) t = *reinterpret_cast<const float4*>(G + (long)row * R + col);
+                gv[4 * v] = t.x; gv[4 * v + 1] = t.y; gv[4 * v + 2] = t.z; gv[4 * v + 3] = t.w;
+            }
+        } else {
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int idx = tid + 1024 * v;
+                const int k = PASS == 0 ? idx >> 8 : idx & 63, c = PASS == 0 ? idx & 255 : idx >> 6;
+                const int row = PASS == 0 ? k0 + k : c0 + c, col = PASS == 0 ? c0 + c : k0 + k;
+                gv[v] = (row < R && col < R) ? G[(long)row * R + col] : 0.0f;
+            }
         }
     };
     auto store_slab = [&]() {
-        lds_f* dst = (lds_f*)smem;
+        if constexpr (VEC) {
 #pragma unroll
-        for (int v = 0; v < 16; ++v) {
-            const int idx = tid + 1024 * v;
-            const int k = PASS == 0 ? idx >> 8 : idx & 63, c = PASS == 0 ? idx & 255 : idx >> 6;
-            dst[k * LD + c] = gv[v];
+            for (int v = 0; v < 4; ++v) {
+                const int p = tid + 1024 * v;
+                *reinterpret_cast<float4*>(smem + (p >> 6) * LD + 4 * (p & 63)) =
+                    make_float4(gv[4 * v], gv[4 * v + 1], gv[4 * v + 2], gv[4 * v + 3]);
+            }
+        } else {
+            lds_f* dst = (lds_f*)smem;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int idx = tid + 1024 * v;
+                const int k = PASS == 0 ? idx >> 8 : idx & 63, c = PASS == 0 ? idx & 255 : idx >> 6;
+                dst[k * LD + c] = gv[v];
+            }
         }
     };
 
@@ -224,14 +252,16 @@ splat_bwd_mfma(int B, int N, int R, const float* __restrict__ rays, const float*
     asm volatile("" : "+v"(pg1));
     asm volatile("" : "+v"(pf1));
 
+    // (skipping the MFMAs of ray blocks past the last heliostat — N = 2000 fills 7.8 of its 8 tiles — was
+    // tried as a wave-uniform choice between a 4- and a 2-MFMA loop: the second unrolled loop cost 72
+    // spilled registers; not kept)
     // the 16 contraction coordinates a wave needs per chunk are wave-uniform: scalar loads, no
     // LDS staging (and one barrier fewer per chunk)
-    const int upk0 = __builtin_amdgcn_readfirstlane(pk0);
     load_slab(0);
     for (int k0 = 0; k0 < R; k0 += KC) {
         float kc[16];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) kc[j] = kcoord[min(k0 + upk0 + j, R - 1)];
+        for (int j = 0; j < 16; ++j) kc[j] = kcoord[min(k0 + pk0 + j, R - 1)];
         __syncthreads();                                   // previous chunk consumed
         store_slab();
         if (k0 + KC < R) load_slab(k0 + KC);               // in flight during the chunk
@@ -239,7 +269,7 @@ splat_bwd_mfma(int B, int N, int R, const float* __restrict__ rays, const float*
         for (int j = 0; j < 16; ++j) {
             const float t = __builtin_fmaf(kc[j], sk, fshift);
             float f = __builtin_amdgcn_exp2f(-__builtin_fmaf(t, t, fcc));
-            if (k0 + upk0 + j >= R) f = 0.0f;              // rows/cols past the image contract nothing
+            if (k0 + pk0 + j >= R) f = 0.0f;               // rows/cols past the image contract nothing
             fdst[j * LD] = f;
         }
         __syncthreads();
@@ -254,36 +284,47 @@ splat_bwd_mfma(int B, int N, int R, const float* __restrict__ rays, const float*
         }
     }
 
-    // epilogue: this lane's ray is column lr of ray block nb; the 16 registers of an
-    // accumulator block are c = (e&3) + 8(e>>2) + 4·lh of c block cb
+    // epilogue: this lane's ray is column lr of ray block nb; the 16 registers of an accumulator block
+    // are c = (e&3) + 8(e>>2) + 4·lh of c block cb.  Two values of c at a time (registers e, e+1 are
+    // neighbours in c): the weights, the products and the three running sums are formed on float pairs
+    // (v_pk_add/mul/fma_f32: one instruction per pair; no MFMA runs beside them here).
     const int JB = (R + 63) / 64;
     const int cblock = (c0 + wc) / 64;
     if (c0 + wc >= R) return;                              // (wave-uniform) nothing of the image here
+    // the lane's place in the wave, read again: keeping lr / lh alive across the loop cost two spilled registers
+    const int lane2 = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const int lr2 = lane2 & 31, lh2 = lane2 >> 5;
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
-        const int n = n0 + wn + 32 * nb + lr;
+        const int n = n0 + wn + 32 * nb + lr2;
         float4 h = make_float4(0.f, 0.f, 0.f, 0.f);
         if (n < N) h = reinterpret_cast<const float4*>(rays)[(long)b * N + n];
         const float hshift = PASS == 0 ? h.y : h.x;
         const float hcc = PASS == 0 ? 0.0f : h.w;
-        float m0 = 0.f, m1 = 0.f, m2 = 0.f;
+        const f32x2 sh = {hshift, hshift}, cc2 = {hcc, hcc}, nk = {-h.z, -h.z};
+        f32x2 m0 = {0.f, 0.f}, m1 = {0.f, 0.f}, m2 = {0.f, 0.f};
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int cl = wc + 32 * cb + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                const float s = sCc[cl] + hshift;
-                const float w = __builtin_amdgcn_exp2f(-(__builtin_fmaf(s, s, hcc) * h.z)) * acc[2 * cb + nb][e];
+            for (int e = 0; e < 16; e += 2) {
+                const int cl = wc + 32 * cb + (e & 3) + 8 * (e >> 2) + 4 * lh2;
+                const f32x2 s = *reinterpret_cast<const f32x2*>(&sCc[cl]) + sh;
+                const f32x2 ss = s * s;
+                const f32x2 arg = (ss + cc2) * nk;
+                const f32x2 a = {acc[2 * cb + nb][e], acc[2 * cb + nb][e + 1]};
+                const f32x2 ex = {__builtin_amdgcn_exp2f(arg.x), __builtin_amdgcn_exp2f(arg.y)};
+                const f32x2 w = ex * a;
                 m0 += w;
-                m1 = __builtin_fmaf(s, w, m1);
-                m2 = __builtin_fmaf(s * s, w, m2);
+                m1 += s * w;
+                m2 += ss * w;
             }
         }
-        m0 += __shfl_xor(m0, 32); m1 += __shfl_xor(m1, 32); m2 += __shfl_xor(m2, 32);
-        if (lh == 0 && n < N) {
+        float t0 = m0.x + m0.y, t1 = m1.x + m1.y, t2 = m2.x + m2.y;
+        t0 += __shfl_xor(t0, 32); t1 += __shfl_xor(t1, 32); t2 += __shfl_xor(t2, 32);
+        if (lh2 == 0 && n < N) {
             float* o = moments + (((long)b * JB + cblock) * N + n) * HELIO_MOMENT_STRIDE;
-            if (PASS == 0) { o[0] = m0; o[2] = m1; o[4] = m2; }
-            else { o[1] = m1; o[3] = m2; }
+            if (PASS == 0) { o[0] = t0; o[2] = t1; o[4] = t2; }
+            else { o[1] = t1; o[3] = t2; }
         }
     }
 }
@@ -471,18 +512,31 @@ static int bwd_small_ks(int B, int N, int R) {
     return (wgs * 8 <= 1536 && R >= 64) ? 8 : 4;
 }
 
-template <int PASS>
-static void launch_bwd_mfma(int B, int N, int R, const float* rays, const float* xs, const float* ys,
-                            const float* gimg, float* moments, hipStream_t st) {
-    const size_t lds = (2 * 64 * 257 + 256 + 64) * sizeof(float);
+template <int PASS, bool VEC>
+static void launch_bwd_mfma_v(int B, int N, int R, const float* rays, const float* xs, const float* ys,
+                              const float* gimg, float* moments, hipStream_t st) {
+    const size_t lds = (2 * 64 * (PASS == 0 ? 260 : 257) + 256 + 64) * sizeof(float);
     static bool configured = false;
     if (!configured) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(splat_bwd_mfma<PASS>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(splat_bwd_mfma<PASS, VEC>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         configured = true;
     }
     const int ct = (R + 255) / 256, nt = (N + 255) / 256;
-    hipLaunchKernelGGL(splat_bwd_mfma<PASS>, dim3(ct * nt, B), dim3(1024), lds, st, B, N, R, rays, xs, ys, gimg, moments);
+    hipLaunchKernelGGL((splat_bwd_mfma<PASS, VEC>), dim3(ct * nt, B), dim3(1024), lds, st, B, N, R, rays, xs, ys, gimg, moments);
+}
+
+template <int PASS>
+static void launch_bwd_mfma(int B, int N, int R, const float* rays, const float* xs, const float* ys,
+                            const float* gimg, float* moments, hipStream_t st) {
+    if constexpr (PASS == 0) {
+        // 16-byte staging of the grad-image slab needs whole 4-pixel pieces per row (the image base is
+        // 16-byte aligned by the ABI's contract)
+        if ((R & 3) == 0) return launch_bwd_mfma_v<0, true>(B, N, R, rays, xs, ys, gimg, moments, st);
+        return launch_bwd_mfma_v<0, false>(B, N, R, rays, xs, ys, gimg, moments, st);
+    } else {
+        return launch_bwd_mfma_v<1, false>(B, N, R, rays, xs, ys, gimg, moments, st);
+    }
 }
 
 // ----------------------------------------------------------------------------------------------

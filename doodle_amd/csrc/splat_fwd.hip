@@ -28,6 +28,7 @@
 // then the running total); the throughput kernels in one level — fewer registers, more waves per
 // SIMD — measured 1.5e-6 of peak apart at N=2000 and inside the tolerance at N=5000.
 #include <hip/hip_runtime.h>
+#include <cstdint>
 #include <cstdlib>
 #include "helio.h"
 #include "ray_trace.h"
@@ -784,14 +785,137 @@ extern "C" int helio_diag_set_stamps(unsigned long long* stamps_d) {
 namespace helio {
 #endif
 
+// A handful of rays per image (the reference's test-time-compute sweeps run ONE heliostat and 500 suns,
+// run_experiments.py:31-56): the render is bound by streaming the image out — and, in HelioEnv.step,
+// the target image and the distance map in — not by arithmetic, and 32×32 MFMA blocks would each
+// re-trace the same ray (the block kernel above ran that shape at 44 % of the HBM rate).  Here a
+// workgroup owns a band of FEW_ROWS image rows of one sun: threads 0..N-1 trace the rays once into LDS,
+// then every thread walks 16-byte pixel quads of the band (lanes ↔ consecutive quads: coalesced
+// float4 stores and loads), evaluating  Σ_n A_n[i]·E_n[j]  directly (1 + 4 exponentials per ray and
+// quad).  LOSS = true: HelioEnv.step's forward in the same launch — the band's share of the three image
+// sums from the pixels in registers, and band 0 also does the per-ray side work (outputs, the two ray
+// losses, the `aux` row).  Partials: [B, bands, 3] / [B, 2], reduced by step_losses_final in fixed
+// order.  Needs R % 4 == 0 and 16-byte aligned images; anything else takes the block kernel.
+constexpr int FEW_ROWS = 32, FEW_MAX_RAYS = 8;
+
+template <bool LOSS>
+__global__ void __launch_bounds__(256)
+render_fwd_few(int N, int R, const float* __restrict__ helios, const float* __restrict__ sun,
+               const float* __restrict__ action, const float* __restrict__ trig, long trig_b_stride,
+               const float* __restrict__ xs, const float* __restrict__ ys, PlaneK P,
+               float* __restrict__ actual, float* __restrict__ refl, float* __restrict__ rays,
+               float* __restrict__ image, StepLossArgs L) {
+    __shared__ float4 sRay[FEW_MAX_RAYS];              // (a, b, k2, c2)
+    __shared__ float sLoss[2 * FEW_MAX_RAYS];
+    __shared__ float scratch[4];
+    const int band = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int i0 = band * FEW_ROWS, rows = min(FEW_ROWS, R - i0);
+    if (tid < N) {
+        const int n = tid;
+        const long m = (long)b * N + n;
+        const vec3 s = ld3(sun + 3l * b);
+        const float4 tg = *reinterpret_cast<const float4*>(trig + (long)b * trig_b_stride + 4l * n);
+        const vec3 v = ld3(action + 3 * m);
+        const Ray q = trace(v, tg.x, tg.y, tg.z, tg.w, ld3(helios + 3l * n), s, P);
+        sRay[n] = make_float4(q.a, q.b, q.k2, q.c2);
+        if (band == 0) {
+            st3(actual + 3 * m, q.act);
+            if (refl) st3(refl + 3 * m, q.r);
+            if (rays) *reinterpret_cast<float4*>(rays + 4 * m) = make_float4(q.a, q.b, q.k2, q.c2);
+            if constexpr (LOSS) {
+                const float act[3] = {q.act.x, q.act.y, q.act.z};
+                const RayLoss r = ray_loss(L.ideal + 3 * m, act, action + 3 * m, helios + 3l * n, L.g);
+                L.align_err[m] = r.ang;
+                L.all_bounds[m] = r.out;
+                if (L.aux) {     // observation row [sun_b, action_b] (test_environment.py:424)
+                    float* a = L.aux + (long)b * (3 + 3l * N);
+                    a[3 + 3 * n] = v.x; a[4 + 3 * n] = v.y; a[5 + 3 * n] = v.z;
+                    if (n == 0) { a[0] = s.x; a[1] = s.y; a[2] = s.z; }
+                }
+                sLoss[2 * n] = r.ang;
+                sLoss[2 * n + 1] = L.g.exponential_risk ? expf(r.out + 1e-6f) : r.out;
+            }
+        }
+    }
+    __syncthreads();
+    if constexpr (LOSS) {
+        if (band == 0 && tid == 0) {
+            float sa = 0.0f, sb = 0.0f;
+            for (int n = 0; n < N; ++n) { sa += sLoss[2 * n]; sb += sLoss[2 * n + 1]; }
+            L.part_ray[2l * b] = sa;
+            L.part_ray[2l * b + 1] = sb;
+        }
+    }
+    const int qpr = R >> 2;                            // 16-byte quads per row
+    const long base = (long)b * R * R + (long)i0 * R;
+    const float sc = LOSS ? L.tx[b] : 1.0f;
+    float sq = 0.f, ab = 0.f, ds = 0.f;
+    for (int qd = tid; qd < rows * qpr; qd += 256) {
+        const int il = qd / qpr, j = 4 * (qd - il * qpr);
+        const long p = base + (long)il * R + j;
+        float4 tg4 = make_float4(0.f, 0.f, 0.f, 0.f), dm4 = tg4;
+        if constexpr (LOSS) {                          // requested first: they are what the kernel waits for
+            tg4 = *reinterpret_cast<const float4*>(L.target + p);
+            dm4 = *reinterpret_cast<const float4*>(L.dmaps + p);
+        }
+        const float xi = xs[i0 + il];
+        const float4 yj = *reinterpret_cast<const float4*>(ys + j);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int n = 0; n < N; ++n) {
+            const float4 q = sRay[n];                  // broadcast read
+            const float t = xi + q.x;
+            const float a = exp2_fast(-(__builtin_fmaf(t, t, q.w) * q.z));
+            const float u0 = yj.x + q.y, u1 = yj.y + q.y, u2 = yj.z + q.y, u3 = yj.w + q.y;
+            acc.x = __builtin_fmaf(a, exp2_fast(-((u0 * u0) * q.z)), acc.x);
+            acc.y = __builtin_fmaf(a, exp2_fast(-((u1 * u1) * q.z)), acc.y);
+            acc.z = __builtin_fmaf(a, exp2_fast(-((u2 * u2) * q.z)), acc.z);
+            acc.w = __builtin_fmaf(a, exp2_fast(-((u3 * u3) * q.z)), acc.w);
+        }
+        *reinterpret_cast<float4*>(image + p) = acc;
+        if constexpr (LOSS) {
+            const float pv[4] = {acc.x, acc.y, acc.z, acc.w}, tv[4] = {tg4.x, tg4.y, tg4.z, tg4.w};
+            const float dv[4] = {dm4.x, dm4.y, dm4.z, dm4.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float d = pv[k] / sc - tv[k] / sc;       // as the reference divides (:438-441)
+                const float ad = fabsf(d);
+                sq = __builtin_fmaf(d, d, sq);
+                ab += ad;
+                ds = __builtin_fmaf(ad, dv[k], ds);
+            }
+        }
+    }
+    if constexpr (LOSS) {
+        sq = block_sum(sq, scratch);
+        ab = block_sum(ab, scratch);
+        ds = block_sum(ds, scratch);
+        if (tid == 0) {
+            float* o = L.part_img + 3l * ((long)b * gridDim.x + band);
+            o[0] = sq; o[1] = ab; o[2] = ds;
+        }
+    }
+}
+
+// the streaming kernel's preconditions (R % 4 == 0 is part of render_is_few's caller check)
+// and where it wins: always for one or two rays; for up to 8 once the images are large enough to be
+// bound by HBM rather than by launch latency (tools/bench_fused.py: N = 8, B = 64, R = 64 takes 4.4 µs in
+// the block kernel and 5.3 µs here — 40 exponentials per pixel quad)
+static bool few_ok(int B, int N, int R, const float* ys, const float* image, const StepLossArgs* L) {
+    auto a16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    const bool wins = N <= 2 || (long)B * R * R >= (1l << 21);
+    return N <= FEW_MAX_RAYS && wins && (R & 3) == 0 && a16(ys) && a16(image) && (!L || (a16(L->target) && a16(L->dmaps)));
+}
+
 // true when launch_render_fwd() would take the single-launch path
 bool render_is_fused(int B, int N, int R) {
     // one launch instead of two wherever the launch boundary (≈1.5–2 µs plus a second wait for kernel
     // arguments) is a visible share of the render: up to 512 128²-tiles' worth of pixels and a heliostat
     // sum that one workgroup traces in one go (N <= 256: four waves of 64 rays).  Every 32×32 block
     // traces the rays of its sun itself, so longer sums go to the geometry + splat pair
+    // a handful of rays per image: one streaming launch at any size (render_fwd_few, or the block kernel
+    // when its alignment preconditions do not hold)
     const long t128 = (long)B * ((R + 127) / 128) * ((R + 127) / 128);
-    return N <= 256 && t128 < 512;
+    return N <= FEW_MAX_RAYS || (N <= 256 && t128 < 512);
 }
 
 // waves per 32×32 block of the fused kernel (the heliostats are split between them; 64·KG >= N): as
@@ -832,6 +956,11 @@ void launch_render_fused(int B, int N, int R, const float* helios, const float* 
                          const float* trig, long trig_b_stride, const helio_plane* plane, const float* xs,
                          const float* ys, float* actual, float* refl, float* rays, float* image, hipStream_t st) {
     const StepLossArgs none{};
+    if (few_ok(B, N, R, ys, image, nullptr)) {
+        hipLaunchKernelGGL(render_fwd_few<false>, dim3((R + FEW_ROWS - 1) / FEW_ROWS, B), dim3(256), 0, st, N, R, helios, sun,
+                           action, trig, trig_b_stride, xs, ys, to_k(plane), actual, refl, rays, image, none);
+        return;
+    }
     switch (fused_kg(B, N, R)) {
     case 4: launch_fused<4, false>(B, N, R, helios, sun, action, trig, trig_b_stride, plane, xs, ys, actual, refl, rays, image, none, st); break;
     case 2: launch_fused<2, false>(B, N, R, helios, sun, action, trig, trig_b_stride, plane, xs, ys, actual, refl, rays, image, none, st); break;
@@ -864,6 +993,14 @@ void launch_env_step_fused(int B, int N, int R, const float* helios, const float
     L.part_img = workspace; L.part_ray = workspace + 3l * B * t * t;
     L.align_err = align_err; L.all_bounds = all_bounds; L.aux = aux;
     L.g = make_geom(tp, tn, W, H, exponential_risk);
+    if (few_ok(B, N, R, ys, image, &L)) {
+        const int bands = (R + FEW_ROWS - 1) / FEW_ROWS;
+        L.part_ray = workspace + 3l * B * bands;
+        hipLaunchKernelGGL(render_fwd_few<true>, dim3(bands, B), dim3(256), 0, st, N, R, helios, sun, action, trig,
+                           trig_b_stride, xs, ys, to_k(plane), actual, refl, rays, image, L);
+        launch_step_losses_final(B, N, R, bands, B, mask_ratio, L.part_img, L.part_ray, out, mae, keep, notify, ticket, st);
+        return;
+    }
     switch (fused_kg(B, N, R)) {
     case 4: launch_fused<4, true>(B, N, R, helios, sun, action, trig, trig_b_stride, plane, xs, ys, actual, refl, rays, image, L, st); break;
     case 2: launch_fused<2, true>(B, N, R, helios, sun, action, trig, trig_b_stride, plane, xs, ys, actual, refl, rays, image, L, st); break;

@@ -1273,3 +1273,33 @@ def test_render_value_and_grad_equals_render_plus_autograd(N, B, R):
     img1, actual1, grad1 = f.render_value_and_grad(suns[0].double().numpy(), act[0].tolist(), G[0].cpu().numpy())
     assert img1.shape == (R, R) and actual1.shape == (1, N, 3) and grad1.shape == (1, 3 * N)
     assert torch.isfinite(grad1).all()
+
+
+@pytest.mark.parametrize("N,B,R", [(1, 500, 128), (2, 7, 64), (5, 3, 100), (8, 40, 256), (3, 2, 36)])
+def test_few_ray_streaming_forward_against_oracle_and_block_kernel(N, B, R):
+    """render_fwd_few (N <= 8, R % 4 == 0: one streaming launch, rays traced once per 32-row band)
+    against the oracle — `actual` / `refl` bit for bit, image at the north-star tolerance — and against
+    the 32x32-block MFMA kernel, which the same call takes when the pixel coordinates are not 16-byte
+    aligned."""
+    from doodle_amd import native
+    f, sc, suns, errs, act = make_case(N, B, R, sigma=0.02, err=40.0, seed=3 * N + R)
+    e = errs if B > 1 else errs[:1]
+    with torch.no_grad():
+        img_o, actual_o, refl_o = to.render(sc, suns, act, e, monitor=True)
+        img, actual, refl = f.render(suns.to(DEV), act.to(DEV), None, monitor=True)
+    assert np.array_equal(actual.cpu().numpy(), actual_o.numpy()) and np.array_equal(refl.cpu().numpy(), refl_o.numpy())
+    np.testing.assert_allclose(img.cpu().numpy(), img_o.numpy(), rtol=1e-5, atol=1e-8)
+    assert (img.cpu() - img_o).abs().max().item() <= 1e-5 * img_o.max().item()
+    # the block kernel on the same inputs: shift the ys table by one float (4-byte aligned only)
+    ys_pad = torch.empty(R + 1, device=DEV)
+    ys_pad[1:] = f._ys
+    keep = f._ys
+    f._ys, f._ctx_key = ys_pad[1:], None
+    try:
+        with torch.no_grad():
+            img_b, actual_b = f.render(suns.to(DEV), act.to(DEV), None)
+    finally:
+        f._ys, f._ctx_key = keep, None
+    assert torch.equal(actual_b, actual)
+    assert (img_b - img).abs().max().item() <= 2e-6 * img.max().item()
+    assert native.get_ops().lib.helio_render_fwd_launches(B, N, R) == 1
