@@ -94,11 +94,20 @@ def time_kernel(fn, iters, warm=3):
     return e0.elapsed_time(e1) * 1e-3 / iters
 
 
-def preheat(fn, seconds):
-    """Run ``fn`` for ``seconds`` of wall time (at least once when seconds > 0)."""
+def preheat(fn, seconds, burst=None, fence=None):
+    """Run ``fn`` for ``seconds`` of wall time.  With ``burst`` and ``fence``: in bursts of ``burst`` calls
+    followed by ``fence()`` — the pattern of the timed region itself.  (Measured, tools/launch_jitter.py:
+    after a long run of unsynchronised launches the first three or four "20 calls + synchronize" samples
+    take 210–260 µs, then 156–168 µs for good; a preheat that never synchronises leaves the timed sample
+    in that transient.)"""
     t0 = time.perf_counter()
     while time.perf_counter() - t0 < seconds:
-        fn()
+        if burst is None:
+            fn()
+        else:
+            for _ in range(burst):
+                fn()
+            fence()
 
 
 def source_sha16(name):
@@ -304,7 +313,13 @@ def main():
     gather_now = [bool(args.gather_every_step)]
     for _ in range(args.warmup):
         step()
-    preheat(step, args.preheat)            # disclosed (preheat_s): host path and GPU clocks at steady state
+    # disclosed (preheat_s): host path and GPU clocks at steady state, in bursts of K steps + fence like
+    # the timed region (at least four of them)
+    preheat(step, args.preheat, burst=args.steps, fence=fence)
+    for _ in range(4 if args.steps <= 1000 else 0):
+        for _ in range(args.steps):
+            step()
+        fence()
     fence()
     if args.mode == "fwd" and not gather_now[0]:
         # the timed loop proper: K calls of HelioField.render and nothing else (config 2 is ≈5 µs of
@@ -342,7 +357,7 @@ def main():
         gather_now[0] = not gather_now[0]
         for _ in range(min(args.warmup, 50)):
             step()
-        preheat(step, min(args.preheat, 0.2))
+        preheat(step, min(args.preheat, 0.2), burst=args.steps, fence=fence)
         fence()
         t0 = time.perf_counter()
         for _ in range(args.steps):
@@ -376,8 +391,9 @@ def main():
                        + ((f", RCCL all-gather of images every step ({gather.transport} transport, "
                            f"{'side stream' if args.overlap else 'stream-ordered'})") if (gather is not None and args.gather_every_step)
                           else (", no data-path collective (images stay on the rank that rendered them)" if world > 1 else "")),
-                       "timing": f"{args.warmup} warm-up steps, {args.preheat} s time-based preheat (untimed), then "
-                                 f"{args.steps} timed steps between barrier + synchronize fences, max over ranks"},
+                       "timing": f"{args.warmup} warm-up steps, {args.preheat} s time-based preheat (untimed, in bursts of "
+                                 f"{args.steps} steps + fence), then {args.steps} timed steps between barrier + synchronize "
+                                 "fences, max over ranks"},
         }
         if dist is not None:
             out["collective"] = {
