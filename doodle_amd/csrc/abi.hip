@@ -34,8 +34,8 @@ void launch_step_losses_bwd(int, int, int, const float*, const float*, const flo
                             const float*, const float*, const float*, const float*, const float*, float, float, int,
                             const float*, const float*, const float*, const float*, const float*, float*, float*,
                             float*, hipStream_t);
-void launch_render_fused(int, int, int, const float*, const float*, const float*, const float*, long,
-                         const helio_plane*, const float*, const float*, float*, float*, float*, float*, hipStream_t);
+bool launch_render_fused(int, int, int, const float*, const float*, const float*, const float*, long,
+                         const helio_plane*, const float*, const float*, float*, float*, float*, float*, int, hipStream_t);
 bool splat_bwd_is_few(int, int);
 void launch_splat_bwd_fused_loss_raw(int, int, int, const float*, const float*, const float*, const float*,
                                      const float*, const float*, const float*, const float*, const float*,
@@ -45,10 +45,10 @@ void launch_geometry_bwd_losses(int, int, int, const float*, const float*, const
                                 const float*, const float*, const float*, const float*, float, float, int,
                                 hipStream_t);
 long env_step_fused_workspace(int, int);
-void launch_env_step_fused(int, int, int, const float*, const float*, const float*, const float*, long,
+bool launch_env_step_fused(int, int, int, const float*, const float*, const float*, const float*, long,
                            const helio_plane*, const float*, const float*, float*, float*, float*, float*,
                            const float*, const float*, const float*, const float*, const float*, const float*, float,
-                           float, int, float, float*, float*, float*, float*, float*, float*, float*, int*, int,
+                           float, int, float, float*, float*, float*, float*, float*, float*, float*, int*, int, int,
                            hipStream_t);
 }  // namespace helio
 
@@ -68,6 +68,10 @@ int after_launch(const char* what) {
     if (e != hipSuccess) return fail(HELIO_E_LAUNCH, "%s: %s", what, hipGetErrorString(e));
     return HELIO_OK;
 }
+
+// variants 10..13 force one form of the single-launch render (parity tests, tuning): the block kernel
+// with 1 / 2 / 4 waves per block, or the few-ray streaming kernel; → 0 when the variant is not one of them
+int fused_form(int variant) { return variant == 10 ? 1 : variant == 11 ? 2 : variant == 12 ? 4 : variant == 13 ? 8 : 0; }
 
 bool sizes_ok(int B, int N) { return B >= 1 && N >= 1 && B <= 65535 && (long)B * N <= (1l << 31) / 4; }
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -125,9 +129,10 @@ int helio_render_fwd(int B, int N, int R, const float* helios_d, const float* su
     if (!aligned16(trig_d) || (rays_d && !aligned16(rays_d)) || !aligned16(image_d))
         return fail(HELIO_E_INVALID, "render_fwd: trig/rays/image must be 16-byte aligned");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if ((variant == 0 || variant == 2) && helio::render_is_fused(B, N, R)) {
-        helio::launch_render_fused(B, N, R, helios_d, sun_d, action_d, trig_d, trig_b_stride, plane, xs_d, ys_d,
-                                   actual_d, refl_d, rays_d, image_d, st);
+    if (((variant == 0 || variant == 2) && helio::render_is_fused(B, N, R)) || fused_form(variant)) {
+        if (!helio::launch_render_fused(B, N, R, helios_d, sun_d, action_d, trig_d, trig_b_stride, plane, xs_d, ys_d,
+                                        actual_d, refl_d, rays_d, image_d, fused_form(variant), st))
+            return fail(HELIO_E_INVALID, "render_fwd: variant %d does not exist for B=%d N=%d R=%d", variant, B, N, R);
         return after_launch("render_fwd(fused)");
     }
     if (!rays_d) return fail(HELIO_E_INVALID, "render_fwd: this problem size needs the rays work buffer");
@@ -302,7 +307,8 @@ int helio_env_step_fwd(int B, int N, int R, const float* helios_d, const float* 
                        float* keep_d, float* align_err_d, float* all_bounds_d, float* aux_d, int* notify, int ticket,
                        void* stream) {
     if (notify && ticket == 0) return fail(HELIO_E_INVALID, "env_step_fwd: ticket 0 is reserved");
-    if ((variant == 0 || variant == 2) && sizes_ok(B, N) && R >= 1 && R <= 16384 && helio::render_is_fused(B, N, R)) {
+    if (sizes_ok(B, N) && R >= 1 && R <= 16384 &&
+        (((variant == 0 || variant == 2) && helio::render_is_fused(B, N, R)) || fused_form(variant))) {
         if (!helios_d || !sun_d || !action_d || !trig_d || !plane || !xs_d || !ys_d || !actual_d || !image_d ||
             !target_d || !tx_d || !dmaps_d || !ideal_d || !target_position || !target_normal || !workspace_d ||
             !out_d || !mae_d || !keep_d || !align_err_d || !all_bounds_d)
@@ -314,11 +320,13 @@ int helio_env_step_fwd(int B, int N, int R, const float* helios_d, const float* 
         if (error_mask_ratio >= 0.0f && (error_mask_ratio > 1.0f || B > helio::step_losses_max_mask_batch()))
             return fail(HELIO_E_INVALID, "env_step_fwd: error mask needs ratio in [0,1] and B <= %d",
                         helio::step_losses_max_mask_batch());
-        helio::launch_env_step_fused(B, N, R, helios_d, sun_d, action_d, trig_d, trig_b_stride, plane, xs_d, ys_d,
-                                     actual_d, refl_d, rays_d, image_d, target_d, tx_d, dmaps_d, ideal_d,
-                                     target_position, target_normal, width, height, exponential_risk,
-                                     error_mask_ratio, workspace_d, out_d, mae_d, keep_d, align_err_d, all_bounds_d,
-                                     aux_d, notify, ticket, static_cast<hipStream_t>(stream));
+        if (!helio::launch_env_step_fused(B, N, R, helios_d, sun_d, action_d, trig_d, trig_b_stride, plane, xs_d, ys_d,
+                                          actual_d, refl_d, rays_d, image_d, target_d, tx_d, dmaps_d, ideal_d,
+                                          target_position, target_normal, width, height, exponential_risk,
+                                          error_mask_ratio, workspace_d, out_d, mae_d, keep_d, align_err_d,
+                                          all_bounds_d, aux_d, notify, ticket, fused_form(variant),
+                                          static_cast<hipStream_t>(stream)))
+            return fail(HELIO_E_INVALID, "env_step_fwd: variant %d does not exist for B=%d N=%d R=%d", variant, B, N, R);
         return after_launch("env_step_fwd(fused)");
     }
     const int rc = helio_render_fwd(B, N, R, helios_d, sun_d, action_d, trig_d, trig_b_stride, plane, xs_d, ys_d,

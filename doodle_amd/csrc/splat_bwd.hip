@@ -981,7 +981,7 @@ void launch_splat_bwd_fused_loss_raw(int B, int N, int R, const float* rays, con
 int splat_bwd_blocks(int R) { return (R + BW_JT - 1) / BW_JT; }
 
 // variant: 0 = by problem size, 1 = VALU kernel, 2 = MFMA kernels (256-tiles), 3 = MFMA small tiles,
-// 4 = few-ray streaming kernel, 5 = split-bf16 MFMA kernels (opt-in)
+// 4 = few-ray streaming kernel, 5 = split-bf16 MFMA kernels (opt-in), 6 / 7 = the small kernel with 4 / 8 waves
 int launch_splat_bwd(int B, int N, int R, const float* rays, const float* xs, const float* ys,
                      const float* gimg, float* moments, int variant, hipStream_t st) {
     if (variant == 0) {
@@ -1000,9 +1000,9 @@ int launch_splat_bwd(int B, int N, int R, const float* rays, const float* xs, co
         launch_bwd_few<false>(B, N, R, rays, xs, ys, gimg, LossGradArgs{}, moments, st);
         return HELIO_OK;
     }
-    if (variant == 3) {
+    if (variant == 3 || variant == 6 || variant == 7) {        // 6 / 7: the small kernel with 4 / 8 waves (tests, tuning)
         const int ct = (R + 63) / 64, nt = (N + 31) / 32;
-        if (bwd_small_ks(B, N, R) == 8)
+        if (variant == 7 || (variant == 3 && bwd_small_ks(B, N, R) == 8))
             hipLaunchKernelGGL(splat_bwd_mfma_small<8>, dim3(ct * nt, B, 2), dim3(512), 0, st, N, R, rays, xs, ys, gimg, moments);
         else
             hipLaunchKernelGGL(splat_bwd_mfma_small<4>, dim3(ct * nt, B, 2), dim3(256), 0, st, N, R, rays, xs, ys, gimg, moments);

@@ -896,15 +896,15 @@ render_fwd_few(int N, int R, const float* __restrict__ helios, const float* __re
     }
 }
 
-// the streaming kernel's preconditions (R % 4 == 0 is part of render_is_few's caller check)
+// the streaming kernel's preconditions
+static bool few_ok(int N, int R, const float* ys, const float* image, const StepLossArgs* L) {
+    auto a16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    return N <= FEW_MAX_RAYS && (R & 3) == 0 && a16(ys) && a16(image) && (!L || (a16(L->target) && a16(L->dmaps)));
+}
 // and where it wins: always for one or two rays; for up to 8 once the images are large enough to be
 // bound by HBM rather than by launch latency (tools/bench_fused.py: N = 8, B = 64, R = 64 takes 4.4 µs in
 // the block kernel and 5.3 µs here — 40 exponentials per pixel quad)
-static bool few_ok(int B, int N, int R, const float* ys, const float* image, const StepLossArgs* L) {
-    auto a16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
-    const bool wins = N <= 2 || (long)B * R * R >= (1l << 21);
-    return N <= FEW_MAX_RAYS && wins && (R & 3) == 0 && a16(ys) && a16(image) && (!L || (a16(L->target) && a16(L->dmaps)));
-}
+static bool few_wins(int B, int N, int R) { return N <= 2 || (long)B * R * R >= (1l << 21); }
 
 // true when launch_render_fwd() would take the single-launch path
 bool render_is_fused(int B, int N, int R) {
@@ -952,19 +952,30 @@ static void launch_fused(int B, int N, int R, const float* helios, const float* 
                        R | (trig_b_stride != 0 ? 1 << 16 : 0), helios, sun, action, trig, xs, ys, late, L);
 }
 
-void launch_render_fused(int B, int N, int R, const float* helios, const float* sun, const float* action,
+// form: 0 = by problem size; 1, 2, 4 = the block kernel with that many waves per block (64·KG >= N);
+// 8 = the few-ray streaming kernel (N <= 8, R % 4 == 0, 16-byte aligned images) — forced forms are for
+// the parity tests and tuning runs.  → false when the forced form does not exist for this problem
+static int resolve_fused_form(int form, int B, int N, int R, bool few_possible) {
+    if (form == 0) return few_possible && few_wins(B, N, R) ? 8 : fused_kg(B, N, R);
+    if (form == 8) return few_possible ? 8 : -1;
+    if ((form == 1 || form == 2 || form == 4) && N <= 64 * form) return form;
+    return -1;
+}
+
+bool launch_render_fused(int B, int N, int R, const float* helios, const float* sun, const float* action,
                          const float* trig, long trig_b_stride, const helio_plane* plane, const float* xs,
-                         const float* ys, float* actual, float* refl, float* rays, float* image, hipStream_t st) {
+                         const float* ys, float* actual, float* refl, float* rays, float* image, int form,
+                         hipStream_t st) {
     const StepLossArgs none{};
-    if (few_ok(B, N, R, ys, image, nullptr)) {
+    switch (resolve_fused_form(form, B, N, R, few_ok(N, R, ys, image, nullptr))) {
+    case 8:
         hipLaunchKernelGGL(render_fwd_few<false>, dim3((R + FEW_ROWS - 1) / FEW_ROWS, B), dim3(256), 0, st, N, R, helios, sun,
                            action, trig, trig_b_stride, xs, ys, to_k(plane), actual, refl, rays, image, none);
-        return;
-    }
-    switch (fused_kg(B, N, R)) {
-    case 4: launch_fused<4, false>(B, N, R, helios, sun, action, trig, trig_b_stride, plane, xs, ys, actual, refl, rays, image, none, st); break;
-    case 2: launch_fused<2, false>(B, N, R, helios, sun, action, trig, trig_b_stride, plane, xs, ys, actual, refl, rays, image, none, st); break;
-    default: launch_fused<1, false>(B, N, R, helios, sun, action, trig, trig_b_stride, plane, xs, ys, actual, refl, rays, image, none, st); break;
+        return true;
+    case 4: launch_fused<4, false>(B, N, R, helios, sun, action, trig, trig_b_stride, plane, xs, ys, actual, refl, rays, image, none, st); return true;
+    case 2: launch_fused<2, false>(B, N, R, helios, sun, action, trig, trig_b_stride, plane, xs, ys, actual, refl, rays, image, none, st); return true;
+    case 1: launch_fused<1, false>(B, N, R, helios, sun, action, trig, trig_b_stride, plane, xs, ys, actual, refl, rays, image, none, st); return true;
+    default: return false;
     }
 }
 
@@ -979,13 +990,13 @@ long env_step_fused_workspace(int B, int R) {
 
 // HelioEnv.step forward for the problems render_is_fused() selects: render + loss partials in one
 // launch, then the finishing workgroup of step_losses.hip — 2 launches for the whole step
-void launch_env_step_fused(int B, int N, int R, const float* helios, const float* sun, const float* action,
+bool launch_env_step_fused(int B, int N, int R, const float* helios, const float* sun, const float* action,
                            const float* trig, long trig_b_stride, const helio_plane* plane, const float* xs,
                            const float* ys, float* actual, float* refl, float* rays, float* image,
                            const float* target, const float* tx, const float* dmaps, const float* ideal,
                            const float* tp, const float* tn, float W, float H, int exponential_risk,
                            float mask_ratio, float* workspace, float* out, float* mae, float* keep,
-                           float* align_err, float* all_bounds, float* aux, int* notify, int ticket,
+                           float* align_err, float* all_bounds, float* aux, int* notify, int ticket, int form,
                            hipStream_t st) {
     const int t = (R + 31) / 32;
     StepLossArgs L;
@@ -993,20 +1004,22 @@ void launch_env_step_fused(int B, int N, int R, const float* helios, const float
     L.part_img = workspace; L.part_ray = workspace + 3l * B * t * t;
     L.align_err = align_err; L.all_bounds = all_bounds; L.aux = aux;
     L.g = make_geom(tp, tn, W, H, exponential_risk);
-    if (few_ok(B, N, R, ys, image, &L)) {
+    switch (resolve_fused_form(form, B, N, R, few_ok(N, R, ys, image, &L))) {
+    case 8: {
         const int bands = (R + FEW_ROWS - 1) / FEW_ROWS;
         L.part_ray = workspace + 3l * B * bands;
         hipLaunchKernelGGL(render_fwd_few<true>, dim3(bands, B), dim3(256), 0, st, N, R, helios, sun, action, trig,
                            trig_b_stride, xs, ys, to_k(plane), actual, refl, rays, image, L);
         launch_step_losses_final(B, N, R, bands, B, mask_ratio, L.part_img, L.part_ray, out, mae, keep, notify, ticket, st);
-        return;
+        return true;
     }
-    switch (fused_kg(B, N, R)) {
     case 4: launch_fused<4, true>(B, N, R, helios, sun, action, trig, trig_b_stride, plane, xs, ys, actual, refl, rays, image, L, st); break;
     case 2: launch_fused<2, true>(B, N, R, helios, sun, action, trig, trig_b_stride, plane, xs, ys, actual, refl, rays, image, L, st); break;
-    default: launch_fused<1, true>(B, N, R, helios, sun, action, trig, trig_b_stride, plane, xs, ys, actual, refl, rays, image, L, st); break;
+    case 1: launch_fused<1, true>(B, N, R, helios, sun, action, trig, trig_b_stride, plane, xs, ys, actual, refl, rays, image, L, st); break;
+    default: return false;
     }
     launch_step_losses_final(B, N, R, t * t, B, mask_ratio, L.part_img, L.part_ray, out, mae, keep, notify, ticket, st);
+    return true;
 }
 
 // (A double-buffered form — 32-ray chunks, two LDS buffers, one barrier per chunk, producers

@@ -106,6 +106,10 @@ int helio_geometry_fwd(int B, int N,
  * levels (16 rays on the pipe, then a round-to-nearest vector add): against fp64 at N = 2000 its
  * worst per-pixel relative error is 8.6e-7, tighter than the exact-f32 MFMA kernel's one-level
  * chain (1.2e-6), at 1.77x its speed; 8 sums in one level: 2.5e-6, 2.03x.
+ * helio_render_fwd / helio_env_step_fwd also take 10, 11, 12 (the single-launch block kernel with 1, 2, 4
+ * waves per 32x32 block; needs N <= 64, 128, 256) and 13 (the few-ray streaming kernel; needs N <= 8,
+ * R % 4 == 0 and 16-byte aligned ys / images): forced forms of what 0 chooses by size, for parity
+ * tests and tuning; HELIO_E_INVALID where the form does not exist for the problem.
  */
 int helio_splat_fwd(int B, int N, int R,
                     const float *rays_d, const float *xs_d, const float *ys_d,
@@ -145,7 +149,8 @@ int helio_splat_bwd_blocks(int R);
  * launches), 3 = f32 MFMA small-tile kernel (both passes in one launch), 4 = streaming VALU kernel
  * for a handful of rays per image (bound by reading grad_image once), 5 = the split-bf16 MFMA
  * kernels (opt-in, never chosen by 0: grad-image values and factors split exactly into three
- * bf16 pieces, six partial products per product on the bf16 matrix pipe, f32 accumulation).
+ * bf16 pieces, six partial products per product on the bf16 matrix pipe, f32 accumulation);
+ * 6 / 7 = the small-tile kernel forced to 4 / 8 waves per workgroup (what 3 chooses by size).
  */
 int helio_splat_bwd(int B, int N, int R,
                     const float *rays_d, const float *xs_d, const float *ys_d,

@@ -51,7 +51,7 @@ def launch_stubs() -> str:
             out.append(f"{ret} {name}({named}) {{ {rules[name]} }}")
         else:
             assert name.startswith("launch_"), f"no stub rule for helio::{name}"
-            tail = "" if ret == "void" else " return 0;"
+            tail = {"void": "", "bool": " return true;"}.get(ret, " return 0;")
             out.append(f"{ret} {name}({named}) {{ {body}{tail} }}")
         n += 1
     assert n >= 20

@@ -38,7 +38,8 @@ def test_odd_sizes_against_oracle(N, B, R, normal):
     G, H = torch.randn(img_o.shape, generator=g), torch.randn(actual_o.shape, generator=g)
     (grad_o,) = torch.autograd.grad((img_o * G).sum() + (actual_o * H).sum(), a_cpu)
     a_dev = act.to(DEV).requires_grad_(True)
-    for variant in (1, 3, 4, 5, 6, 7, 8):
+    forms = [v for v, ok in ((10, N <= 64), (11, N <= 128), (12, N <= 256), (13, N <= 8 and R % 4 == 0)) if ok]
+    for variant in (1, 3, 4, 5, 6, 7, 8, *forms):           # every splat kernel and every form of the fused kernel
         from doodle_amd import native
         native.get_ops().splat_variant = variant
         try:
@@ -49,7 +50,7 @@ def test_odd_sizes_against_oracle(N, B, R, normal):
         assert np.array_equal(refl.detach().cpu().numpy(), refl_o.detach().numpy())
         np.testing.assert_allclose(img.detach().cpu().numpy(), img_o.detach().numpy(), rtol=1e-5, atol=1e-8)
     scale = grad_o.abs().max().item()
-    for bwd_variant in (1, 2, 3, 4, 5):
+    for bwd_variant in (1, 2, 3, 4, 5, 6, 7):
         native.get_ops().bwd_variant = bwd_variant
         try:
             (grad,) = torch.autograd.grad((img * G.to(DEV)).sum() + (actual * H.to(DEV)).sum(), a_dev, retain_graph=True)
@@ -1303,3 +1304,46 @@ def test_few_ray_streaming_forward_against_oracle_and_block_kernel(N, B, R):
     assert torch.equal(actual_b, actual)
     assert (img_b - img).abs().max().item() <= 2e-6 * img.max().item()
     assert native.get_ops().lib.helio_render_fwd_launches(B, N, R) == 1
+
+
+@pytest.mark.parametrize("N,B,R", [(50, 25, 64), (5, 6, 36), (200, 3, 96)])
+def test_every_form_of_the_fused_env_step_agrees(N, B, R):
+    """HelioEnv.step's single-launch forward in each of its forms (block kernel with 1 / 2 / 4 waves per
+    block, few-ray streaming kernel; helio.h variants 10..13) against the form the size rule picks:
+    `actual`, `refl` and `aux` bit for bit, image and metrics to summation-order accuracy."""
+    from doodle_amd import native
+    from doodle_amd.env import HelioEnv
+    from doodle_amd import synthetic
+    w = synthetic.Workload("t", N=N, B=B, R=R, sigma_scale=0.02, error_scale_mrad=40.0, span=10.0)
+    helios, suns, _, noise = synthetic.make_inputs(w, 5)
+    env = HelioEnv(helios.to(DEV), torch.tensor(synthetic.TARGET_POSITION, device=DEV), synthetic.TARGET_AREA,
+                   torch.tensor(synthetic.TARGET_NORMAL, device=DEV), sigma_scale=0.02, error_scale_mrad=40.0,
+                   resolution=R, batch_size=B, device=DEV, new_errors_every_reset=False)
+    env.set_sun_pos(suns.to(DEV))
+    env.reset()
+    act = torch.nn.functional.normalize(env.ideal_normals + noise.to(DEV), dim=2).reshape(B, -1)
+    ops = native.get_ops()
+    with torch.no_grad():
+        obs0, m0, mon0 = env.step(act)
+    forms = [v for v, ok in ((10, N <= 64), (11, N <= 128), (12, N <= 256), (13, N <= 8 and R % 4 == 0)) if ok]
+    assert forms
+    for v in forms:
+        ops.splat_variant = v
+        try:
+            with torch.no_grad():
+                obs, m, mon = env.step(act)
+        finally:
+            ops.splat_variant = 0
+        assert torch.equal(mon["reflected_rays"], mon0["reflected_rays"]) and torch.equal(obs["aux"], obs0["aux"])
+        peak = obs0["img"].max().item()
+        assert (obs["img"] - obs0["img"]).abs().max().item() <= 2e-6 * peak, v
+        for k in m0:
+            assert abs(m[k].item() - m0[k].item()) <= 2e-5 * max(abs(m0[k].item()), 1e-6), (v, k)
+        assert torch.allclose(mon["mae_image"], mon0["mae_image"], rtol=2e-5, atol=1e-9)
+    if N > 64:                                              # a form that does not exist for this size is refused
+        ops.splat_variant = 10
+        try:
+            with pytest.raises(RuntimeError, match="does not exist"), torch.no_grad():
+                env.step(act)
+        finally:
+            ops.splat_variant = 0

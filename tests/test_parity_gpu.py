@@ -36,11 +36,18 @@ def assert_image_close(img, ref):
     assert np.abs(img - ref).max() <= 1e-5 * max(np.abs(ref).max(), 1e-30)
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8])
+def fused_form_exists(variant, N, R):
+    """Variants 10..13 force one form of the single-launch render; not every form exists for every size."""
+    return {10: N <= 64, 11: N <= 128, 12: N <= 256, 13: N <= 8 and R % 4 == 0}.get(variant, True)
+
+
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8, 10, 11, 12, 13])
 @pytest.mark.parametrize("name", NAMES)
 def test_forward_matches_reference(name, variant, monkeypatch):
     from doodle_amd import native
     g = golden(name)
+    if not fused_form_exists(variant, g["helios"].shape[0], int(g["resolution"])):
+        pytest.skip("this form of the fused kernel does not exist for the fixture's size")
     f = field_from(g)
     monkeypatch.setattr(native.get_ops(), "splat_variant", variant)
     img, actual, refl = f.render(torch.from_numpy(g["sun"]), torch.from_numpy(g["action"]), None, monitor=True)
@@ -70,7 +77,7 @@ def test_ray_parameters_match_reference_intersections(name):
     assert np.array_equal(rays[:, 2] > 0, mask > 0)
 
 
-@pytest.mark.parametrize("bwd_variant", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("bwd_variant", [1, 2, 3, 4, 5, 6, 7])
 @pytest.mark.parametrize("name", NAMES)
 def test_backward_matches_reference_autograd(name, bwd_variant, monkeypatch):
     from doodle_amd import native
