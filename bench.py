@@ -470,16 +470,24 @@ def extras_leg(field, suns_d, action, w, dev):
         img, actual = field.render(suns_d, a, None)
         torch.autograd.grad((img * G).sum() + actual.sum(), a)
 
+    # BASELINE config 3 — forward + backward through the render for L = (img·G).sum() + actual.sum() —
+    # three ways, same kernels, same numbers (GPU tests):
+    #   render_fwd_bwd_us           HelioField.render_value_and_grad: forward and backward kernels enqueued
+    #                               back to back by ONE binding call for the cotangents (G, 1) — no autograd graph
+    #   render_fwd_bwd_autograd_us  render + the loss as torch ops + torch.autograd.grad (the autograd engine's
+    #                               thread hand-off and the bench's own torch ops are most of it)
+    #   render_fwd_bwd_graph_us     the autograd iteration captured once and replayed as a HIP graph
+    ones = torch.ones((w.B, w.N, 3), device=dev)
+    t_vg = wall(lambda: field.render_value_and_grad(suns_d, action, G, ones), 300)
     t_fb = wall(fwdbwd, 300)
-    out = {"render_fwd_bwd_frames_per_s": round(w.B / t_fb, 1), "render_fwd_bwd_us": round(t_fb * 1e6, 1)}
-    vg = getattr(field, "render_value_and_grad", None)
-    if vg is not None:
-        # config 3 without the autograd engine: render + the gradient for GIVEN cotangents of (image,
-        # actual) in one binding call (two C-ABI calls) — what an optimiser that supplies dL/dimage needs
-        ones = torch.ones((w.B, w.N, 3), device=dev)
-        t_vg = wall(lambda: vg(suns_d, action, G, ones), 300)
-        out["render_value_and_grad_us"] = round(t_vg * 1e6, 1)
-        out["render_value_and_grad_frames_per_s"] = round(w.B / t_vg, 1)
+    out = {"render_fwd_bwd_frames_per_s": round(w.B / t_vg, 1), "render_fwd_bwd_us": round(t_vg * 1e6, 1),
+           "render_fwd_bwd_autograd_us": round(t_fb * 1e6, 1)}
+    try:
+        from doodle_amd.graphed import GraphedRenderGrad
+        gr = GraphedRenderGrad(field, suns_d, like=action, loss=lambda img, actual: (img * G).sum() + actual.sum())
+        out["render_fwd_bwd_graph_us"] = round(wall(lambda: gr(), 300) * 1e6, 1)
+    except Exception as e:  # noqa: BLE001
+        out["render_fwd_bwd_graph_error"] = repr(e)
     env = HelioEnv(field.heliostat_positions, torch.tensor(synthetic.TARGET_POSITION, device=dev), synthetic.TARGET_AREA,
                    torch.tensor(synthetic.TARGET_NORMAL, device=dev), sigma_scale=w.sigma_scale,
                    error_scale_mrad=w.error_scale_mrad, resolution=w.R, batch_size=w.B, device=dev)
@@ -497,9 +505,11 @@ def extras_leg(field, suns_d, action, w, dev):
     out.update({
         "env_step_fwd_frames_per_s": round(w.B / t_step, 1), "env_step_fwd_us": round(t_step * 1e6, 1),
         "env_step_fwd_bwd_us": round(t_sb * 1e6, 1),
-        "note": "config 3 = render + autograd.grad of (img*G).sum()+actual.sum(); env.step = render + loss "
-                "block (2 launches) + NaN/Inf check (one wait on a pinned host record); fwd_bwd adds "
-                "metrics['dist'].backward(); best of 3 wall-clock loops through the Python surface"})
+        "note": "config 3 (L = (img*G).sum()+actual.sum()): render_fwd_bwd_us = HelioField.render_value_and_grad, "
+                "forward + backward kernels for the cotangents (G, 1) in one binding call; _autograd_us = render + "
+                "torch ops + torch.autograd.grad; _graph_us = that iteration replayed from a HIP graph.  env.step = "
+                "render + loss block (2 launches) + NaN/Inf check (one wait on a pinned host record); "
+                "env_step_fwd_bwd adds metrics['dist'].backward(); best of 3 wall-clock loops through the Python surface"})
     return out
 
 

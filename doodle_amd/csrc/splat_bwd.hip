@@ -252,6 +252,9 @@ splat_bwd_mfma(int B, int N, int R, const float* __restrict__ rays, const float*
     asm volatile("" : "+v"(pg1));
     asm volatile("" : "+v"(pf1));
 
+    // (a PERSISTENT form — one workgroup per CU walking its 32 tiles, no workgroup turnover — was built and
+    // measured at 8.70 ms against 8.33: the loop-carried tile state does not fit the 128-register budget
+    // of a 16-wave workgroup — 21 spilled VGPRs and 25 SGPRs in pass 1; not kept.)
     // (skipping the MFMAs of ray blocks past the last heliostat — N = 2000 fills 7.8 of its 8 tiles — was
     // tried as a wave-uniform choice between a 4- and a 2-MFMA loop: the second unrolled loop cost 72
     // spilled registers; not kept)
@@ -265,12 +268,29 @@ splat_bwd_mfma(int B, int N, int R, const float* __restrict__ rays, const float*
         __syncthreads();                                   // previous chunk consumed
         store_slab();
         if (k0 + KC < R) load_slab(k0 + KC);               // in flight during the chunk
+        if constexpr (!VEC) {       // (the packed form below costs these two instantiations a spilled register)
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const float t = __builtin_fmaf(kc[j], sk, fshift);
-            float f = __builtin_amdgcn_exp2f(-__builtin_fmaf(t, t, fcc));
-            if (k0 + pk0 + j >= R) f = 0.0f;               // rows/cols past the image contract nothing
-            fdst[j * LD] = f;
+            for (int j = 0; j < 16; ++j) {
+                const float t = __builtin_fmaf(kc[j], sk, fshift);
+                float f = __builtin_amdgcn_exp2f(-__builtin_fmaf(t, t, fcc));
+                if (k0 + pk0 + j >= R) f = 0.0f;           // rows/cols past the image contract nothing
+                fdst[j * LD] = f;
+            }
+        } else {
+            // factor pairs: the two fused multiply-adds of two factors are one v_pk_fma_f32 each (the same
+            // IEEE fma per component; producer instructions are MFMA time on this chip)
+            const f32x2 sk2 = {sk, sk}, sh2 = {fshift, fshift}, cc2 = {fcc, fcc};
+#pragma unroll
+            for (int j = 0; j < 16; j += 2) {
+                const f32x2 kc2 = {kc[j], kc[j + 1]};
+                const f32x2 t = __builtin_elementwise_fma(kc2, sk2, sh2);
+                const f32x2 a = __builtin_elementwise_fma(t, t, cc2);
+                float f0 = __builtin_amdgcn_exp2f(-a.x), f1 = __builtin_amdgcn_exp2f(-a.y);
+                if (k0 + pk0 + j >= R) f0 = 0.0f;          // rows/cols past the image contract nothing
+                if (k0 + pk0 + j + 1 >= R) f1 = 0.0f;
+                fdst[j * LD] = f0;
+                fdst[(j + 1) * LD] = f1;
+            }
         }
         __syncthreads();
 #pragma unroll

@@ -383,12 +383,18 @@ splat_fwd_mfma_tile(int B, int N, int R, const float* __restrict__ rays, const f
             lds_f* wdst = (lds_f*)smem + (is_a ? 0 : NC * LD) + lane * LD + p0;
             typedef float f32x2 __attribute__((ext_vector_type(2)));
             typedef __attribute__((address_space(3))) f32x2 lds_f2;
+            // two pixels per instruction: the two fused multiply-adds of a factor pair are v_pk_fma_f32
+            // (the same IEEE fma per component — bit-identical factors — in half the issue slots; the
+            // f32 MFMA and the VALU share a SIMD's issue, so producer instructions are MFMA time)
+            const f32x2 sk2 = {sk, sk}, shift2 = {shift, shift}, cc2 = {cc, cc};
 #pragma unroll
             for (int j = 0; j < 32; j += 2) {
-                const float t0 = __builtin_fmaf(cs[j], sk, shift), t1 = __builtin_fmaf(cs[j + 1], sk, shift);
+                const f32x2 c2 = {cs[j], cs[j + 1]};
+                const f32x2 t = __builtin_elementwise_fma(c2, sk2, shift2);
+                const f32x2 a = __builtin_elementwise_fma(t, t, cc2);
                 f32x2 v;
-                v.x = exp2_fast(-__builtin_fmaf(t0, t0, cc));
-                v.y = exp2_fast(-__builtin_fmaf(t1, t1, cc));
+                v.x = exp2_fast(-a.x);
+                v.y = exp2_fast(-a.y);
                 *reinterpret_cast<lds_f2*>(wdst + j) = v;
             }
         } else

@@ -76,3 +76,54 @@ class GraphedEnvStep:
         """The reference's NaN/Inf asserts for the last replay (synchronises)."""
         vals = torch.stack([self.metrics["mse"], self.metrics["dist"], self.metrics["bound"]])
         return not bool(torch.isfinite(vals).all())
+
+
+class GraphedRenderGrad:
+    """``HelioField.render`` + a caller-supplied scalar loss of ``(image, actual)`` + its gradient
+    w.r.t. the action as one HIP graph (BASELINE config 3: forward + backward through the render).
+
+    >>> g = GraphedRenderGrad(field, sun, like=action, loss=lambda img, actual: (img * G).sum() + actual.sum())
+    >>> loss, grad = g(action)            # replays; the tensors are overwritten by the next call
+
+    Eagerly that iteration is the render's autograd node, the caller's few torch ops and PyTorch's
+    autograd engine — 85–210 µs of host time for ≈30 µs of kernels at config 3; replayed, it is one
+    graph launch.  The graph bakes in the field's current errors and ``sigma_scale`` (``recapture()``
+    after ``reset_errors()``) and the sun positions passed here.  For a loss whose cotangents are
+    known in closed form, :meth:`HelioField.render_value_and_grad` needs neither graph nor autograd.
+    """
+
+    def __init__(self, field, sun_position, like: torch.Tensor, loss: Callable[[torch.Tensor, torch.Tensor], torch.Tensor],
+                 warmup: int = 3):
+        if not like.is_cuda:
+            raise RuntimeError("GraphedRenderGrad needs a HIP device tensor; there is no CPU path")
+        self.field, self.loss_fn, self.warmup = field, loss, warmup
+        self.sun = torch.as_tensor(sun_position, dtype=torch.float32, device=like.device).clone()
+        self.x = like.detach().clone().requires_grad_(True)        # the graph's static input
+        self.recapture()
+
+    def _iteration(self):
+        img, actual = self.field.render(self.sun, self.x, None)
+        loss = self.loss_fn(img, actual)
+        (grad,) = torch.autograd.grad(loss, self.x)
+        return img, actual, loss, grad
+
+    def recapture(self):
+        self.field._select_trig(self.sun.shape[0] if self.sun.dim() > 1 else 1)   # trig table: not part of the graph
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(self.warmup):
+                self._iteration()
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.image, self.actual, self.loss, self.grad = self._iteration()
+
+    def __call__(self, x: Optional[torch.Tensor] = None):
+        """Replay on ``x`` (copied into the static input; None: the caller updated ``self.x`` in place).
+        → (loss, grad) — static tensors, valid until the next call; ``self.image`` / ``self.actual`` too."""
+        if x is not None:
+            with torch.no_grad():
+                self.x.copy_(x)
+        self.graph.replay()
+        return self.loss, self.grad

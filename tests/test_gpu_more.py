@@ -1347,3 +1347,26 @@ def test_every_form_of_the_fused_env_step_agrees(N, B, R):
                 env.step(act)
         finally:
             ops.splat_variant = 0
+
+
+def test_graphed_render_grad_replays_the_eager_iteration_bit_for_bit():
+    """doodle_amd.graphed.GraphedRenderGrad: render + a torch loss + autograd.grad captured once,
+    replayed as one HIP graph — the same loss and gradient as the eager iteration, also on new inputs."""
+    from doodle_amd.graphed import GraphedRenderGrad
+    f, _, suns, _, act = make_case(N=50, B=25, R=128, seed=8)
+    suns_d, a = suns.to(DEV), act.to(DEV)
+    G = torch.randn(25, 128, 128, device=DEV, generator=torch.Generator(device=DEV).manual_seed(1))
+    loss_fn = lambda img, actual: (img * G).sum() + actual.sum()   # noqa: E731
+    g = GraphedRenderGrad(f, suns_d, like=a, loss=loss_fn)
+    for k in range(3):
+        x = torch.nn.functional.normalize(a.view(25, 50, 3) + 0.002 * k, dim=2).reshape(25, -1)
+        loss, grad = g(x)
+        xr = x.clone().requires_grad_(True)
+        img, actual = f.render(suns_d, xr, None)
+        le = loss_fn(img, actual)
+        (ge,) = torch.autograd.grad(le, xr)
+        assert torch.equal(loss, le.detach()) and torch.equal(grad, ge)
+        assert torch.equal(g.image, img.detach())
+        # and render_value_and_grad with the same cotangents
+        _, _, gv = f.render_value_and_grad(suns_d, x, G, torch.ones(25, 50, 3, device=DEV))
+        assert torch.equal(gv, ge)
