@@ -259,6 +259,11 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    # launch-bound loop: keep the launching thread on the socket the card hangs off (doodle_amd/affinity.py);
+    # the CPU baseline below runs under the original mask
+    from doodle_amd import affinity
+    cpu_mask0 = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None
+    numa = affinity.bind_to_gpu_node(local)
     dist = None
     if world > 1 or args.force_dist:
         import torch.distributed as dist
@@ -393,7 +398,9 @@ def main():
                           else (", no data-path collective (images stay on the rank that rendered them)" if world > 1 else "")),
                        "timing": f"{args.warmup} warm-up steps, {args.preheat} s time-based preheat (untimed, in bursts of "
                                  f"{args.steps} steps + fence), then {args.steps} timed steps between barrier + synchronize "
-                                 "fences, max over ranks"},
+                                 "fences, max over ranks",
+                       "host_affinity": (f"process bound to the {numa['cpus']} CPUs of the GPU's NUMA node {numa['numa_node']}"
+                                         if numa is not None else "scheduler's choice")},
         }
         if dist is not None:
             out["collective"] = {
@@ -435,6 +442,8 @@ def main():
                 except Exception as e:  # noqa: BLE001
                     out["hbm_bound_kernels"] = {"error": repr(e)}
             if not args.no_cpu:
+                if numa is not None:
+                    os.sched_setaffinity(0, cpu_mask0)
                 out["cpu_baseline"] = cpu_baseline(w, args.seed)
                 out["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
         os.write(json_fd, (json.dumps(out) + "\n").encode())

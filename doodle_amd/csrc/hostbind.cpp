@@ -7,8 +7,14 @@
 // instead of ≈7 µs.  No arithmetic happens here.  Optional: if it is not built, native.py's
 // ctypes path is used.
 #include <torch/extension.h>
+#include <c10/hip/HIPFunctions.h>
+#include <c10/hip/HIPGuard.h>
 #include <c10/hip/HIPStream.h>
+#include <torch/csrc/autograd/python_variable.h>
 
+#include <atomic>
+
+#include <chrono>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -98,6 +104,45 @@ py::tuple render_any(int64_t plane, const at::Tensor& helios, const at::Tensor& 
     return render_fwd(plane, helios, sun, normals, trig, trig_b_stride, xs, ys, rays_ws, want_refl, variant);
 }
 
+// Outputs of one launch-bound render: ONE block from torch's caching allocator carved into image | actual
+// (| refl), each a tensor of its own over the shared storage.  Two or three at::empty calls cost 0.72 µs each
+// (dispatcher, device guard, allocator, TensorImpl) next to a 3.3 µs launch and a 3.7 µs kernel; one allocator
+// call and three bare TensorImpls cost about a third of that.  The block goes back to the allocator when the
+// last of the tensors dies — which is why this is only done for small outputs (a caller that keeps `actual`
+// keeps the image's bytes too) — and record_stream() on any of them covers the block, as with at::empty.
+constexpr int64_t kCarveMaxBytes = 8 << 20;
+
+struct Carver {
+    c10::DispatchKeySet keys;
+    caffe2::TypeMeta dtype;
+    c10::Device device;
+    c10::Allocator* alloc;         // the allocator at::empty itself uses for this device (on ROCm: the caching
+                                   // allocator that labels its blocks with torch's "cuda" device type)
+    explicit Carver(const at::Tensor& like)
+        : keys(like.key_set()), dtype(like.dtype()), device(like.device()),
+          alloc(at::empty({0}, like.options()).storage().allocator()) {
+        TORCH_CHECK(alloc != nullptr, "no allocator behind at::empty on ", device);
+    }
+    static int64_t pad(int64_t n) { return (n + 63) & ~int64_t(63); }            // 256-byte sections
+    c10::Storage block(int64_t floats) const {
+        c10::hip::OptionalHIPGuard guard;
+        if (c10::hip::current_device() != device.index()) guard.set_index(device.index());
+        const size_t bytes = (size_t)floats * sizeof(float);
+        return c10::Storage(c10::Storage::use_byte_size_t(), bytes, alloc->allocate(bytes), alloc, /*resizable=*/false);
+    }
+    at::Tensor tensor(const c10::Storage& st, int64_t offset, at::IntArrayRef sizes) const {
+        at::Tensor t = at::detail::make_tensor<c10::TensorImpl>(c10::Storage(st), keys, dtype);
+        auto* impl = t.unsafeGetTensorImpl();
+        impl->set_storage_offset(offset);
+        impl->set_sizes_contiguous(sizes);
+        return t;
+    }
+};
+
+// bumped whenever something a bound context was built from is reassigned on the Python side (the forced
+// kernel variant, the binding itself); a context of an older generation declines its fast entry
+std::atomic<int64_t> g_generation{0};
+
 // A field's render context: everything of HelioField.render's no-autograd call that does not change
 // from call to call (plane, heliostats, pixel coordinates, the trig table of the current errors),
 // bound once — the per-call binding then converts two tensor arguments instead of eleven.  At
@@ -106,11 +151,70 @@ struct RenderCtx {
     int64_t plane;
     at::Tensor helios, xs, ys, trig, rays_ws;
     int64_t trig_b_stride, variant;
+    Carver carve;
+    int64_t generation;
+    at::Tensor errs;               // the error tensor the trig table was made from (bind_errors), for render_checked
+    int64_t errs_version = -1;
     RenderCtx(int64_t plane_, at::Tensor helios_, at::Tensor xs_, at::Tensor ys_, at::Tensor trig_, int64_t stride_,
               int64_t variant_)
         : plane(plane_), helios(std::move(helios_)), xs(std::move(xs_)), ys(std::move(ys_)), trig(std::move(trig_)),
-          trig_b_stride(stride_), variant(variant_) {
+          trig_b_stride(stride_), variant(variant_), carve(helios), generation(g_generation.load()) {
         fp(helios, "heliostat_positions"); fp(xs, "xs"); fp(ys, "ys"); fp(trig, "trig");
+    }
+    void bind_errors(const at::Tensor& e) { errs = e; errs_version = (int64_t)e._version(); }
+
+    struct Outputs { at::Tensor image, actual, refl; };
+    // image [B,R,R] ([R,R] when !batched), actual [B,N,3], refl [B·N,3] (the reference's monitor shape)
+    Outputs outputs(int64_t B, int64_t N, int64_t R, bool want_refl, bool batched) const {
+        Outputs o;
+        const int64_t ni = B * R * R, na = B * N * 3;
+        const int64_t total = Carver::pad(ni) + Carver::pad(na) + (want_refl ? na : 0);
+        if (total * (int64_t)sizeof(float) <= kCarveMaxBytes) {
+            const c10::Storage st = carve.block(total);
+            o.image = batched ? carve.tensor(st, 0, {B, R, R}) : carve.tensor(st, 0, {R, R});
+            o.actual = carve.tensor(st, Carver::pad(ni), {B, N, 3});
+            if (want_refl) o.refl = carve.tensor(st, Carver::pad(ni) + Carver::pad(na), {B * N, 3});
+        } else {
+            const auto opt = helios.options();
+            o.actual = at::empty({B, N, 3}, opt);
+            if (want_refl) o.refl = at::empty({B * N, 3}, opt);
+            o.image = batched ? at::empty({B, R, R}, opt) : at::empty({R, R}, opt);
+        }
+        return o;
+    }
+    // HelioField.render's whole no-autograd call for the arguments as the caller passed them, in the reference's
+    // return shapes: (image, actual) or (image, actual, refl [B·N,3]); a 1-D sun gives image [R,R], actual [1,N,3].
+    // None — the caller then takes the general path — unless: both are plain float32 tensors on the field's device,
+    // contiguous, of matching sizes; no gradient is being recorded for the action; the error tensor this context
+    // was bound to has not been written since; nothing the context was built from has been reassigned
+    // (generation); and the batch size is one this context's trig table serves.
+    py::object render_checked(py::handle sun_h, py::handle action_h, bool want_refl) {
+        if (!THPVariable_CheckExact(sun_h.ptr()) || !THPVariable_CheckExact(action_h.ptr())) return py::none();
+        const at::Tensor& sun = THPVariable_Unpack(sun_h.ptr());
+        const at::Tensor& action = THPVariable_Unpack(action_h.ptr());
+        if (generation != g_generation.load(std::memory_order_relaxed) || !errs.defined() ||
+            (int64_t)errs._version() != errs_version)
+            return py::none();
+        if (action.requires_grad() && at::GradMode::is_enabled()) return py::none();
+        const int64_t N = helios.size(0), R = xs.size(0);
+        const bool batched = sun.dim() == 2;
+        if (!(batched || (sun.dim() == 1 && sun.size(0) == 3))) return py::none();
+        const int64_t B = batched ? sun.size(0) : 1;
+        if (batched && sun.size(1) != 3) return py::none();
+        if (trig_b_stride == 0 ? B != 1 : (B < 2 || trig.numel() < B * N * 4)) return py::none();
+        if (!(sun.scalar_type() == at::kFloat && action.scalar_type() == at::kFloat && sun.device() == helios.device() &&
+              action.device() == helios.device() && sun.is_contiguous() && action.is_contiguous() &&
+              action.numel() == B * N * 3))
+            return py::none();
+        Outputs o = outputs(B, N, R, want_refl, batched);
+        if (!rays_ws.defined() || rays_ws.size(0) != B) rays_ws = at::empty({B, N, HELIO_RAY_STRIDE}, helios.options());
+        check(helio_render_fwd((int)B, (int)N, (int)R, helios.data_ptr<float>(), sun.data_ptr<float>(),
+                               action.data_ptr<float>(), trig.data_ptr<float>(), (long)trig_b_stride,
+                               reinterpret_cast<const helio_plane*>(plane), xs.data_ptr<float>(), ys.data_ptr<float>(),
+                               o.actual.data_ptr<float>(), want_refl ? o.refl.data_ptr<float>() : nullptr,
+                               rays_ws.data_ptr<float>(), o.image.data_ptr<float>(), (int)variant, cur_stream(helios)));
+        if (want_refl) return py::make_tuple(o.image, o.actual, o.refl);
+        return py::make_tuple(o.image, o.actual);
     }
     // → (image [B,R,R], actual [B,N,3]) or, with want_refl, (image, actual, refl [B,N,3]); None when the
     // tensors need a dtype / device / layout fix-up (the caller then takes the general path)
@@ -122,18 +226,62 @@ struct RenderCtx {
             return py::none();
         const int64_t B = sun.size(0);
         if (trig_b_stride != 0 && trig.numel() < B * N * 4) return py::none();
-        const auto opt = helios.options();
-        at::Tensor actual = at::empty({B, N, 3}, opt);
-        at::Tensor refl = want_refl ? at::empty({B, N, 3}, opt) : at::Tensor();
-        if (!rays_ws.defined() || rays_ws.size(0) != B) rays_ws = at::empty({B, N, HELIO_RAY_STRIDE}, opt);
-        at::Tensor image = at::empty({B, R, R}, opt);
+        Outputs o = outputs(B, N, R, want_refl, true);
+        if (!rays_ws.defined() || rays_ws.size(0) != B) rays_ws = at::empty({B, N, HELIO_RAY_STRIDE}, helios.options());
         check(helio_render_fwd((int)B, (int)N, (int)R, helios.data_ptr<float>(), sun.data_ptr<float>(),
                                action.data_ptr<float>(), trig.data_ptr<float>(), (long)trig_b_stride,
                                reinterpret_cast<const helio_plane*>(plane), xs.data_ptr<float>(), ys.data_ptr<float>(),
-                               actual.data_ptr<float>(), want_refl ? refl.data_ptr<float>() : nullptr,
-                               rays_ws.data_ptr<float>(), image.data_ptr<float>(), (int)variant, cur_stream(helios)));
-        if (want_refl) return py::make_tuple(image, actual, refl);
-        return py::make_tuple(image, actual);
+                               o.actual.data_ptr<float>(), want_refl ? o.refl.data_ptr<float>() : nullptr,
+                               rays_ws.data_ptr<float>(), o.image.data_ptr<float>(), (int)variant, cur_stream(helios)));
+        if (want_refl) return py::make_tuple(o.image, o.actual, o.refl.view({B, N, 3}));
+        return py::make_tuple(o.image, o.actual);
+    }
+    // Measurement aid (tools/launch_floor.py): wall-clock nanoseconds per repetition of the pieces of
+    // render() above, each looped n times on the calling thread — the two output allocations, the stream
+    // lookup, and the C-ABI call with fixed output buffers.
+    py::dict host_costs(const at::Tensor& sun, const at::Tensor& action, int64_t n) {
+        const int64_t N = helios.size(0), R = xs.size(0), B = sun.size(0);
+        const auto opt = helios.options();
+        auto now = [] { return std::chrono::steady_clock::now(); };
+        auto ns = [&](std::chrono::steady_clock::time_point t0) {
+            return std::chrono::duration<double, std::nano>(now() - t0).count() / (double)n;
+        };
+        py::dict d;
+        auto t0 = now();
+        for (int64_t i = 0; i < n; ++i) { at::Tensor a = at::empty({B, N, 3}, opt); at::Tensor im = at::empty({B, R, R}, opt); }
+        d["two_at_empty_ns"] = ns(t0);
+        t0 = now();
+        for (int64_t i = 0; i < n; ++i) { Outputs o = outputs(B, N, R, false, true); }
+        d["carved_outputs_ns"] = ns(t0);
+        t0 = now();
+        void* st = nullptr;
+        for (int64_t i = 0; i < n; ++i) st = cur_stream(helios);
+        d["cur_stream_ns"] = ns(t0);
+        at::Tensor actual = at::empty({B, N, 3}, opt), image = at::empty({B, R, R}, opt);
+        if (!rays_ws.defined() || rays_ws.size(0) != B) rays_ws = at::empty({B, N, HELIO_RAY_STRIDE}, opt);
+        check(hipStreamSynchronize((hipStream_t)st) == hipSuccess ? 0 : 1);
+        t0 = now();
+        for (int64_t i = 0; i < n; ++i)
+            check(helio_render_fwd((int)B, (int)N, (int)R, helios.data_ptr<float>(), sun.data_ptr<float>(),
+                                   action.data_ptr<float>(), trig.data_ptr<float>(), (long)trig_b_stride,
+                                   reinterpret_cast<const helio_plane*>(plane), xs.data_ptr<float>(), ys.data_ptr<float>(),
+                                   actual.data_ptr<float>(), nullptr, rays_ws.data_ptr<float>(), image.data_ptr<float>(),
+                                   (int)variant, st));
+        d["abi_call_enqueue_ns"] = ns(t0);
+        (void)hipStreamSynchronize((hipStream_t)st);
+        d["abi_call_with_drain_ns"] = ns(t0);
+        bind_errors(trig);
+        py::object sun_o = py::cast(sun), act_o = py::cast(action);
+        t0 = now();
+        for (int64_t i = 0; i < n; ++i) { py::object o = render_checked(sun_o, act_o, false); }
+        d["render_checked_enqueue_ns"] = ns(t0);
+        (void)hipStreamSynchronize((hipStream_t)st);
+        t0 = now();
+        for (int64_t i = 0; i < n; ++i) { py::object o = render(sun, action, false); }
+        d["render_enqueue_ns"] = ns(t0);
+        (void)hipStreamSynchronize((hipStream_t)st);
+        d["render_with_drain_ns"] = ns(t0);
+        return d;
     }
     // Forward AND the gradient w.r.t. the action for GIVEN cotangents of (image, actual, refl) in one binding
     // call: helio_render_fwd + helio_render_bwd back to back on the current stream, no autograd graph, the
@@ -565,6 +713,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.doc() = "compiled torch binding of libhelio.so's C ABI (same entry points as doodle_amd/native.py)";
     m.def("abi_version", []() { return helio_abi_version(); });
     m.def("make_plane", &make_plane);
+    m.def("invalidate_contexts", []() { return ++g_generation; });
     m.def("current_stream_handle", &current_stream_handle);
     m.def("render_fwd", &render_fwd);
     m.def("render_any", &render_any);
@@ -578,6 +727,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         .def(py::init<int64_t, at::Tensor, at::Tensor, at::Tensor, at::Tensor, int64_t, int64_t>())
         .def("render", &RenderCtx::render)
         .def("render_and_grad", &RenderCtx::render_and_grad)
+        .def("host_costs", &RenderCtx::host_costs)
+        .def("render_checked", &RenderCtx::render_checked)
+        .def("bind_errors", &RenderCtx::bind_errors)
         .def_readonly("trig", &RenderCtx::trig)
         .def_readonly("variant", &RenderCtx::variant);
     m.def("step_losses_fwd", &step_losses_fwd, py::arg("img"), py::arg("target"), py::arg("tx"), py::arg("dmaps"),

@@ -109,8 +109,16 @@ class HelioField:
         self._ray_ws = None
         self._fast_render = None      # ops.render_context once resolved (False: compiled binding absent)
         self._render_ctx, self._ctx_key, self._ops = None, None, None
+        self._fast = None             # the render context of the previous fast call (see __setattr__)
         self.reset_errors()
         self.initial_action = None
+
+    def __setattr__(self, name, value):
+        # any reassignment (errors, heliostats, sigma_scale → _plane, device_trig …) retires the memoised
+        # render context; the slots of the caches themselves are exempt
+        object.__setattr__(self, name, value)
+        if name != "_fast":
+            object.__setattr__(self, "_fast", None)
 
     @property
     def sigma_scale(self) -> float:
@@ -220,6 +228,15 @@ class HelioField:
         ``[B,N,3]`` (``[1,N,3]`` for a 1-D sun), ``refl`` is ``[B·N,3]``.
         ``ideal_normals`` and ``show_spillage`` are accepted and unused, as in the reference.
         """
+        memo = self._fast
+        if memo is not None:
+            # the context of the previous call, still valid (every assignment to an attribute of this field
+            # clears the memo; in-place writes to the error tensor, a forced variant and gradient recording are
+            # checked inside): argument checks, allocation, launch and the reference's return shapes in one
+            # compiled call — at config 2 the kernel needs 3.7 µs, so every host microsecond shows
+            out = memo.render_checked(sun_position, action, monitor)
+            if out is not None:
+                return out
         if (type(sun_position) is torch.Tensor and type(action) is torch.Tensor
                 and not (action.requires_grad and torch.is_grad_enabled())):
             # launch-bound fast path (config 2 is ≈5.3 µs of GPU per call: every host microsecond shows):
@@ -235,8 +252,10 @@ class HelioField:
                 hit = self._trig_cache.get("batch") if B > 1 else None
                 if hit is not None and hit[2] is batch and hit[0][1] == batch._version and B <= batch.shape[0]:
                     trig, stride = hit[1], 4 * self.num_heliostats      # the common case of _select_trig, inlined
+                    cached = True
                 else:
                     trig, stride = self._select_trig(B)
+                    cached = B == 1 or (batch is not None and B <= batch.shape[0])   # else: errors drawn per call
                 ops = self._ops
                 key = self._ctx_key
                 if (key is None or key[0] is not trig or key[1] != stride or key[2] != ops.splat_variant
@@ -249,6 +268,9 @@ class HelioField:
                 if ctx is not None:
                     out = ctx.render(sun_position if batched else sun_position.unsqueeze(0), action, monitor)
                     if out is not None:
+                        if cached:                               # the next call may skip all of the above
+                            ctx.bind_errors(self.error_angles_mrad if stride == 0 else batch)
+                            self._fast = ctx
                         if not monitor:
                             return out if batched else (out[0][0], out[1])
                         img = out[0] if batched else out[0][0]

@@ -139,6 +139,15 @@ def _plane_handle(hb, plane: "Plane") -> int:
 class HipOps:
     """Tensor-level front end of the C ABI.  All tensors fp32, contiguous, on one HIP device."""
 
+    def __setattr__(self, name, value):
+        # compiled render contexts bake in the forced kernel variant and belong to one binding: reassigning
+        # either retires every context built so far (csrc/hostbind.cpp, g_generation)
+        if name in ("splat_variant", "bwd_variant", "hb"):
+            for hb in (self.__dict__.get("hb"), value if name == "hb" else None):
+                if hb is not None and hasattr(hb, "invalidate_contexts"):
+                    hb.invalidate_contexts()
+        object.__setattr__(self, name, value)
+
     def __init__(self):
         self.lib = load_library()
         if not torch.cuda.is_available():

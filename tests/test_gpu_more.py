@@ -1370,3 +1370,87 @@ def test_graphed_render_grad_replays_the_eager_iteration_bit_for_bit():
         # and render_value_and_grad with the same cotangents
         _, _, gv = f.render_value_and_grad(suns_d, x, G, torch.ones(25, 50, 3, device=DEV))
         assert torch.equal(gv, ge)
+
+
+def test_memoised_render_context_keeps_every_semantic_of_the_general_path():
+    """The second and later calls of HelioField.render with conforming arguments run one compiled call
+    (RenderCtx.render_checked: checks, one carved output block, launch, the reference's return shapes).
+    What must survive: the same numbers and shapes as the general path; fresh outputs per call; disjoint
+    image / actual; in-place writes to the error tensor, reassigned attributes, a forced variant and
+    gradient recording all take effect on the NEXT call; batch sizes the bound table does not serve and
+    non-conforming arguments leave through the general path."""
+    from doodle_amd import native
+    f, _, suns, errs, act = make_case(N=9, B=4, R=40, seed=8)
+    sun_d, act_d = suns.to(DEV), act.to(DEV)
+    rows = lambda mon=False: f.render_rows(sun_d, act_d, 0, 4, mon)        # noqa: E731  the general path, no memo
+    want_img, want_actual, want_refl = rows(True)
+    f.render(sun_d, act_d, None)
+    assert f._fast is not None
+    for _ in range(3):
+        img, actual = f.render(sun_d, act_d, None)
+        assert f._fast is not None and torch.equal(img, want_img) and torch.equal(actual, want_actual)
+        assert img.shape == (4, 40, 40) and actual.shape == (4, 9, 3) and img.is_contiguous() and actual.is_contiguous()
+    img3, actual3, refl3 = f.render(sun_d, act_d, None, monitor=True)
+    assert refl3.shape == (36, 3) and torch.equal(refl3, want_refl.reshape(-1, 3)) and torch.equal(img3, want_img)
+    # fresh, disjoint outputs: writing one leaves the others and the next call's alone
+    keep = img.clone()
+    actual.fill_(7.0)
+    refl3.zero_()
+    img_b, actual_b = f.render(sun_d, act_d, None)
+    assert torch.equal(img, keep) and torch.equal(img3, keep) and torch.equal(actual_b, want_actual)
+    assert img_b.data_ptr() != img.data_ptr() and torch.equal(actual3, want_actual)
+    # a smaller batch is a prefix of the same table; B = 1 and a 1-D sun use the single-error tensor
+    img2, actual2 = f.render(sun_d[:2], act_d[:2], None)
+    assert f._fast is not None and torch.equal(img2, want_img[:2]) and torch.equal(actual2, want_actual[:2])
+    one_img, one_actual, _ = f.render_rows(sun_d[1:2], act_d[1:2], 0, 1, False)
+    for _ in range(2):
+        i1, a1 = f.render(sun_d[1], act_d[1], None)
+        assert i1.shape == (40, 40) and a1.shape == (1, 9, 3) and torch.equal(i1, one_img[0]) and torch.equal(a1, one_actual)
+        i1b, a1b, r1b = f.render(sun_d[1:2], act_d[1:2], None, monitor=True)
+        assert i1b.shape == (1, 40, 40) and r1b.shape == (9, 3) and torch.equal(i1b, one_img)
+    for _ in range(2):
+        assert torch.equal(f.render(sun_d, act_d, None)[0], want_img)
+    # in-place write to the bound error tensor
+    f.batch_error_angles_mrad.mul_(0.5)
+    half, _ = f.render(sun_d, act_d, None)
+    g, _, _, _, _ = make_case(N=9, B=4, R=40, seed=8)
+    g.batch_error_angles_mrad = errs.clone()          # make_case binds `errs` itself: it is halved by now
+    assert torch.equal(half, g.render(sun_d, act_d, None)[0]) and not torch.equal(half, want_img)
+    assert torch.equal(f.render(sun_d, act_d, None)[0], half)
+    # gradient recording: the memo declines, autograd runs, and the memo serves the next plain call again
+    a_req = act_d.clone().requires_grad_(True)
+    img_g, _ = f.render(sun_d, a_req, None)
+    assert img_g.requires_grad and torch.equal(img_g.detach(), half)
+    with torch.no_grad():
+        assert not f.render(sun_d, a_req, None)[0].requires_grad
+    # forced variant: retires every context
+    ops = native.get_ops()
+    ops.splat_variant = 1
+    try:
+        valu, _ = f.render(sun_d, act_d, None)
+        assert f._render_ctx.variant == 1
+        assert torch.equal(valu, f.render_rows(sun_d, act_d, 0, 4, False)[0])
+        torch.testing.assert_close(valu, half, rtol=1e-5, atol=1e-8)
+    finally:
+        ops.splat_variant = 0
+    assert torch.equal(f.render(sun_d, act_d, None)[0], half)
+    # reassigned attributes
+    f.sigma_scale = 0.05
+    assert f._fast is None
+    g.sigma_scale = 0.05
+    assert torch.equal(f.render(sun_d, act_d, None)[0], g.render_rows(sun_d, act_d, 0, 4, False)[0])
+    f.device_trig = True
+    assert f._fast is None
+    f.device_trig = False
+    # more suns than pre-sampled errors: errors are drawn per call (:349-353) — never memoised
+    big_s, big_a = sun_d.repeat(2, 1), act_d.repeat(2, 1)
+    x1, _ = f.render(big_s, big_a, None)
+    assert f._fast is None
+    x2, _ = f.render(big_s, big_a, None)
+    assert x1.shape == (8, 40, 40) and not torch.equal(x1, x2)
+    # non-conforming arguments after a memoised call
+    f.render(sun_d, act_d, None)
+    assert f._fast is not None
+    want5 = f.render(sun_d, act_d, None)[0]
+    assert torch.equal(f.render(suns, act.double(), None)[0], want5)
+    assert torch.equal(f.render(sun_d.tolist(), act_d.reshape(4, 9, 3), None)[0], want5)

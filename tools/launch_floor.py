@@ -45,3 +45,9 @@ if hb is not None:
         print(f"field.render(sun, action, None)                           {wall(lambda: f.render(suns_d, act, None)):.2f} us")
         e = torch.empty
         print(f"torch.empty((25,128,128)) alone                           {wall(lambda: e((25, 128, 128), device=dev)):.2f} us")
+        ctx, _, _ = f._render_context(w.B)
+        if ctx is not None and hasattr(ctx, "host_costs"):
+            for rep in range(2):
+                d = ctx.host_costs(suns_d, normals, 20000)
+                print("RenderCtx pieces, ns per repetition inside C++:", {k: round(v) for k, v in d.items()})
+            print(f"ctx.render(sun, action, False) from Python                {wall(lambda: ctx.render(suns_d, normals, False)):.2f} us")
