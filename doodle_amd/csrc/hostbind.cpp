@@ -12,6 +12,7 @@
 #include <c10/hip/HIPStream.h>
 #include <torch/csrc/autograd/python_variable.h>
 
+#include <array>
 #include <atomic>
 
 #include <chrono>
@@ -142,6 +143,27 @@ struct Carver {
 // bumped whenever something a bound context was built from is reassigned on the Python side (the forced
 // kernel variant, the binding itself); a context of an older generation declines its fast entry
 std::atomic<int64_t> g_generation{0};
+
+// one Carver per device, made on first use (the key set and allocator of a plain float32 tensor there)
+const Carver& carver_for(const at::Tensor& like) {
+    static std::array<std::atomic<const Carver*>, 64> table{};
+    const int idx = like.get_device();
+    TORCH_CHECK(idx >= 0 && idx < 64 && like.scalar_type() == at::kFloat, "carver_for: float32 device tensor expected");
+    const Carver* c = table[idx].load(std::memory_order_acquire);
+    if (c == nullptr) {
+        const Carver* fresh = new Carver(like);
+        if (table[idx].compare_exchange_strong(c, fresh, std::memory_order_acq_rel)) c = fresh;
+        else delete fresh;
+    }
+    return *c;
+}
+
+// a tensor of its own over `base`'s storage, `delta` elements past base's first (base contiguous): what
+// select / narrow / view return, minus the dispatcher and the view bookkeeping — for outputs of the no-grad
+// paths only (nothing tracks that the two alias)
+at::Tensor bare_view(const at::Tensor& base, int64_t delta, at::IntArrayRef sizes) {
+    return carver_for(base).tensor(base.storage(), base.storage_offset() + delta, sizes);
+}
 
 // A field's render context: everything of HelioField.render's no-autograd call that does not change
 // from call to call (plane, heliostats, pixel coordinates, the trig table of the current errors),
@@ -423,25 +445,35 @@ StepOut step_core(int64_t plane, const at::Tensor& helios, const at::Tensor& sun
     const auto opt = normals.options();
     const float* pn = fp(normals, "action");
     StepOut o;
-    o.actual = at::empty_like(normals);
-    o.refl = at::empty_like(normals);
-    o.rays = rays_ws.has_value() ? *rays_ws : at::empty({B, N, HELIO_RAY_STRIDE}, opt);
-    o.image = at::empty({B, R, R}, opt);
-    // the six small buffers (workspace, 5 scalars, per-image and per-ray vectors) are slices of ONE
-    // allocation: a caching-allocator round trip costs about twice what a view does, and this call sits
-    // in front of a launch the caller then waits for
+    // workspace, the 5 scalars, the per-image and per-ray vectors — and, while the whole step is small (the
+    // launch-bound regime), image / actual / refl / aux too — are sections of ONE block from the caching
+    // allocator (Carver): an at::empty costs 0.7 µs and a view op 0.3–0.4 µs in front of two 3.4 µs launches
     const int64_t nws = helio_env_step_workspace((int)B, (int)N, (int)R);
-    auto up4 = [](int64_t n) { return (n + 3) & ~int64_t(3); };          // keep every slice 16-byte aligned
-    const int64_t o_out = up4(nws), o_mae = o_out + 8, o_keep = o_mae + up4(B), o_align = o_keep + up4(B),
-                  o_allb = o_align + up4(B * N), total = o_allb + up4(B * N);
-    at::Tensor flat = at::empty({total}, opt);
-    at::Tensor ws = flat;                                                  // the first nws floats
-    o.out = flat.narrow(0, o_out, 5);
-    o.mae = flat.narrow(0, o_mae, B);
-    o.keep = flat.narrow(0, o_keep, B);
-    o.align = at::as_strided(flat, {B, N}, {N, 1}, o_align);
-    o.allb = at::as_strided(flat, {B, N}, {N, 1}, o_allb);
-    if (want_aux) o.aux = at::empty({B, 3 + 3 * N}, opt);
+    const int64_t ni = B * R * R, na = B * N * 3, naux = want_aux ? B * (3 + 3 * N) : 0;
+    auto P = Carver::pad;
+    const int64_t f_out = P(nws), f_mae = f_out + 64, f_keep = f_mae + P(B), f_align = f_keep + P(B),
+                  f_allb = f_align + P(B * N), f_small = f_allb + P(B * N);
+    const bool carve_all = (f_small + P(ni) + 2 * P(na) + P(naux)) * (int64_t)sizeof(float) <= kCarveMaxBytes;
+    const Carver& cv = carver_for(helios);
+    const c10::Storage st = cv.block(carve_all ? f_small + P(ni) + 2 * P(na) + P(naux) : f_small);
+    at::Tensor ws = cv.tensor(st, 0, {nws});
+    o.out = cv.tensor(st, f_out, {5});
+    o.mae = cv.tensor(st, f_mae, {B});
+    o.keep = cv.tensor(st, f_keep, {B});
+    o.align = cv.tensor(st, f_align, {B, N});
+    o.allb = cv.tensor(st, f_allb, {B, N});
+    if (carve_all) {
+        o.image = cv.tensor(st, f_small, {B, R, R});
+        o.actual = cv.tensor(st, f_small + P(ni), {B, N, 3});
+        o.refl = cv.tensor(st, f_small + P(ni) + P(na), {B, N, 3});
+        if (want_aux) o.aux = cv.tensor(st, f_small + P(ni) + 2 * P(na), {B, 3 + 3 * N});
+    } else {
+        o.actual = at::empty_like(normals);
+        o.refl = at::empty_like(normals);
+        o.image = at::empty({B, R, R}, opt);
+        if (want_aux) o.aux = at::empty({B, 3 + 3 * N}, opt);
+    }
+    o.rays = rays_ws.has_value() ? *rays_ws : at::empty({B, N, HELIO_RAY_STRIDE}, opt);
     check(helio_env_step_fwd((int)B, (int)N, (int)R, fp(helios, "heliostat_positions"), fp(sun, "sun"), pn,
                              fp(trig, "trig"), (long)trig_b_stride, reinterpret_cast<const helio_plane*>(plane),
                              fp(xs, "xs"), fp(ys, "ys"), o.actual.data_ptr<float>(), o.refl.data_ptr<float>(),
@@ -524,9 +556,10 @@ struct EnvStepCtx {
         const StepOut r = step_core(plane, helios, sun, normals, trig, trig_b_stride, xs, ys, ws, variant, target, tx, dmaps,
                                     ideal, tp, tn, W, H, exp_risk, mask_ratio, true, ticket != 0 ? notify : 0, ticket);
         rays_ws = r.rays;
-        return py::make_tuple(r.image, r.actual, r.refl.view({B * N, 3}), r.out.select(0, 0), r.out.select(0, 1),
-                              r.out.select(0, 2), r.out.select(0, 3), r.out.select(0, 4), r.mae.view({B, 1}),
-                              r.align.view({B * N}), r.allb, r.aux, normals);
+        return py::make_tuple(r.image, r.actual, bare_view(r.refl, 0, {B * N, 3}), bare_view(r.out, 0, {}),
+                              bare_view(r.out, 1, {}), bare_view(r.out, 2, {}), bare_view(r.out, 3, {}),
+                              bare_view(r.out, 4, {}), bare_view(r.mae, 0, {B, 1}), bare_view(r.align, 0, {B * N}), r.allb,
+                              r.aux, normals);
     }
 };
 
