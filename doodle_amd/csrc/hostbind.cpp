@@ -114,14 +114,22 @@ py::tuple render_any(int64_t plane, const at::Tensor& helios, const at::Tensor& 
 constexpr int64_t kCarveMaxBytes = 8 << 20;
 
 struct Carver {
-    c10::DispatchKeySet keys;
+    c10::DispatchKeySet keys, keys_inference;   // of what at::empty returns outside / inside torch.inference_mode()
     caffe2::TypeMeta dtype;
     c10::Device device;
     c10::Allocator* alloc;         // the allocator at::empty itself uses for this device (on ROCm: the caching
                                    // allocator that labels its blocks with torch's "cuda" device type)
-    explicit Carver(const at::Tensor& like)
-        : keys(like.key_set()), dtype(like.dtype()), device(like.device()),
-          alloc(at::empty({0}, like.options()).storage().allocator()) {
+    explicit Carver(const at::Tensor& like) : dtype(like.dtype()), device(like.device()), alloc(nullptr) {
+        {
+            c10::InferenceMode off(false);
+            const at::Tensor proto = at::empty({0}, like.options());
+            keys = proto.key_set();
+            alloc = proto.storage().allocator();
+        }
+        {
+            c10::InferenceMode on(true);
+            keys_inference = at::empty({0}, like.options()).key_set();
+        }
         TORCH_CHECK(alloc != nullptr, "no allocator behind at::empty on ", device);
     }
     static int64_t pad(int64_t n) { return (n + 63) & ~int64_t(63); }            // 256-byte sections
@@ -132,7 +140,8 @@ struct Carver {
         return c10::Storage(c10::Storage::use_byte_size_t(), bytes, alloc->allocate(bytes), alloc, /*resizable=*/false);
     }
     at::Tensor tensor(const c10::Storage& st, int64_t offset, at::IntArrayRef sizes) const {
-        at::Tensor t = at::detail::make_tensor<c10::TensorImpl>(c10::Storage(st), keys, dtype);
+        at::Tensor t = at::detail::make_tensor<c10::TensorImpl>(
+            c10::Storage(st), c10::InferenceMode::is_enabled() ? keys_inference : keys, dtype);
         auto* impl = t.unsafeGetTensorImpl();
         impl->set_storage_offset(offset);
         impl->set_sizes_contiguous(sizes);

@@ -1454,3 +1454,40 @@ def test_memoised_render_context_keeps_every_semantic_of_the_general_path():
     want5 = f.render(sun_d, act_d, None)[0]
     assert torch.equal(f.render(suns, act.double(), None)[0], want5)
     assert torch.equal(f.render(sun_d.tolist(), act_d.reshape(4, 9, 3), None)[0], want5)
+
+
+def test_carved_outputs_behave_like_at_empty_tensors():
+    """The outputs of the launch-bound paths are sections of one allocator block (hostbind.cpp, Carver).
+    They must be indistinguishable from at::empty tensors where it matters: device / dtype / layout,
+    usable as autograd leaves and saved tensors, inference tensors exactly when made under
+    torch.inference_mode(), record_stream, and alive independently of each other."""
+    import gc
+    f, _, suns, _, act = make_case(N=9, B=4, R=40, seed=11)
+    sun_d, act_d = suns.to(DEV), act.to(DEV)
+    f.render(sun_d, act_d, None)
+    img, actual, refl = f.render(sun_d, act_d, None, monitor=True)
+    ref = torch.empty(1, device=DEV)
+    for t in (img, actual, refl):
+        assert t.device == ref.device and t.dtype == torch.float32 and t.is_contiguous() and not t.is_inference()
+        assert t.data_ptr() % 16 == 0 and not t.requires_grad and t.grad_fn is None and t._base is None
+    # a leaf of a later graph, and a saved tensor of one
+    w = torch.ones_like(img).requires_grad_(True)
+    (img * w).sum().backward()
+    assert torch.equal(w.grad, img)
+    leaf = img.requires_grad_(True)
+    (leaf * 2).sum().backward()
+    assert torch.equal(leaf.grad, torch.full_like(img, 2.0))
+    # one survives the others
+    want = actual.clone()
+    del img, refl, leaf, w
+    gc.collect()
+    junk = [torch.randn(4, 40, 40, device=DEV) for _ in range(8)]          # would land in a freed block
+    torch.cuda.synchronize()
+    assert torch.equal(actual, want)
+    del junk
+    actual.record_stream(torch.cuda.Stream())
+    with torch.inference_mode():
+        i2, a2 = f.render(sun_d, act_d, None)
+        assert i2.is_inference() and a2.is_inference()
+    i3, _ = f.render(sun_d, act_d, None)
+    assert not i3.is_inference() and torch.equal(i3, i2)
