@@ -22,6 +22,7 @@ int launch_splat_fwd(int, int, int, const float*, const float*, const float*, fl
 int launch_splat_bwd(int, int, int, const float*, const float*, const float*, const float*, float*, int, hipStream_t);
 int splat_bwd_blocks(int);
 bool render_is_fused(int, int, int);
+int render_fwd_choice(int, int, int);
 void launch_distance_maps(int, int, const float*, float, int*, float*, int*, float*, hipStream_t);
 int step_losses_chunks(int);
 int step_losses_ray_wgs(int, int);
@@ -45,6 +46,11 @@ void launch_geometry_bwd_losses(int, int, int, const float*, const float*, const
                                 const float*, const float*, const float*, const float*, float, float, int,
                                 hipStream_t);
 long env_step_fused_workspace(int, int);
+bool render_bwd_is_fused(int, int, int);
+bool launch_render_bwd_fused(int, int, int, const float*, const float*, const float*, const float*, const float*,
+                             const float*, const float*, const float*, long, const helio_plane*, const float*,
+                             const float*, float*, const float*, const float*, const float*, const float*,
+                             const float*, float, float, int, hipStream_t);
 bool launch_env_step_fused(int, int, int, const float*, const float*, const float*, const float*, long,
                            const helio_plane*, const float*, const float*, float*, float*, float*, float*,
                            const float*, const float*, const float*, const float*, const float*, const float*, float,
@@ -191,6 +197,14 @@ int helio_render_bwd(int B, int N, int R, const float* helios_d, const float* su
         if (!rays_d || !xs_d || !ys_d || !moments_d) return fail(HELIO_E_INVALID, "render_bwd: null pointer");
         if (!aligned16(rays_d) || !aligned16(grad_image_d))
             return fail(HELIO_E_INVALID, "render_bwd: rays/grad_image must be 16-byte aligned");
+        // variant 8 forces, variant 0 chooses by size: moments and the geometry adjoint in ONE launch
+        if (variant == 8 || (variant == 0 && helio::render_bwd_is_fused(B, N, R))) {
+            if (!helio::launch_render_bwd_fused(B, N, R, rays_d, xs_d, ys_d, grad_image_d, helios_d, sun_d, action_d, trig_d,
+                                                trig_b_stride, plane, grad_actual_d, grad_refl_d, grad_action_d, nullptr,
+                                                nullptr, nullptr, nullptr, nullptr, 0.0f, 0.0f, 0, st))
+                return fail(HELIO_E_INVALID, "render_bwd: variant 8 does not exist for B=%d N=%d R=%d", B, N, R);
+            return after_launch("render_bwd");
+        }
         if (helio::launch_splat_bwd(B, N, R, rays_d, xs_d, ys_d, grad_image_d, moments_d, variant, st) != HELIO_OK)
             return fail(HELIO_E_INVALID, "render_bwd: unknown variant %d", variant);
     }
@@ -292,6 +306,11 @@ long helio_env_step_workspace(int B, int N, int R) {
     if (a == 0) return 0;
     const long f = helio::env_step_fused_workspace(B, R);
     return a > f ? a : f;
+}
+
+int helio_render_fwd_choice(int B, int N, int R) {
+    if (!sizes_ok(B, N) || R < 1 || R > 16384) return 0;
+    return helio::render_fwd_choice(B, N, R);
 }
 
 int helio_env_step_launches(int B, int N, int R) {
@@ -418,6 +437,15 @@ int helio_env_step_bwd(int B, int N, int R, const float* helios_d, const float* 
                                           helios_d, target_position, target_normal, width, height, exponential_risk,
                                           g_mse_d, g_dist_d, nullptr, nullptr, keep_d, grad_image_ws_d, nullptr,
                                           nullptr, st);
+            if (variant == 8 || (variant == 0 && helio::render_bwd_is_fused(B, N, R))) {
+                const bool ray_losses = g_align_d || g_bound_d;
+                if (!helio::launch_render_bwd_fused(B, N, R, rays_d, xs_d, ys_d, grad_image_ws_d, helios_d, sun_d, action_d,
+                                                    trig_d, trig_b_stride, plane, grad_actual_d, grad_refl_d, grad_action_d,
+                                                    ray_losses ? ideal_d : nullptr, g_align_d, g_bound_d, target_position,
+                                                    target_normal, width, height, exponential_risk, st))
+                    return fail(HELIO_E_INVALID, "env_step_bwd: variant 8 does not exist for B=%d N=%d R=%d", B, N, R);
+                return after_launch("env_step_bwd");
+            }
             if (helio::launch_splat_bwd(B, N, R, rays_d, xs_d, ys_d, grad_image_ws_d, moments_d, variant, st) != HELIO_OK)
                 return fail(HELIO_E_INVALID, "env_step_bwd: unknown variant %d", variant);
         }

@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include "helio.h"
 #include "step_loss_math.h"
+#include "geometry_bwd_ray.h"
 
 namespace helio {
 
@@ -363,35 +364,24 @@ splat_bwd_mfma(int B, int N, int R, const float* __restrict__ rays, const float*
 //   * every wave weights its partial block with the other-axis factor and reduces it over c in
 //     registers, so that only three numbers per ray cross the workgroup (LDS, one barrier), summed in
 //     fixed wave order.
-template <int PASS, int KS>
-__device__ __forceinline__ void splat_bwd_small_body(int N, int R, const float* __restrict__ rays,
-                                                     const float* __restrict__ xs, const float* __restrict__ ys,
-                                                     const float* __restrict__ gimg, float* __restrict__ moments,
-                                                     float* smem) {
-    float* __restrict__ sCc = smem;                // [KS][64] c coordinates, one private copy per wave
-    float* __restrict__ sRed = smem + KS * 64;     // [KS][32 rays][3]
-
-    const int JB = (R + 63) / 64;
-    const int b = blockIdx.y;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+// One wave's share of one contraction: the 64 c × 32 rays block at (c0, n0) of image `G`, contracted over
+// k in [k_begin, k_end) (even bounds), weighted by the other-axis factor and reduced over the block's 64 c
+// in registers → (m0, m1, m2) for the ray n0 + (lane & 31), complete in BOTH halves of the wave.
+// `sCc_wave`: 64 floats of LDS private to the wave.
+template <int PASS>
+__device__ __forceinline__ void small_wave_partial(int N, int R, const float* __restrict__ rays_b,
+                                                   const float* __restrict__ xs, const float* __restrict__ ys,
+                                                   const float* __restrict__ G, int c0, int n0, int k_begin, int k_end,
+                                                   float* __restrict__ sCc_wave, float& m0, float& m1, float& m2) {
+    const int lane = threadIdx.x & 63;
     const int lr = lane & 31, lh = lane >> 5;
-    const int c0 = (blockIdx.x % JB) * 64, n0 = (blockIdx.x / JB) * 32;
     const float* __restrict__ ccoord = PASS == 0 ? ys : xs;   // coordinates along c (the axis that survives)
     const float* __restrict__ kcoord = PASS == 0 ? xs : ys;   // coordinates along k (the contracted axis)
-    const float* __restrict__ G = gimg + (long)b * R * R;
-
-    // this wave's part of the contracted axis: k-pairs dealt evenly, in multiples of 2 (so that a wave
-    // starts at a multiple of 4: 16-byte row segments in pass 1)
-    const int pairs = (R + 1) >> 1;
-    const int per = (((pairs + KS - 1) / KS) + 1) & ~1;
-    const int k_begin = min(R, 2 * per * wave), k_end = min(R, 2 * per * (wave + 1));
-
     // this lane's ray (B operand and epilogue) and its c coordinate: requested first, used only after the
     // first group of grad-image loads has been issued — every first touch of memory in a freshly launched
     // kernel costs ≈900 cycles, so none of them may wait for another
     const int n = n0 + lr;
-    const float4 qraw = reinterpret_cast<const float4*>(rays)[(long)b * N + min(n, N - 1)];
+    const float4 qraw = reinterpret_cast<const float4*>(rays_b)[min(n, N - 1)];
     const float ccv = ccoord[min(c0 + lane, R - 1)];
 
     f32x16 acc0, acc1;
@@ -480,8 +470,8 @@ __device__ __forceinline__ void splat_bwd_small_body(int N, int R, const float* 
     const float hshift = PASS == 0 ? qraw.y : qraw.x;
     const float hcc = PASS == 0 ? 0.0f : qraw.w;
     const float hk = n < N ? qraw.z : 0.0f;
-    float m0 = 0.f, m1 = 0.f, m2 = 0.f;
-    sCc[wave * 64 + lane] = ccv;                                // wave-private: LDS is in order within a wave
+    m0 = 0.f; m1 = 0.f; m2 = 0.f;
+    sCc_wave[lane] = ccv;                                // wave-private: LDS is in order within a wave
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -489,13 +479,40 @@ __device__ __forceinline__ void splat_bwd_small_body(int N, int R, const float* 
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int cl = 32 * blk + (e & 3) + 8 * (e >> 2) + 4 * lh;
-            const float s = sCc[wave * 64 + cl] + hshift;
+            const float s = sCc_wave[cl] + hshift;
             const float w = __builtin_amdgcn_exp2f(-(__builtin_fmaf(s, s, hcc) * hk)) * (blk == 0 ? acc0[e] : acc1[e]);
             m0 += w;
             m1 = __builtin_fmaf(s, w, m1);
             m2 = __builtin_fmaf(s * s, w, m2);
         }
     m0 += __shfl_xor(m0, 32); m1 += __shfl_xor(m1, 32); m2 += __shfl_xor(m2, 32);
+}
+
+template <int PASS, int KS>
+__device__ __forceinline__ void splat_bwd_small_body(int N, int R, const float* __restrict__ rays,
+                                                     const float* __restrict__ xs, const float* __restrict__ ys,
+                                                     const float* __restrict__ gimg, float* __restrict__ moments,
+                                                     float* smem) {
+    float* __restrict__ sCc = smem;                // [KS][64] c coordinates, one private copy per wave
+    float* __restrict__ sRed = smem + KS * 64;     // [KS][32 rays][3]
+
+    const int JB = (R + 63) / 64;
+    const int b = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 31, lh = lane >> 5;
+    const int c0 = (blockIdx.x % JB) * 64, n0 = (blockIdx.x / JB) * 32;
+    const float* __restrict__ G = gimg + (long)b * R * R;
+
+    // this wave's part of the contracted axis: k-pairs dealt evenly, in multiples of 2 (so that a wave
+    // starts at a multiple of 4: 16-byte row segments in pass 1)
+    const int pairs = (R + 1) >> 1;
+    const int per = (((pairs + KS - 1) / KS) + 1) & ~1;
+    const int k_begin = min(R, 2 * per * wave), k_end = min(R, 2 * per * (wave + 1));
+
+    const int n = n0 + lr;
+    float m0, m1, m2;
+    small_wave_partial<PASS>(N, R, rays + 4l * b * N, xs, ys, G, c0, n0, k_begin, k_end, sCc + wave * 64, m0, m1, m2);
     if (lh == 0) {
         float* r = sRed + (wave * 32 + lr) * 3;
         r[0] = m0; r[1] = m1; r[2] = m2;
@@ -521,6 +538,109 @@ splat_bwd_mfma_small(int N, int R, const float* __restrict__ rays, const float* 
     __shared__ float smem[KS * 64 + KS * 32 * 3];
     if (blockIdx.z == 0) splat_bwd_small_body<0, KS>(N, R, rays, xs, ys, gimg, moments, smem);
     else splat_bwd_small_body<1, KS>(N, R, rays, xs, ys, gimg, moments, smem);
+}
+
+// ----------------------------------------------------------------------------------------------
+// Small problems, the WHOLE backward of the render in one launch: moments + geometry adjoint.
+// ----------------------------------------------------------------------------------------------
+// At config 3 the backward was two launches of latency — splat_bwd_mfma_small (6.6 µs: first touch of the
+// rays and of the grad image, 32 MFMAs a wave, epilogue, LDS reduce, store of the partial moments) and
+// geometry_bwd_kernel (4.2 µs: first touch again — of the moments just written —, the trace and its
+// adjoint), with a 1.5 µs kernel boundary between them.  Here a workgroup owns 32 rays of one sun
+// COMPLETELY: its 16 waves are the (pass, 64-wide c block, k part) combinations the small kernel spreads
+// over workgroups — CT c blocks (R <= 64·CT), KS = 8 / CT k parts, every wave exactly small_wave_partial —
+// so all five moments of its rays meet in LDS, and lanes 0..31 of wave 0 run the geometry adjoint on them
+// at once.  Those lanes request their ray's inputs before the contraction starts; the moments never
+// touch memory.  Sums in fixed order (k parts, then c blocks — the order the two-launch path adds them in).
+bool splat_bwd_is_few(int B, int N);
+
+template <int CT>
+__global__ void __launch_bounds__(1024)
+render_bwd_fused_small(int B, int N, int R, const float* __restrict__ rays, const float* __restrict__ xs,
+                       const float* __restrict__ ys, const float* __restrict__ gimg,
+                       const float* __restrict__ helios, const float* __restrict__ sun,
+                       const float* __restrict__ action, const float* __restrict__ trig, long trig_b_stride,
+                       PlaneK P, const float* __restrict__ g_actual, const float* __restrict__ g_refl,
+                       float* __restrict__ g_action, RayLossBwdArgs RL) {
+    constexpr int KS = 8 / CT;
+    __shared__ float sCc[16 * 64];                   // c coordinates, one private copy per wave
+    __shared__ float sRed[16 * 32 * 3];              // [pass][c block][k part][ray][3]
+    const int b = blockIdx.y, n0 = blockIdx.x * 32;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 31, lh = lane >> 5;
+    const int pass = wave >> 3, cblk = (wave & 7) / KS, kpart = (wave & 7) % KS;
+    const float* __restrict__ G = gimg + (long)b * R * R;
+
+    // the ray adjoint's own inputs (wave 0, one ray per lane of its lower half): in flight during the contraction
+    const int n = n0 + lr;
+    const long m = (long)b * N + min(n, N - 1);
+    RayBwdIn in;
+    if (wave == 0) in.load(m, b, min(n, N - 1), helios, sun, action, trig, trig_b_stride, g_actual, g_refl);
+
+    const int pairs = (R + 1) >> 1;
+    const int per = (((pairs + KS - 1) / KS) + 1) & ~1;
+    const int k_begin = min(R, 2 * per * kpart), k_end = min(R, 2 * per * (kpart + 1));
+    float m0 = 0.f, m1 = 0.f, m2 = 0.f;
+    if (64 * cblk < R) {                             // (wave-uniform) c blocks past the image contribute nothing
+        if (pass == 0) small_wave_partial<0>(N, R, rays + 4l * b * N, xs, ys, G, 64 * cblk, n0, k_begin, k_end, sCc + wave * 64, m0, m1, m2);
+        else small_wave_partial<1>(N, R, rays + 4l * b * N, xs, ys, G, 64 * cblk, n0, k_begin, k_end, sCc + wave * 64, m0, m1, m2);
+    }
+    if (lh == 0) {
+        float* r = sRed + (wave * 32 + lr) * 3;
+        r[0] = m0; r[1] = m1; r[2] = m2;
+    }
+    __syncthreads();
+    if (tid >= 32 || n >= N) return;
+    // pass 0 → (M0, Ms = My, Mss = Myy), pass 1 → (·, Mt = Mx, Mtt = Mxx); k parts first, then c blocks
+    float M0 = 0.f, Mx = 0.f, My = 0.f, Mxx = 0.f, Myy = 0.f;
+#pragma unroll
+    for (int cb = 0; cb < CT; ++cb) {
+        float t[2][3];
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps)
+#pragma unroll
+            for (int w = 0; w < KS; ++w) {
+                const float* r = sRed + (((ps * 8 + cb * KS + w) * 32) + lr) * 3;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) t[ps][k] = w == 0 ? r[k] : t[ps][k] + r[k];
+            }
+        M0 += t[0][0]; Mx += t[1][1]; My += t[0][1]; Mxx += t[1][2]; Myy += t[0][2];
+    }
+    st3(g_action + 3 * m, geometry_bwd_ray(in, m, n, B, N, P, true, M0, Mx, My, Mxx, Myy, g_actual != nullptr, helios, action, RL));
+}
+
+// The sizes the single-launch backward serves.  Measured at config 3 (rocprofv3): 12.1 µs, the same GPU time
+// as the two launches it replaces (6.6 + 4.0 + the boundary) — its 16 waves share ONE CU's matrix pipe
+// (4 per SIMD, 8192 MFMA cycles each SIMD) where the small kernel spreads them over four CUs, which eats
+// what the saved boundary and the saved round trip of the moments give — but one launch less for the host
+// (render_value_and_grad 20.7 → 17.2 µs).  So it is chosen only where the two-launch form cannot spread
+// either: at most 64 workgroups (B · ⌈N/32⌉), an image of at most four 64-wide c blocks, the small MFMA
+// kernel's regime (not the few-ray one).  HELIO_BWD_FUSED=0 switches the choice off; variant 8 forces it.
+bool render_bwd_is_fused(int B, int N, int R) {
+    static const bool off = [] { const char* e = getenv("HELIO_BWD_FUSED"); return e && e[0] == '0'; }();
+    if (off || splat_bwd_is_few(B, N) || R > 256 || (R > 128 && N >= 96)) return false;
+    return (long)B * ((N + 31) / 32) <= 64;
+}
+
+// ideal == nullptr: the render's backward alone; else with the adjoint of HelioEnv.step's two ray losses
+bool launch_render_bwd_fused(int B, int N, int R, const float* rays, const float* xs, const float* ys, const float* gimg,
+                             const float* helios, const float* sun, const float* action, const float* trig,
+                             long trig_b_stride, const helio_plane* plane, const float* g_actual, const float* g_refl,
+                             float* g_action, const float* ideal, const float* g_align, const float* g_bound,
+                             const float* tp, const float* tn, float W, float H, int exponential_risk, hipStream_t st) {
+    if (R > 256 || B > 65535) return false;
+    RayLossBwdArgs RL{};
+    if (ideal) {
+        RL.ideal = ideal; RL.g_align = g_align; RL.g_bound = g_bound;
+        RL.g = make_geom(tp, tn, W, H, exponential_risk);
+    }
+    const dim3 grid((N + 31) / 32, B), block(1024);
+    const PlaneK P = to_k(plane);
+    if (R <= 64) hipLaunchKernelGGL(render_bwd_fused_small<1>, grid, block, 0, st, B, N, R, rays, xs, ys, gimg, helios, sun, action, trig, trig_b_stride, P, g_actual, g_refl, g_action, RL);
+    else if (R <= 128) hipLaunchKernelGGL(render_bwd_fused_small<2>, grid, block, 0, st, B, N, R, rays, xs, ys, gimg, helios, sun, action, trig, trig_b_stride, P, g_actual, g_refl, g_action, RL);
+    else hipLaunchKernelGGL(render_bwd_fused_small<4>, grid, block, 0, st, B, N, R, rays, xs, ys, gimg, helios, sun, action, trig, trig_b_stride, P, g_actual, g_refl, g_action, RL);
+    return true;
 }
 
 // waves per workgroup of the small backward kernel (they split the contracted axis): 8 while that keeps
@@ -1004,6 +1124,7 @@ int splat_bwd_blocks(int R) { return (R + BW_JT - 1) / BW_JT; }
 // 4 = few-ray streaming kernel, 5 = split-bf16 MFMA kernels (opt-in), 6 / 7 = the small kernel with 4 / 8 waves
 int launch_splat_bwd(int B, int N, int R, const float* rays, const float* xs, const float* ys,
                      const float* gimg, float* moments, int variant, hipStream_t st) {
+    if (variant == 8) variant = 3;       // 8 is helio_render_bwd's single-launch form; its moments alone are the small kernel's
     if (variant == 0) {
         const long wgs = (long)B * ((R + 255) / 256) * ((N + 255) / 256);
         // tools/sweep_bwd.py: the 256-wide tiles pay off only when the image is wider than 128

@@ -303,6 +303,125 @@ splat_fwd_mfma_regs(int B, int N, int R, const float* __restrict__ rays, const f
             store_block(img, R, i0 + 32 * mi, j0 + 32 * mj, lr, lh, TWO_LEVEL ? tot[mi][mj] : acc[mi][mj]);
 }
 
+// Few images, many heliostats (one sun over a whole plant: B·(R/64)² workgroups of the kernel above do not
+// fill the chip, and each walks all N rays alone — 30 ns a ray, 150 µs at N = 5000 whatever B is).  Here a
+// workgroup owns ONE 32×32 block and its KP waves SPLIT THE HELIOSTAT SUM.  The sum is always cut into
+// KSPLIT_PARTS = 16 parts of `per` consecutive rays, each accumulated from zero; a wave takes 16 / KP of
+// them (one accumulator each), and the 16 partial blocks meet in LDS at the end and are added in part
+// order — so the bits do not depend on KP, i.e. not on how many images the call renders (a shard of a
+// batch gives the rows the whole batch would: doodle_amd/sharded.py).  A part's rays are staged 64 at a
+// time — one ray per lane, pre-scaled as above — in a buffer of LDS private to the wave, double-buffered
+// (the next 64 are requested before the current 64 are consumed; a wave's LDS operations are ordered, so
+// there is no workgroup barrier in the loop).  B·(R/32)² workgroups × KP waves: 16× the waves of the kernel
+// above at KP = 16.
+constexpr int KSPLIT_PARTS = 16;
+
+template <int KP>
+__global__ void __launch_bounds__(64 * KP)
+splat_fwd_block_ksplit(int N, int R, const float* __restrict__ rays, const float* __restrict__ xs,
+                       const float* __restrict__ ys, float* __restrict__ image) {
+    constexpr int PW = KSPLIT_PARTS / KP;              // parts per wave
+    // ray buffers [KP][2][64 + 4] float4 during the sum; afterwards the same space holds the partial blocks,
+    // 8 of the 16 accumulator registers at a time: [16 parts][8][64] floats (35 KB at KP = 16)
+    constexpr int RAY_FLOATS = KP * 2 * 68 * 4, RED_FLOATS = KSPLIT_PARTS * 8 * 64;
+    __shared__ __attribute__((aligned(16))) float smem[RAY_FLOATS > RED_FLOATS ? RAY_FLOATS : RED_FLOATS];
+    const int b = blockIdx.z, i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 31, lh = lane >> 5;
+    const float xv = xs[min(i0 + lr, R - 1)], yv = ys[min(j0 + lr, R - 1)];
+
+    const int per = (((N + KSPLIT_PARTS - 1) / KSPLIT_PARTS) + 3) & ~3;
+    const float4* __restrict__ rb = reinterpret_cast<const float4*>(rays) + (long)b * N;
+    // (clamped, unconditional loads: "in range ? load : pad" becomes a branch around the load)
+    auto fetch = [&](int base) { return rb[min(base + lane, N - 1)]; };
+
+    f32x16 acc[PW];
+    int buf = 0;
+#pragma unroll
+    for (int pw = 0; pw < PW; ++pw) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[pw][e] = 0.0f;
+        const int part = wave * PW + pw;
+        const int n_begin = min(N, per * part), n_end = min(N, n_begin + per);
+        float4 nxt = fetch(n_begin);
+        for (int base = n_begin; base < n_end; base += 64, buf ^= 1) {
+            float4* __restrict__ tab = reinterpret_cast<float4*>(smem) + (wave * 2 + buf) * 68;
+            {
+                const float sk = __builtin_sqrtf(nxt.z);
+                // a ray past this part: √k2 = 0, cc = 1e30 → A = exp2(-1e30) = 0 exactly, E = 1
+                tab[lane] = base + lane < n_end ? make_float4(nxt.x * sk, nxt.y * sk, sk, nxt.w * nxt.z)
+                                                : make_float4(0.f, 0.f, 0.f, 1e30f);
+            }
+            if (lane < 4) tab[64 + lane] = make_float4(0.f, 0.f, 0.f, 1e30f);   // what the look-ahead reads past the end
+            if (base + 64 < n_end) nxt = fetch(base + 64);                       // in flight during this chunk
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const int cnt = min(64, n_end - base);
+            float4 q0 = tab[lh], q1 = tab[2 + lh];
+            for (int k = 0; k < cnt; k += 4) {
+                const float4 p0 = q0, p1 = q1;
+                q0 = tab[k + 4 + lh];
+                q1 = tab[k + 6 + lh];
+                const float t0 = __builtin_fmaf(xv, p0.z, p0.x), t1 = __builtin_fmaf(xv, p1.z, p1.x);
+                const float u0 = __builtin_fmaf(yv, p0.z, p0.y), u1 = __builtin_fmaf(yv, p1.z, p1.y);
+                const float fa0 = exp2_fast(-__builtin_fmaf(t0, t0, p0.w)), fa1 = exp2_fast(-__builtin_fmaf(t1, t1, p1.w));
+                const float fe0 = exp2_fast(-(u0 * u0)), fe1 = exp2_fast(-(u1 * u1));
+                acc[pw] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0, fe0, acc[pw], 0, 0, 0);
+                acc[pw] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1, fe1, acc[pw], 0, 0, 0);
+            }
+            __builtin_amdgcn_wave_barrier();   // the other buffer is rewritten only after every lane has left this chunk
+        }
+    }
+
+    // element (e, l) of the block: row (e&3) + 8(e>>2) + 4(l>>5), column l&31 (the MFMA's C/D map); thread t
+    // adds the 16 partials of elements t, t + 64·KP, … in part order — lanes ↔ consecutive columns
+    float* __restrict__ img = image + (long)b * R * R;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        __syncthreads();                       // every wave has left its ray buffers / the previous half is summed
+#pragma unroll
+        for (int pw = 0; pw < PW; ++pw)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) smem[((wave * PW + pw) * 8 + e) * 64 + lane] = acc[pw][8 * half + e];
+        __syncthreads();
+        for (int idx = tid; idx < 512; idx += 64 * KP) {
+            const int e8 = idx >> 6, l = idx & 63, e = 8 * half + e8;
+            float v = smem[e8 * 64 + l];
+#pragma unroll
+            for (int p = 1; p < KSPLIT_PARTS; ++p) v += smem[(p * 8 + e8) * 64 + l];
+            const int i = i0 + (e & 3) + 8 * (e >> 2) + 4 * (l >> 5), j = j0 + (l & 31);
+            if (i < R && j < R) img[(long)i * R + j] = v;
+        }
+    }
+}
+
+// the shapes it serves: more heliostats than the single-launch kernel's table holds, and so few 64×64 tiles
+// that the register-operand kernel would leave most of the chip idle; → waves per workgroup (0: not this kernel)
+static int ksplit_parts(int B, int N, int R) {
+    static const int forced = [] { const char* e = getenv("HELIO_KSPLIT"); return e ? atoi(e) : -1; }();
+    if (forced == 0) return 0;
+    const long blocks = (long)B * ((R + 31) / 32) * ((R + 31) / 32);
+    if (N < 128) return 0;
+    // tools/sweep_ksplit.py: with 16 or 8 waves a block (≈ 4096 waves on the chip) it wins wherever the sum is
+    // longer than the single-launch kernel's table; with 4 waves it is the 64² kernel's equal — ahead by
+    // 5–15 % from N = 1000 (shorter ray loops per wave), behind by 10 % at N = 300 (the LDS reduce)
+    if (blocks <= 512) { const int kp = blocks <= 256 ? 16 : 8; return N >= 32 * kp ? kp : 4; }
+    return (blocks <= 2048 && N >= 1000) ? 4 : 0;
+}
+
+static bool launch_ksplit(int B, int N, int R, const float* rays, const float* xs, const float* ys, float* image,
+                          int kp, hipStream_t st) {
+    const int t = (R + 31) / 32;
+    if (t > 65535 || B > 65535) return false;
+    const dim3 grid(t, t, B);
+    if (kp == 16) hipLaunchKernelGGL(splat_fwd_block_ksplit<16>, grid, dim3(1024), 0, st, N, R, rays, xs, ys, image);
+    else if (kp == 8) hipLaunchKernelGGL(splat_fwd_block_ksplit<8>, grid, dim3(512), 0, st, N, R, rays, xs, ys, image);
+    else if (kp == 4) hipLaunchKernelGGL(splat_fwd_block_ksplit<4>, grid, dim3(256), 0, st, N, R, rays, xs, ys, image);
+    else return false;
+    return true;
+}
+
 // Operands through LDS.  Workgroup = W×W waves of 64×64 pixels (W = 2: 256 threads, 128×128
 // tile, two-level sums, two workgroups per CU; W = 4: 1024 threads, 256×256 tile, one level,
 // one workgroup per CU).  Per chunk of 64 rays:
@@ -1302,20 +1421,42 @@ static void launch_bf16x3(int B, int N, int R, const float* rays, const float* x
 // variant: 0/2 = MFMA, kernel chosen by problem size; 1 = VALU; 3/4/5/6 force one MFMA kernel
 // (regs 128², tile 128², tile 256², regs 64²) — used by the tests and tools/bench_splat.py.
 // (tile 128² is never the fastest in the sweep; it stays as a forced variant for A/B runs.)
+// the kernel variant 0 stands for at this size (a forced variant gives the same bits for ANY number of
+// images: every kernel sums an image's heliostats in an order that depends on N and R only)
+static int splat_fwd_choice(int B, int N, int R) {
+    const long t128 = (long)B * ((R + 127) / 128) * ((R + 127) / 128);
+    const long t256 = (long)B * ((R + 255) / 256) * ((R + 255) / 256);
+    // measured on MI355X over B ∈ {4..256}, N ∈ {50, 500, 5000}, R ∈ {64..512}
+    // (tools/sweep_variants.py, tools/sweep_render.py): the 256² LDS-table kernel wins once its tiles fill
+    // the 256 CUs and the heliostat sum is long enough to amortise its 64-ray chunks; the 128²
+    // register-operand kernel once ITS tiles fill the chip; below that, 32² blocks with the heliostat sum
+    // split over the waves of a workgroup where it is long, else 64² tiles.
+    if (N >= 200 && R > 128 && t256 >= 192) return 5;
+    if (t128 >= 192 && R > 64) return 3;
+    return ksplit_parts(B, N, R) ? 9 : 6;
+}
+
+// What helio_render_fwd's variant 0 resolves to for (B, N, R): 10..13 (a form of the single-launch kernel)
+// or 3, 5, 6, 9 (geometry + that splat kernel).  A caller that renders a batch in pieces — one shard per
+// GPU — passes the choice of the WHOLE batch with every piece and gets the rows of the unsharded render
+// bit for bit.  (The few-ray form assumes 16-byte aligned images, as torch's allocations are.)
+int render_fwd_choice(int B, int N, int R) {
+    if (render_is_fused(B, N, R)) {
+        const int f = resolve_fused_form(0, B, N, R, N <= FEW_MAX_RAYS && (R & 3) == 0);
+        return f == 8 ? 13 : f == 4 ? 12 : f == 2 ? 11 : 10;
+    }
+    return splat_fwd_choice(B, N, R);
+}
+
 int launch_splat_fwd(int B, int N, int R, const float* rays, const float* xs, const float* ys,
                      float* image, int variant, hipStream_t st) {
     const long t128 = (long)B * ((R + 127) / 128) * ((R + 127) / 128);
-    const long t256 = (long)B * ((R + 255) / 256) * ((R + 255) / 256);
-    if (variant == 0 || variant == 2) {
-        // measured on MI355X over B ∈ {4..256}, N ∈ {50, 500, 5000}, R ∈ {64..512}
-        // (tools/sweep_variants.py): the 256² LDS-table kernel wins once its tiles fill the 256 CUs
-        // and the heliostat sum is long enough to amortise its 64-ray chunks; the 128²
-        // register-operand kernel once ITS tiles fill the chip; below that, 64² tiles.
-        if (N >= 200 && R > 128 && t256 >= 192) variant = 5;
-        else if (t128 >= 192 && R > 64) variant = 3;
-        else variant = 6;
-    }
+    if (variant == 0 || variant == 2) variant = splat_fwd_choice(B, N, R);
     switch (variant) {
+    case 9: {       // the k-split block kernel; forced: 16 waves where the rule would not choose it
+        const int kp = ksplit_parts(B, N, R);
+        return launch_ksplit(B, N, R, rays, xs, ys, image, kp ? kp : (N >= 512 ? 16 : 4), st) ? HELIO_OK : HELIO_E_INVALID;
+    }
     case 1:
         if (t128 < 512) {
             const int t = (R + 63) / 64;

@@ -346,17 +346,31 @@ class HelioField:
         normals = act.reshape(B, N, 3).contiguous()
         trig, stride = self._select_trig(global_batch, row_offset, B)
 
-        if torch.is_grad_enabled() and normals.requires_grad:
-            node = getattr(_get_ops(), "render_node", None)
-            out = node(self, sun, normals, trig, stride) if node is not None else None
-            # (the same node as a C++ autograd Function when the compiled binding is built)
-            images, actual, refl = out if out is not None else _Render.apply(normals, self, sun, trig, stride)
-        else:
-            # no autograd: the ray work buffer is scratch, reuse it between calls
-            ws = self._ray_ws
-            if ws is None or ws.shape[0] != B or ws.device != normals.device:
-                ws = self._ray_ws = torch.empty((B, N, native.RAY_STRIDE), dtype=torch.float32, device=normals.device)
-            images, actual, refl, _ = _get_ops().render_fwd(
-                self.heliostat_positions, sun, normals, trig, stride, self._plane, self._xs, self._ys,
-                want_refl=monitor, rays=ws)
+        # a piece of a larger batch is rendered by the kernel the WHOLE batch would get (the size rules look at
+        # B; every kernel's summation order depends on N and R only): the rows of the unsharded render, bit
+        # for bit, whatever the shard size
+        ops = _get_ops()
+        forced = 0
+        if global_batch != B and getattr(ops, "splat_variant", 0) == 0:
+            choose = getattr(ops, "render_choice", None)
+            forced = choose(global_batch, N, self.resolution) if choose is not None else 0
+        if forced:
+            object.__setattr__(ops, "splat_variant", forced)      # (no context is built while it is set)
+        try:
+            if torch.is_grad_enabled() and normals.requires_grad:
+                node = getattr(ops, "render_node", None)
+                out = node(self, sun, normals, trig, stride) if node is not None else None
+                # (the same node as a C++ autograd Function when the compiled binding is built)
+                images, actual, refl = out if out is not None else _Render.apply(normals, self, sun, trig, stride)
+            else:
+                # no autograd: the ray work buffer is scratch, reuse it between calls
+                ws = self._ray_ws
+                if ws is None or ws.shape[0] != B or ws.device != normals.device:
+                    ws = self._ray_ws = torch.empty((B, N, native.RAY_STRIDE), dtype=torch.float32, device=normals.device)
+                images, actual, refl, _ = ops.render_fwd(
+                    self.heliostat_positions, sun, normals, trig, stride, self._plane, self._xs, self._ys,
+                    want_refl=monitor, rays=ws)
+        finally:
+            if forced:
+                object.__setattr__(ops, "splat_variant", 0)
         return images, actual, (refl.view(-1, 3) if refl is not None else None)

@@ -23,7 +23,7 @@ EXPORTS = (
     "helio_splat_fwd", "helio_render_fwd", "helio_render_bwd", "helio_render_fwd_launches", "helio_splat_bwd_blocks", "helio_splat_bwd", "helio_geometry_bwd",
     "helio_ideal_normals", "helio_init_actions", "helio_step_losses_workspace", "helio_step_losses_fwd", "helio_step_losses_bwd",
     "helio_distance_maps_workspace", "helio_distance_maps",
-    "helio_env_step_workspace", "helio_env_step_launches", "helio_env_step_fwd",
+    "helio_env_step_workspace", "helio_env_step_launches", "helio_render_fwd_choice", "helio_env_step_fwd",
     "helio_notify_create", "helio_notify_destroy", "helio_notify_wait",
     "helio_env_step_bwd_image_ws", "helio_env_step_bwd",
 )
@@ -74,6 +74,7 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
         "helio_step_losses_bwd": (_i, [_i, _i, _i] + [_vp] * 8 + [_f3, _f3, _f, _f, _i] + [_vp] * 5 + [_vp] * 3 + [_vp]),
         "helio_env_step_workspace": (_l, [_i, _i, _i]),
         "helio_env_step_launches": (_i, [_i, _i, _i]),
+        "helio_render_fwd_choice": (_i, [_i, _i, _i]),
         "helio_env_step_fwd": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _l, pp, _vp, _vp, _vp, _vp, _vp, _vp, _i]
                                + [_vp] * 4 + [_f3, _f3, _f, _f, _i, _f] + [_vp] * 7 + [_vp, _i, _vp]),
         "helio_env_step_bwd_image_ws": (_i, [_i, _i, _i]),
@@ -198,6 +199,11 @@ class HipOps:
             _dev(xs), _dev(ys), actual.data_ptr(), refl.data_ptr() if want_refl else None,
             rays.data_ptr(), image.data_ptr(), self.splat_variant, _stream()))
         return image, actual, refl, rays
+
+    def render_choice(self, B, N, R):
+        """The variant ``helio_render_fwd``'s 0 resolves to at (B, N, R) (``helio_render_fwd_choice``): what a
+        shard of a batch of B suns forces so that it reproduces the unsharded render's rows bit for bit."""
+        return int(self.lib.helio_render_fwd_choice(int(B), int(N), int(R)))
 
     def render_context(self, field, trig, trig_b_stride):
         """A compiled render context of ``field`` for the trig table ``trig`` (csrc/hostbind.cpp

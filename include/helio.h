@@ -100,6 +100,10 @@ int helio_geometry_fwd(int B, int N,
  * image dim0 runs along plane_u, dim1 along plane_v.
  * variant: 0 or 2 = f32 MFMA (kernel chosen by problem size), 1 = VALU LDS-tiled;
  * 3..6 force one MFMA kernel (regs 128x128, LDS-tile 128x128, LDS-tile 256x256, regs 64x64);
+ * 9 = the k-split block kernel (one 32x32 block per workgroup, its 4 / 8 / 16 waves split the heliostat
+ * sum and add their partial blocks in wave order): what 0 chooses for few images of many heliostats
+ * (B*(R/32)^2 <= 512 blocks and N >= 128, or <= 2048 blocks and N >= 1000 — one sun over a whole plant;
+ * HELIO_KSPLIT=0 switches it off);
  * 7, 8 = the split-bf16 kernels (opt-in, never chosen by 0/2): every f32 factor split exactly
  * into three bf16 pieces, six partial products per product on the bf16 matrix pipe, f32
  * accumulation; the dropped partial products are below 2^-23 of each product.  7 sums in two
@@ -131,6 +135,15 @@ int helio_render_fwd(int B, int N, int R,
 
 /* Kernel launches helio_render_fwd(variant 0) issues for this size: 1 (fused) or 2. */
 int helio_render_fwd_launches(int B, int N, int R);
+
+/*
+ * The variant that helio_render_fwd's variant 0 resolves to at (B, N, R): 10..13 (a form of the
+ * single-launch kernel) or 3, 5, 6, 9 (geometry + that splat kernel); 0 for invalid sizes.  Every
+ * kernel sums an image's heliostats in an order that depends on N and R only, so a caller that
+ * renders a batch in pieces (one shard of the sun batch per GPU) passes the choice
+ * of the WHOLE batch with every piece and gets the rows of the unsharded render bit for bit.
+ */
+int helio_render_fwd_choice(int B, int N, int R);
 
 /* Column blocks the backward splat splits an R-wide image into (the size of the
  * second dimension of moments_d). */
@@ -176,6 +189,11 @@ int helio_geometry_bwd(int B, int N, int n_blocks,
  * The whole backward of HelioField.render in one call: helio_splat_bwd (skipped when
  * grad_image_d is NULL) followed by helio_geometry_bwd on the same stream.  moments_d is the
  * [B, helio_splat_bwd_blocks(R), N, 5] work buffer; any cotangent may be NULL.
+ * variant: helio_splat_bwd's, plus 8 = moments AND geometry adjoint in ONE launch (a workgroup owns
+ * 32 rays of a sun completely, the moments stay in LDS; R <= 256) — what 0 chooses for small,
+ * latency-bound problems (B * ceil(N/32) <= 64 workgroups in the small-tile kernel's regime;
+ * HELIO_BWD_FUSED=0 switches the choice off).  moments_d is not written in that form.
+ * helio_env_step_bwd takes the same variants.
  */
 int helio_render_bwd(int B, int N, int R,
                      const float *helios_d, const float *sun_d, const float *action_d,

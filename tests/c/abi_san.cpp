@@ -115,6 +115,8 @@ int main() {
     EXPECT_INVALID(helio_render_fwd(512, 2000, 512, P, P, P, P, 8000, &plane, P, P, P, P, nullptr, P, 0, nullptr));
     EXPECT_LAUNCH(helio_render_fwd(512, 2000, 512, P, P, P, P, 8000, &plane, P, P, P, P, P, P, 0, nullptr));
     if (helio_render_fwd_launches(B, N, R) != 1 || helio_render_fwd_launches(512, 2000, 512) != 2) { printf("FAIL launches\n"); ++failures; }
+    if (helio_render_fwd_choice(B, N, R) != 12 || helio_render_fwd_choice(512, 2000, 512) != 6 || helio_render_fwd_choice(0, N, R) != 0 ||
+        helio_render_fwd_choice(B, N, 0) != 0) { printf("FAIL choice\n"); ++failures; }
 
     // ---- helio_splat_bwd / helio_geometry_bwd / helio_render_bwd
     EXPECT_INVALID(helio_splat_bwd(B, N, 0, P, P, P, P, P, 0, nullptr));
