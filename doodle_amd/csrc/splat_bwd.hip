@@ -156,8 +156,8 @@ typedef __attribute__((address_space(3))) const float lds_cf;
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-template <int PASS, bool VEC>
-__global__ void __launch_bounds__(1024)
+template <int PASS, bool VEC, int WC = 4>
+__global__ void __launch_bounds__(256 * WC)
 splat_bwd_mfma(int B, int N, int R, const float* __restrict__ rays, const float* __restrict__ xs,
                const float* __restrict__ ys, const float* __restrict__ gimg, float* __restrict__ moments) {
     static_assert(!(VEC && PASS == 1), "16-byte staging is pass 0's");
@@ -165,32 +165,38 @@ splat_bwd_mfma(int B, int N, int R, const float* __restrict__ rays, const float*
     // an odd pitch keeps that conflict-free.  Pass 0 writes it along c and stages it 16 bytes at a time
     // (global_load_dwordx4 + ds_write_b128 where R % 4 == 0): a pitch that is a multiple of 4 keeps
     // every row 16-byte aligned; reads (lanes ↔ consecutive c or rays) are conflict-free either way.
-    constexpr int KC = 64, T = 256, LD = PASS == 0 ? T + 4 : T + 1;
-    extern __shared__ __attribute__((aligned(16))) float smem[];   // sG[KC][LD] sF[KC][LD] ccoord[T]
-    float* __restrict__ sCc = smem + 2 * KC * LD;
+    // WC = rows of 64-wide waves along c: 4 → the 256 c × 256 rays tile, 16 waves (images wider than 128);
+    // 2 → 128 c × 256 rays, 8 waves, for images of at most 128 pixels across, where half of a 256-wide tile
+    // would be padding (R = 128, the reference's default resolution: 0.37 → of the peak with either the padded
+    // tile or the small-tile kernel).  The ray extent stays 256: the factor table costs exps per (k, ray),
+    // the slab only loads, so the narrow side is the slab's.
+    constexpr int KC = 64, T = 256, TC = 64 * WC, NT = 256 * WC, KPT = KC / WC;
+    constexpr int LDG = PASS == 0 ? TC + 4 : TC + 1, LD = PASS == 0 ? T + 4 : T + 1;
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // sG[KC][LDG] sF[KC][LD] ccoord[TC]
+    float* __restrict__ sCc = smem + KC * (LDG + LD);
 
-    const int c_tiles = (R + T - 1) / T;
+    const int c_tiles = (R + TC - 1) / TC;
     const int b = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // scalar: nothing of it is kept in (or spilled from) VGPRs
     const int lr = lane & 31, lh = lane >> 5;
-    const int c0 = (blockIdx.x % c_tiles) * T, n0 = (blockIdx.x / c_tiles) * T;
+    const int c0 = (blockIdx.x % c_tiles) * TC, n0 = (blockIdx.x / c_tiles) * T;
     const int wc = (wave >> 2) * 64, wn = (wave & 3) * 64;
     const float* __restrict__ ccoord = PASS == 0 ? ys : xs;   // coordinates along c
     const float* __restrict__ kcoord = PASS == 0 ? xs : ys;   // coordinates along k
     const float* __restrict__ G = gimg + (long)b * R * R;
 
-    if (tid < T) sCc[tid] = ccoord[min(c0 + tid, R - 1)];
+    if (tid < TC) sCc[tid] = ccoord[min(c0 + tid, R - 1)];
 
-    // producer role for the factor table: ray (wave&3)*64 + lane of the tile, 16 k of every chunk
+    // producer role for the factor table: ray (wave&3)*64 + lane of the tile, KPT = 64 / WC k of every chunk
     const int pr = wn + lane;
-    const int pk0 = (wave >> 2) * 16;
+    const int pk0 = (wave >> 2) * KPT;
     float4 q = make_float4(0.f, 0.f, 1.f, 1e30f);
     if (n0 + pr < N) q = reinterpret_cast<const float4*>(rays)[(long)b * N + n0 + pr];
     const float sk = __builtin_sqrtf(q.z);
     const float fshift = (PASS == 0 ? q.x : q.y) * sk;
     const float fcc = PASS == 0 ? q.w * q.z : 0.0f;
-    lds_f* fdst = (lds_f*)smem + KC * LD + pk0 * LD + pr;
+    lds_f* fdst = (lds_f*)smem + KC * LDG + pk0 * LD + pr;
 
     // loader role for the grad-image slab Gm[k][c]: 16 dwords per thread and chunk.
     //   pass 0: Gm[k][c] = G[k0+k][c0+c].  R % 4 == 0 (uniform): four 16-byte pieces per thread, piece
@@ -202,8 +208,8 @@ splat_bwd_mfma(int B, int N, int R, const float* __restrict__ rays, const float*
         if constexpr (VEC) {
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
-                const int p = tid + 1024 * v;
-                const int row = k0 + (p >> 6), col = c0 + 4 * (p & 63);
+                const int p = tid + NT * v;
+                const int row = k0 + p / (TC / 4), col = c0 + 4 * (p % (TC / 4));
                 float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (row < R && col < R) t = *reinterpret_cast<const float4*>(G + (long)row * R + col);
                 gv[4 * v] = t.x; gv[4 * v + 1] = t.y; gv[4 * v + 2] = t.z; gv[4 * v + 3] = t.w;
@@ -211,8 +217,8 @@ splat_bwd_mfma(int B, int N, int R, const float* __restrict__ rays, const float*
         } else {
 #pragma unroll
             for (int v = 0; v < 16; ++v) {
-                const int idx = tid + 1024 * v;
-                const int k = PASS == 0 ? idx >> 8 : idx & 63, c = PASS == 0 ? idx & 255 : idx >> 6;
+                const int idx = tid + NT * v;
+                const int k = PASS == 0 ? idx / TC : idx & 63, c = PASS == 0 ? idx % TC : idx >> 6;
                 const int row = PASS == 0 ? k0 + k : c0 + c, col = PASS == 0 ? c0 + c : k0 + k;
                 gv[v] = (row < R && col < R) ? G[(long)row * R + col] : 0.0f;
             }
@@ -222,17 +228,17 @@ splat_bwd_mfma(int B, int N, int R, const float* __restrict__ rays, const float*
         if constexpr (VEC) {
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
-                const int p = tid + 1024 * v;
-                *reinterpret_cast<float4*>(smem + (p >> 6) * LD + 4 * (p & 63)) =
+                const int p = tid + NT * v;
+                *reinterpret_cast<float4*>(smem + (p / (TC / 4)) * LDG + 4 * (p % (TC / 4))) =
                     make_float4(gv[4 * v], gv[4 * v + 1], gv[4 * v + 2], gv[4 * v + 3]);
             }
         } else {
             lds_f* dst = (lds_f*)smem;
 #pragma unroll
             for (int v = 0; v < 16; ++v) {
-                const int idx = tid + 1024 * v;
-                const int k = PASS == 0 ? idx >> 8 : idx & 63, c = PASS == 0 ? idx & 255 : idx >> 6;
-                dst[k * LD + c] = gv[v];
+                const int idx = tid + NT * v;
+                const int k = PASS == 0 ? idx / TC : idx & 63, c = PASS == 0 ? idx % TC : idx >> 6;
+                dst[k * LDG + c] = gv[v];
             }
         }
     };
@@ -244,8 +250,8 @@ splat_bwd_mfma(int B, int N, int R, const float* __restrict__ rays, const float*
         for (int e = 0; e < 16; ++e) acc[m][e] = 0.0f;
 
     // consumer: A operand = Gm[k = 2kp + lh][c = wc + 32·blk + lr], B operand = F[k][ray = wn + 32·blk + lr]
-    lds_cf* pg = (lds_cf*)smem + lh * LD + wc + lr;
-    lds_cf* pf = (lds_cf*)smem + KC * LD + lh * LD + wn + lr;
+    lds_cf* pg = (lds_cf*)smem + lh * LDG + wc + lr;
+    lds_cf* pf = (lds_cf*)smem + KC * LDG + lh * LD + wn + lr;
     lds_cf* pg1 = pg + 32;
     lds_cf* pf1 = pf + 32;
     asm volatile("" : "+v"(pg));
@@ -263,15 +269,15 @@ splat_bwd_mfma(int B, int N, int R, const float* __restrict__ rays, const float*
     // LDS staging (and one barrier fewer per chunk)
     load_slab(0);
     for (int k0 = 0; k0 < R; k0 += KC) {
-        float kc[16];
+        float kc[KPT];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) kc[j] = kcoord[min(k0 + pk0 + j, R - 1)];
+        for (int j = 0; j < KPT; ++j) kc[j] = kcoord[min(k0 + pk0 + j, R - 1)];
         __syncthreads();                                   // previous chunk consumed
         store_slab();
         if (k0 + KC < R) load_slab(k0 + KC);               // in flight during the chunk
         if constexpr (!VEC) {       // (the packed form below costs these two instantiations a spilled register)
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
+            for (int j = 0; j < KPT; ++j) {
                 const float t = __builtin_fmaf(kc[j], sk, fshift);
                 float f = __builtin_amdgcn_exp2f(-__builtin_fmaf(t, t, fcc));
                 if (k0 + pk0 + j >= R) f = 0.0f;           // rows/cols past the image contract nothing
@@ -282,7 +288,7 @@ splat_bwd_mfma(int B, int N, int R, const float* __restrict__ rays, const float*
             // IEEE fma per component; producer instructions are MFMA time on this chip)
             const f32x2 sk2 = {sk, sk}, sh2 = {fshift, fshift}, cc2 = {fcc, fcc};
 #pragma unroll
-            for (int j = 0; j < 16; j += 2) {
+            for (int j = 0; j < KPT; j += 2) {
                 const f32x2 kc2 = {kc[j], kc[j + 1]};
                 const f32x2 t = __builtin_elementwise_fma(kc2, sk2, sh2);
                 const f32x2 a = __builtin_elementwise_fma(t, t, cc2);
@@ -296,7 +302,7 @@ splat_bwd_mfma(int B, int N, int R, const float* __restrict__ rays, const float*
         __syncthreads();
 #pragma unroll
         for (int kp = 0; kp < KC / 2; ++kp) {
-            const float g0 = pg[kp * 2 * LD], g1 = pg1[kp * 2 * LD];
+            const float g0 = pg[kp * 2 * LDG], g1 = pg1[kp * 2 * LDG];
             const float f0 = pf[kp * 2 * LD], f1 = pf1[kp * 2 * LD];
             acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(g0, f0, acc[0], 0, 0, 0);
             acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(g0, f1, acc[1], 0, 0, 0);
@@ -652,30 +658,35 @@ static int bwd_small_ks(int B, int N, int R) {
     return (wgs * 8 <= 1536 && R >= 64) ? 8 : 4;
 }
 
-template <int PASS, bool VEC>
+template <int PASS, bool VEC, int WC>
 static void launch_bwd_mfma_v(int B, int N, int R, const float* rays, const float* xs, const float* ys,
                               const float* gimg, float* moments, hipStream_t st) {
-    const size_t lds = (2 * 64 * (PASS == 0 ? 260 : 257) + 256 + 64) * sizeof(float);
+    constexpr int TC = 64 * WC;
+    const size_t lds = (64 * ((PASS == 0 ? TC + 4 : TC + 1) + (PASS == 0 ? 260 : 257)) + TC + 64) * sizeof(float);
     static bool configured = false;
     if (!configured) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(splat_bwd_mfma<PASS, VEC>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(splat_bwd_mfma<PASS, VEC, WC>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         configured = true;
     }
-    const int ct = (R + 255) / 256, nt = (N + 255) / 256;
-    hipLaunchKernelGGL((splat_bwd_mfma<PASS, VEC>), dim3(ct * nt, B), dim3(1024), lds, st, B, N, R, rays, xs, ys, gimg, moments);
+    const int ct = (R + TC - 1) / TC, nt = (N + 255) / 256;
+    hipLaunchKernelGGL((splat_bwd_mfma<PASS, VEC, WC>), dim3(ct * nt, B), dim3(256 * WC), lds, st, B, N, R, rays, xs, ys, gimg, moments);
 }
 
 template <int PASS>
 static void launch_bwd_mfma(int B, int N, int R, const float* rays, const float* xs, const float* ys,
                             const float* gimg, float* moments, hipStream_t st) {
+    const bool narrow = R <= 128;          // 128-wide c tiles: a 256-wide one would be at least half padding
     if constexpr (PASS == 0) {
         // 16-byte staging of the grad-image slab needs whole 4-pixel pieces per row (the image base is
         // 16-byte aligned by the ABI's contract)
-        if ((R & 3) == 0) return launch_bwd_mfma_v<0, true>(B, N, R, rays, xs, ys, gimg, moments, st);
-        return launch_bwd_mfma_v<0, false>(B, N, R, rays, xs, ys, gimg, moments, st);
+        if ((R & 3) == 0) return narrow ? launch_bwd_mfma_v<0, true, 2>(B, N, R, rays, xs, ys, gimg, moments, st)
+                                        : launch_bwd_mfma_v<0, true, 4>(B, N, R, rays, xs, ys, gimg, moments, st);
+        return narrow ? launch_bwd_mfma_v<0, false, 2>(B, N, R, rays, xs, ys, gimg, moments, st)
+                      : launch_bwd_mfma_v<0, false, 4>(B, N, R, rays, xs, ys, gimg, moments, st);
     } else {
-        return launch_bwd_mfma_v<1, false>(B, N, R, rays, xs, ys, gimg, moments, st);
+        return narrow ? launch_bwd_mfma_v<1, false, 2>(B, N, R, rays, xs, ys, gimg, moments, st)
+                      : launch_bwd_mfma_v<1, false, 4>(B, N, R, rays, xs, ys, gimg, moments, st);
     }
 }
 
@@ -1127,9 +1138,10 @@ int launch_splat_bwd(int B, int N, int R, const float* rays, const float* xs, co
     if (variant == 8) variant = 3;       // 8 is helio_render_bwd's single-launch form; its moments alone are the small kernel's
     if (variant == 0) {
         const long wgs = (long)B * ((R + 255) / 256) * ((N + 255) / 256);
-        // tools/sweep_bwd.py: the 256-wide tiles pay off only when the image is wider than 128
-        // pixels (at R = 128 half of every tile is padding) and there are enough of them
-        variant = splat_bwd_is_few(B, N) ? 4 : (R > 128 && N >= 96 && wgs >= 128) ? 2 : 3;
+        // tools/sweep_bwd.py, tools/sweep_bwd_mid.py: the LDS-tile kernels (256 rays × 256 c, or × 128 c
+        // for images of at most 128 pixels across) pay off once there are enough tiles; below 65 pixels
+        // even the narrow tile is half padding and the small-tile kernel is its equal
+        variant = splat_bwd_is_few(B, N) ? 4 : (R > 64 && N >= 96 && wgs >= 128) ? 2 : 3;
     }
     if (variant == 5) {
         launch_bwd_bf16x3<0>(B, N, R, rays, xs, ys, gimg, moments, st);
