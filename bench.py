@@ -7,8 +7,10 @@ A "step" is one ``HelioField.render`` forward over one batch of B synthetic sun 
 (B frames), inputs resident in HBM.  After the W warm-up steps a time-based preheat runs
 (``--preheat`` seconds of the same call, default 0.5 — disclosed in the line as ``preheat_s``):
 a fresh host path and a GPU coming out of idle run slow for their first ~0.1 s, and a K = 20
-sample is only ≈0.13 ms long.  Then EXACTLY K steps are timed between barrier + synchronize
-fences, MAX over ranks.
+sample is only ≈0.1 ms long.  Then EXACTLY K steps are timed between barrier + synchronize
+fences, MAX over ranks.  The process binds itself to the CPUs of its GPU's NUMA node first
+(doodle_amd/affinity.py — what ``numactl --cpunodebind`` would do; disclosed as
+``config.host_affinity``; the CPU baseline runs under the original mask).
 
 With N > 1 (``torch.distributed.run``, one rank per GPU) every rank renders its own B-row shard
 of a global batch of N·B suns (weak scaling).  The suns are independent, so the timed loop has no
