@@ -374,11 +374,15 @@ splat_bwd_mfma(int B, int N, int R, const float* __restrict__ rays, const float*
 // k in [k_begin, k_end) (even bounds), weighted by the other-axis factor and reduced over the block's 64 c
 // in registers → (m0, m1, m2) for the ray n0 + (lane & 31), complete in BOTH halves of the wave.
 // `sCc_wave`: 64 floats of LDS private to the wave.
-template <int PASS>
-__device__ __forceinline__ void small_wave_partial(int N, int R, const float* __restrict__ rays_b,
-                                                   const float* __restrict__ xs, const float* __restrict__ ys,
-                                                   const float* __restrict__ G, int c0, int n0, int k_begin, int k_end,
-                                                   float* __restrict__ sCc_wave, float& m0, float& m1, float& m2) {
+// NRB ray blocks of 32 share the wave's grad-image operands (one load of the 64 c × k slab feeds 2·NRB MFMAs
+// per k-pair): NRB = 1 where latency is everything, 2 or 4 where there are ray blocks enough to keep the
+// chip's workgroup slots full anyway — then the slab is fetched from L2 half / a quarter as often.
+// → m[rb][0..2] for the ray n0 + 32·rb + (lane & 31).
+template <int PASS, int NRB>
+__device__ __forceinline__ void small_wave_partial_n(int N, int R, const float* __restrict__ rays_b,
+                                                     const float* __restrict__ xs, const float* __restrict__ ys,
+                                                     const float* __restrict__ G, int c0, int n0, int k_begin, int k_end,
+                                                     float* __restrict__ sCc_wave, float (&m)[NRB][3]) {
     const int lane = threadIdx.x & 63;
     const int lr = lane & 31, lh = lane >> 5;
     const float* __restrict__ ccoord = PASS == 0 ? ys : xs;   // coordinates along c (the axis that survives)
@@ -386,13 +390,16 @@ __device__ __forceinline__ void small_wave_partial(int N, int R, const float* __
     // this lane's ray (B operand and epilogue) and its c coordinate: requested first, used only after the
     // first group of grad-image loads has been issued — every first touch of memory in a freshly launched
     // kernel costs ≈900 cycles, so none of them may wait for another
-    const int n = n0 + lr;
-    const float4 qraw = reinterpret_cast<const float4*>(rays_b)[min(n, N - 1)];
+    float4 qraw[NRB];
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb) qraw[rb] = reinterpret_cast<const float4*>(rays_b)[min(n0 + 32 * rb + lr, N - 1)];
     const float ccv = ccoord[min(c0 + lane, R - 1)];
 
-    f32x16 acc0, acc1;
+    f32x16 acc0[NRB], acc1[NRB];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) { acc0[e] = 0.0f; acc1[e] = 0.0f; }
+    for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { acc0[rb][e] = 0.0f; acc1[rb][e] = 0.0f; }
 
     const int ca = c0 + lr, cb = c0 + 32 + lr;                  // this lane's two c (A operands of the two blocks)
     const bool vec = PASS == 1 && (R & 3) == 0;                 // (uniform) pass 1 may read 16-byte row segments
@@ -448,66 +455,88 @@ __device__ __forceinline__ void small_wave_partial(int N, int R, const float* __
         }
         // (the ray's constants are derived HERE, behind the group's loads: computed in front of the loop
         // they would put the ray's own load latency in front of every other load)
-        float4 q = qraw;
-        asm volatile("" : "+v"(q.x), "+v"(q.y), "+v"(q.z), "+v"(q.w));
-        if (n >= N) q = make_float4(0.f, 0.f, 1.f, 1e30f);      // padding ray: factor = exp2(-1e30) = 0
-        const float sk = __builtin_sqrtf(q.z);
-        const float fshift = (PASS == 0 ? q.x : q.y) * sk;
-        const float fcc = PASS == 0 ? q.w * q.z : 0.0f;
-        float f[8];
+        float f[NRB][8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float t = __builtin_fmaf(kc[j], sk, fshift);
-            f[j] = (k0 + 2 * j + lh < k_end) ? __builtin_amdgcn_exp2f(-__builtin_fmaf(t, t, fcc)) : 0.0f;
+        for (int rb = 0; rb < NRB; ++rb) {
+            float4 q = qraw[rb];
+            asm volatile("" : "+v"(q.x), "+v"(q.y), "+v"(q.z), "+v"(q.w));
+            if (n0 + 32 * rb + lr >= N) q = make_float4(0.f, 0.f, 1.f, 1e30f);      // padding ray: factor = exp2(-1e30) = 0
+            const float sk = __builtin_sqrtf(q.z);
+            const float fshift = (PASS == 0 ? q.x : q.y) * sk;
+            const float fcc = PASS == 0 ? q.w * q.z : 0.0f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float t = __builtin_fmaf(kc[j], sk, fshift);
+                f[rb][j] = (k0 + 2 * j + lh < k_end) ? __builtin_amdgcn_exp2f(-__builtin_fmaf(t, t, fcc)) : 0.0f;
+            }
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) asm volatile("" :: "v"(f[j]));
+        for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) asm volatile("" :: "v"(f[rb][j]));
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             if (k0 + 2 * j >= k_end) break;
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[j], f[j], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(gb[j], f[j], acc1, 0, 0, 0);
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb) {
+                acc0[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[j], f[rb][j], acc0[rb], 0, 0, 0);
+                acc1[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(gb[j], f[rb][j], acc1[rb], 0, 0, 0);
+            }
         }
     }
 
     // epilogue: lane = ray (column lr), registers = 16 values of c per block; weight by the other-axis
     // factor and reduce over this wave's 64 c
-    const float hshift = PASS == 0 ? qraw.y : qraw.x;
-    const float hcc = PASS == 0 ? 0.0f : qraw.w;
-    const float hk = n < N ? qraw.z : 0.0f;
-    m0 = 0.f; m1 = 0.f; m2 = 0.f;
     sCc_wave[lane] = ccv;                                // wave-private: LDS is in order within a wave
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int blk = 0; blk < 2; ++blk)
+    for (int rb = 0; rb < NRB; ++rb) {
+        const float hshift = PASS == 0 ? qraw[rb].y : qraw[rb].x;
+        const float hcc = PASS == 0 ? 0.0f : qraw[rb].w;
+        const float hk = n0 + 32 * rb + lr < N ? qraw[rb].z : 0.0f;
+        float m0 = 0.f, m1 = 0.f, m2 = 0.f;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int cl = 32 * blk + (e & 3) + 8 * (e >> 2) + 4 * lh;
-            const float s = sCc_wave[cl] + hshift;
-            const float w = __builtin_amdgcn_exp2f(-(__builtin_fmaf(s, s, hcc) * hk)) * (blk == 0 ? acc0[e] : acc1[e]);
-            m0 += w;
-            m1 = __builtin_fmaf(s, w, m1);
-            m2 = __builtin_fmaf(s * s, w, m2);
-        }
-    m0 += __shfl_xor(m0, 32); m1 += __shfl_xor(m1, 32); m2 += __shfl_xor(m2, 32);
+        for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int cl = 32 * blk + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                const float s = sCc_wave[cl] + hshift;
+                const float w = __builtin_amdgcn_exp2f(-(__builtin_fmaf(s, s, hcc) * hk)) * (blk == 0 ? acc0[rb][e] : acc1[rb][e]);
+                m0 += w;
+                m1 = __builtin_fmaf(s, w, m1);
+                m2 = __builtin_fmaf(s * s, w, m2);
+            }
+        m[rb][0] = m0 + __shfl_xor(m0, 32); m[rb][1] = m1 + __shfl_xor(m1, 32); m[rb][2] = m2 + __shfl_xor(m2, 32);
+    }
 }
 
-template <int PASS, int KS>
+// (one ray block: what the latency-bound callers use)
+template <int PASS>
+__device__ __forceinline__ void small_wave_partial(int N, int R, const float* __restrict__ rays_b,
+                                                   const float* __restrict__ xs, const float* __restrict__ ys,
+                                                   const float* __restrict__ G, int c0, int n0, int k_begin, int k_end,
+                                                   float* __restrict__ sCc_wave, float& m0, float& m1, float& m2) {
+    float m[1][3];
+    small_wave_partial_n<PASS, 1>(N, R, rays_b, xs, ys, G, c0, n0, k_begin, k_end, sCc_wave, m);
+    m0 = m[0][0]; m1 = m[0][1]; m2 = m[0][2];
+}
+
+template <int PASS, int KS, int NRB>
 __device__ __forceinline__ void splat_bwd_small_body(int N, int R, const float* __restrict__ rays,
                                                      const float* __restrict__ xs, const float* __restrict__ ys,
                                                      const float* __restrict__ gimg, float* __restrict__ moments,
                                                      float* smem) {
     float* __restrict__ sCc = smem;                // [KS][64] c coordinates, one private copy per wave
-    float* __restrict__ sRed = smem + KS * 64;     // [KS][32 rays][3]
+    float* __restrict__ sRed = smem + KS * 64;     // [KS][32·NRB rays][3]
 
     const int JB = (R + 63) / 64;
     const int b = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 31, lh = lane >> 5;
-    const int c0 = (blockIdx.x % JB) * 64, n0 = (blockIdx.x / JB) * 32;
+    const int c0 = (blockIdx.x % JB) * 64, n0 = (blockIdx.x / JB) * 32 * NRB;
     const float* __restrict__ G = gimg + (long)b * R * R;
 
     // this wave's part of the contracted axis: k-pairs dealt evenly, in multiples of 2 (so that a wave
@@ -516,19 +545,22 @@ __device__ __forceinline__ void splat_bwd_small_body(int N, int R, const float* 
     const int per = (((pairs + KS - 1) / KS) + 1) & ~1;
     const int k_begin = min(R, 2 * per * wave), k_end = min(R, 2 * per * (wave + 1));
 
-    const int n = n0 + lr;
-    float m0, m1, m2;
-    small_wave_partial<PASS>(N, R, rays + 4l * b * N, xs, ys, G, c0, n0, k_begin, k_end, sCc + wave * 64, m0, m1, m2);
+    float m[NRB][3];
+    small_wave_partial_n<PASS, NRB>(N, R, rays + 4l * b * N, xs, ys, G, c0, n0, k_begin, k_end, sCc + wave * 64, m);
     if (lh == 0) {
-        float* r = sRed + (wave * 32 + lr) * 3;
-        r[0] = m0; r[1] = m1; r[2] = m2;
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb) {
+            float* r = sRed + (wave * 32 * NRB + 32 * rb + lr) * 3;
+            r[0] = m[rb][0]; r[1] = m[rb][1]; r[2] = m[rb][2];
+        }
     }
     __syncthreads();
-    if (tid < 32 && n < N) {                                       // fixed order over the KS k-parts
+    const int n = n0 + tid;
+    if (tid < 32 * NRB && n < N) {                                 // fixed order over the KS k-parts
         float t0 = 0.f, t1 = 0.f, t2 = 0.f;
 #pragma unroll
         for (int w = 0; w < KS; ++w) {
-            const float* r = sRed + (w * 32 + lr) * 3;
+            const float* r = sRed + (w * 32 * NRB + tid) * 3;
             if (w == 0) { t0 = r[0]; t1 = r[1]; t2 = r[2]; } else { t0 += r[0]; t1 += r[1]; t2 += r[2]; }
         }
         float* o = moments + (((long)b * JB + c0 / 64) * N + n) * HELIO_MOMENT_STRIDE;
@@ -537,13 +569,13 @@ __device__ __forceinline__ void splat_bwd_small_body(int N, int R, const float* 
     }
 }
 
-template <int KS>
+template <int KS, int NRB = 1>
 __global__ void __launch_bounds__(64 * KS)
 splat_bwd_mfma_small(int N, int R, const float* __restrict__ rays, const float* __restrict__ xs,
                      const float* __restrict__ ys, const float* __restrict__ gimg, float* __restrict__ moments) {
-    __shared__ float smem[KS * 64 + KS * 32 * 3];
-    if (blockIdx.z == 0) splat_bwd_small_body<0, KS>(N, R, rays, xs, ys, gimg, moments, smem);
-    else splat_bwd_small_body<1, KS>(N, R, rays, xs, ys, gimg, moments, smem);
+    __shared__ float smem[KS * 64 + KS * 32 * NRB * 3];
+    if (blockIdx.z == 0) splat_bwd_small_body<0, KS, NRB>(N, R, rays, xs, ys, gimg, moments, smem);
+    else splat_bwd_small_body<1, KS, NRB>(N, R, rays, xs, ys, gimg, moments, smem);
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -656,6 +688,16 @@ static int bwd_small_ks(int B, int N, int R) {
     if (forced == 4 || forced == 8) return forced;
     const long wgs = 2l * B * ((R + 63) / 64) * ((N + 31) / 32);
     return (wgs * 8 <= 1536 && R >= 64) ? 8 : 4;
+}
+
+// ray blocks per wave of the small backward kernel (1, 2 or 4); HELIO_BWD_NRB forces one — tuning runs only
+static int bwd_small_nrb(int B, int N, int R) {
+    static const int forced = [] { const char* e = getenv("HELIO_BWD_NRB"); return e ? atoi(e) : 0; }();
+    if (forced == 1 || forced == 2 || forced == 4) return forced;
+    // tools/sweep_bwd_nrb.py: two ray blocks per wave are 3–10 % ahead from N = 300 (B = 25: 36.5 → 35.3 µs at
+    // N = 1000, R = 128; 110.9 → 101.8 at R = 256), behind below (N = 100: 7.2 → 8.3 µs); four never pay
+    // (344 registers: one wave per SIMD).  Same sums per ray: the bits do not change.
+    return (N >= 300 && bwd_small_ks(B, N, R) == 4) ? 2 : 1;
 }
 
 template <int PASS, bool VEC, int WC>
@@ -1155,7 +1197,12 @@ int launch_splat_bwd(int B, int N, int R, const float* rays, const float* xs, co
     }
     if (variant == 3 || variant == 6 || variant == 7) {        // 6 / 7: the small kernel with 4 / 8 waves (tests, tuning)
         const int ct = (R + 63) / 64, nt = (N + 31) / 32;
-        if (variant == 7 || (variant == 3 && bwd_small_ks(B, N, R) == 8))
+        const int nrb = variant == 3 ? bwd_small_nrb(B, N, R) : 1;
+        if (nrb == 4)
+            hipLaunchKernelGGL((splat_bwd_mfma_small<4, 4>), dim3(ct * ((N + 127) / 128), B, 2), dim3(256), 0, st, N, R, rays, xs, ys, gimg, moments);
+        else if (nrb == 2)
+            hipLaunchKernelGGL((splat_bwd_mfma_small<4, 2>), dim3(ct * ((N + 63) / 64), B, 2), dim3(256), 0, st, N, R, rays, xs, ys, gimg, moments);
+        else if (variant == 7 || (variant == 3 && bwd_small_ks(B, N, R) == 8))
             hipLaunchKernelGGL(splat_bwd_mfma_small<8>, dim3(ct * nt, B, 2), dim3(512), 0, st, N, R, rays, xs, ys, gimg, moments);
         else
             hipLaunchKernelGGL(splat_bwd_mfma_small<4>, dim3(ct * nt, B, 2), dim3(256), 0, st, N, R, rays, xs, ys, gimg, moments);

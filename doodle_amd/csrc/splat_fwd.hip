@@ -403,11 +403,13 @@ static int ksplit_parts(int B, int N, int R) {
     if (forced == 0) return 0;
     const long blocks = (long)B * ((R + 31) / 32) * ((R + 31) / 32);
     if (N < 128) return 0;
-    // tools/sweep_ksplit.py: with 16 or 8 waves a block (≈ 4096 waves on the chip) it wins wherever the sum is
-    // longer than the single-launch kernel's table; with 4 waves it is the 64² kernel's equal — ahead by
-    // 5–15 % from N = 1000 (shorter ray loops per wave), behind by 10 % at N = 300 (the LDS reduce)
-    if (blocks <= 512) { const int kp = blocks <= 256 ? 16 : 8; return N >= 32 * kp ? kp : 4; }
-    return (blocks <= 2048 && N >= 1000) ? 4 : 0;
+    if (forced == 4 || forced == 8 || forced == 16) return forced;      // tuning runs
+    // tools/sweep_ksplit.py, tools/sweep_ksplit_kp.py: 16 waves a block are the best or within 3 % of it at
+    // every block count it was measured at (4 and 8 waves: 3–15 % behind); against the 64² and 128² tile
+    // kernels it wins up to 1024 blocks from N = 128 and up to 2048 blocks from N = 500 (5–25 %; at N = 300
+    // and 2048 blocks the 64² kernel is 10 % ahead: the LDS reduce), and loses to the 128² kernel at 4096
+    if (blocks <= 1024) return N >= 256 ? 16 : 8;
+    return (blocks <= 2048 && N >= 500) ? 16 : 0;
 }
 
 static bool launch_ksplit(int B, int N, int R, const float* rays, const float* xs, const float* ys, float* image,

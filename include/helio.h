@@ -102,7 +102,7 @@ int helio_geometry_fwd(int B, int N,
  * 3..6 force one MFMA kernel (regs 128x128, LDS-tile 128x128, LDS-tile 256x256, regs 64x64);
  * 9 = the k-split block kernel (one 32x32 block per workgroup, its 4 / 8 / 16 waves split the heliostat
  * sum and add their partial blocks in wave order): what 0 chooses for few images of many heliostats
- * (B*(R/32)^2 <= 512 blocks and N >= 128, or <= 2048 blocks and N >= 1000 — one sun over a whole plant;
+ * (B*(R/32)^2 <= 1024 blocks and N >= 128, or <= 2048 blocks and N >= 500 — one sun over a whole plant;
  * HELIO_KSPLIT=0 switches it off);
  * 7, 8 = the split-bf16 kernels (opt-in, never chosen by 0/2): every f32 factor split exactly
  * into three bf16 pieces, six partial products per product on the bf16 matrix pipe, f32
