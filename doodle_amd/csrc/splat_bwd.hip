@@ -523,59 +523,83 @@ __device__ __forceinline__ void small_wave_partial(int N, int R, const float* __
     m0 = m[0][0]; m1 = m[0][1]; m2 = m[0][2];
 }
 
-template <int PASS, int KS, int NRB>
+// A workgroup = KS × RBW waves: KS of them split the contracted axis of one (64 c, 32·NRB rays) block — the
+// latency-bound end: config 3 runs KS = 4, RBW = 1 —, RBW such groups sit side by side along the rays.  KS = 1
+// (no split, no LDS reduce: RBW independent waves) is the throughput end: every wave pays the epilogue — 32
+// exps and ≈400 vector instructions per ray block, PMC: more SIMD time than its MFMAs at KS = 4 — once per
+// R MFMAs instead of once per R / 4.
+template <int PASS, int KS, int NRB, int RBW>
 __device__ __forceinline__ void splat_bwd_small_body(int N, int R, const float* __restrict__ rays,
                                                      const float* __restrict__ xs, const float* __restrict__ ys,
                                                      const float* __restrict__ gimg, float* __restrict__ moments,
                                                      float* smem) {
-    float* __restrict__ sCc = smem;                // [KS][64] c coordinates, one private copy per wave
-    float* __restrict__ sRed = smem + KS * 64;     // [KS][32·NRB rays][3]
+    constexpr int NW = KS * RBW, RPG = 32 * NRB;      // waves per workgroup; rays per k-split group
+    float* __restrict__ sCc = smem;                // [NW][64] c coordinates, one private copy per wave
+    float* __restrict__ sRed = smem + NW * 64;     // [RBW][KS][RPG rays][3]
 
     const int JB = (R + 63) / 64;
     const int b = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kpart = wave % KS, grp = wave / KS;
     const int lr = lane & 31, lh = lane >> 5;
-    const int c0 = (blockIdx.x % JB) * 64, n0 = (blockIdx.x / JB) * 32 * NRB;
+    const int c0 = (blockIdx.x % JB) * 64, n0 = ((blockIdx.x / JB) * RBW + grp) * RPG;
     const float* __restrict__ G = gimg + (long)b * R * R;
 
     // this wave's part of the contracted axis: k-pairs dealt evenly, in multiples of 2 (so that a wave
     // starts at a multiple of 4: 16-byte row segments in pass 1)
     const int pairs = (R + 1) >> 1;
     const int per = (((pairs + KS - 1) / KS) + 1) & ~1;
-    const int k_begin = min(R, 2 * per * wave), k_end = min(R, 2 * per * (wave + 1));
+    const int k_begin = min(R, 2 * per * kpart), k_end = min(R, 2 * per * (kpart + 1));
 
     float m[NRB][3];
     small_wave_partial_n<PASS, NRB>(N, R, rays + 4l * b * N, xs, ys, G, c0, n0, k_begin, k_end, sCc + wave * 64, m);
+    if constexpr (KS == 1) {
+        if (lh == 0) {
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb) {
+                const int n = n0 + 32 * rb + lr;
+                if (n < N) {
+                    float* o = moments + (((long)b * JB + c0 / 64) * N + n) * HELIO_MOMENT_STRIDE;
+                    if (PASS == 0) { o[0] = m[rb][0]; o[2] = m[rb][1]; o[4] = m[rb][2]; }
+                    else { o[1] = m[rb][1]; o[3] = m[rb][2]; }
+                }
+            }
+        }
+        return;
+    }
     if (lh == 0) {
 #pragma unroll
         for (int rb = 0; rb < NRB; ++rb) {
-            float* r = sRed + (wave * 32 * NRB + 32 * rb + lr) * 3;
+            float* r = sRed + ((grp * KS + kpart) * RPG + 32 * rb + lr) * 3;
             r[0] = m[rb][0]; r[1] = m[rb][1]; r[2] = m[rb][2];
         }
     }
     __syncthreads();
-    const int n = n0 + tid;
-    if (tid < 32 * NRB && n < N) {                                 // fixed order over the KS k-parts
-        float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+    if (tid < RBW * RPG) {                                          // fixed order over the KS k-parts
+        const int g = tid / RPG, rl = tid % RPG;
+        const int n = ((blockIdx.x / JB) * RBW + g) * RPG + rl;
+        if (n < N) {
+            float t0 = 0.f, t1 = 0.f, t2 = 0.f;
 #pragma unroll
-        for (int w = 0; w < KS; ++w) {
-            const float* r = sRed + (w * 32 * NRB + tid) * 3;
-            if (w == 0) { t0 = r[0]; t1 = r[1]; t2 = r[2]; } else { t0 += r[0]; t1 += r[1]; t2 += r[2]; }
+            for (int w = 0; w < KS; ++w) {
+                const float* r = sRed + ((g * KS + w) * RPG + rl) * 3;
+                if (w == 0) { t0 = r[0]; t1 = r[1]; t2 = r[2]; } else { t0 += r[0]; t1 += r[1]; t2 += r[2]; }
+            }
+            float* o = moments + (((long)b * JB + c0 / 64) * N + n) * HELIO_MOMENT_STRIDE;
+            if (PASS == 0) { o[0] = t0; o[2] = t1; o[4] = t2; }
+            else { o[1] = t1; o[3] = t2; }
         }
-        float* o = moments + (((long)b * JB + c0 / 64) * N + n) * HELIO_MOMENT_STRIDE;
-        if (PASS == 0) { o[0] = t0; o[2] = t1; o[4] = t2; }
-        else { o[1] = t1; o[3] = t2; }
     }
 }
 
-template <int KS, int NRB = 1>
-__global__ void __launch_bounds__(64 * KS)
+template <int KS, int NRB = 1, int RBW = 1>
+__global__ void __launch_bounds__(64 * KS * RBW)
 splat_bwd_mfma_small(int N, int R, const float* __restrict__ rays, const float* __restrict__ xs,
                      const float* __restrict__ ys, const float* __restrict__ gimg, float* __restrict__ moments) {
-    __shared__ float smem[KS * 64 + KS * 32 * NRB * 3];
-    if (blockIdx.z == 0) splat_bwd_small_body<0, KS, NRB>(N, R, rays, xs, ys, gimg, moments, smem);
-    else splat_bwd_small_body<1, KS, NRB>(N, R, rays, xs, ys, gimg, moments, smem);
+    __shared__ float smem[KS * RBW * 64 + KS * RBW * 32 * NRB * 3];
+    if (blockIdx.z == 0) splat_bwd_small_body<0, KS, NRB, RBW>(N, R, rays, xs, ys, gimg, moments, smem);
+    else splat_bwd_small_body<1, KS, NRB, RBW>(N, R, rays, xs, ys, gimg, moments, smem);
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -1198,7 +1222,20 @@ int launch_splat_bwd(int B, int N, int R, const float* rays, const float* xs, co
     if (variant == 3 || variant == 6 || variant == 7) {        // 6 / 7: the small kernel with 4 / 8 waves (tests, tuning)
         const int ct = (R + 63) / 64, nt = (N + 31) / 32;
         const int nrb = variant == 3 ? bwd_small_nrb(B, N, R) : 1;
-        if (nrb == 4)
+        static const int ks_exp = [] { const char* e = getenv("HELIO_BWD_KSX"); return e ? atoi(e) : 0; }();     // tuning runs
+        // tools/sweep_bwd_nrb.py: from N = 600 — with workgroups enough — no split of the contracted axis at all
+        // (4 independent waves of 64 rays each: one epilogue per 2·R MFMAs): B = 25: N = 1000, R = 128: 37 → 30 µs,
+        // R = 256: 112 → 98 µs; B = 256, N = 1000, R = 64: 96 → 62 µs; at N = 300 it is 1.5× slower
+        const bool whole_k = variant == 3 && ks_exp == 0 && N >= 600 && 2l * ct * ((N + 255) / 256) * B >= 256;
+        if (whole_k || (variant == 3 && ks_exp == 1 && nrb == 2))
+            hipLaunchKernelGGL((splat_bwd_mfma_small<1, 2, 4>), dim3(ct * ((N + 255) / 256), B, 2), dim3(256), 0, st, N, R, rays, xs, ys, gimg, moments);
+        else if (variant == 3 && ks_exp == 1 && nrb == 1)
+            hipLaunchKernelGGL((splat_bwd_mfma_small<1, 1, 4>), dim3(ct * ((N + 127) / 128), B, 2), dim3(256), 0, st, N, R, rays, xs, ys, gimg, moments);
+        else if (variant == 3 && ks_exp == 2 && nrb == 1)
+            hipLaunchKernelGGL((splat_bwd_mfma_small<2, 1, 2>), dim3(ct * ((N + 63) / 64), B, 2), dim3(256), 0, st, N, R, rays, xs, ys, gimg, moments);
+        else if (variant == 3 && ks_exp == 2 && nrb == 2)
+            hipLaunchKernelGGL((splat_bwd_mfma_small<2, 2, 2>), dim3(ct * ((N + 127) / 128), B, 2), dim3(256), 0, st, N, R, rays, xs, ys, gimg, moments);
+        else if (nrb == 4)
             hipLaunchKernelGGL((splat_bwd_mfma_small<4, 4>), dim3(ct * ((N + 127) / 128), B, 2), dim3(256), 0, st, N, R, rays, xs, ys, gimg, moments);
         else if (nrb == 2)
             hipLaunchKernelGGL((splat_bwd_mfma_small<4, 2>), dim3(ct * ((N + 63) / 64), B, 2), dim3(256), 0, st, N, R, rays, xs, ys, gimg, moments);
