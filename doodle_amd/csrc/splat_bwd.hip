@@ -1225,7 +1225,9 @@ int launch_splat_bwd(int B, int N, int R, const float* rays, const float* xs, co
         static const int ks_exp = [] { const char* e = getenv("HELIO_BWD_KSX"); return e ? atoi(e) : 0; }();     // tuning runs
         // tools/sweep_bwd_nrb.py: from N = 600 — with workgroups enough — no split of the contracted axis at all
         // (4 independent waves of 64 rays each: one epilogue per 2·R MFMAs): B = 25: N = 1000, R = 128: 37 → 30 µs,
-        // R = 256: 112 → 98 µs; B = 256, N = 1000, R = 64: 96 → 62 µs; at N = 300 it is 1.5× slower
+        // R = 256: 112 → 98 µs; B = 256, N = 1000, R = 64: 96 → 62 µs; at N = 300 it is 1.5× slower.  (Held to 128
+        // registers — four waves per SIMD instead of two — it is no faster: 35.6 µs; the two passes alone take
+        // 16.5 and 21.0 µs of the 31 µs they take together.)
         const bool whole_k = variant == 3 && ks_exp == 0 && N >= 600 && 2l * ct * ((N + 255) / 256) * B >= 256;
         if (whole_k || (variant == 3 && ks_exp == 1 && nrb == 2))
             hipLaunchKernelGGL((splat_bwd_mfma_small<1, 2, 4>), dim3(ct * ((N + 255) / 256), B, 2), dim3(256), 0, st, N, R, rays, xs, ys, gimg, moments);
