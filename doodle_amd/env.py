@@ -214,6 +214,14 @@ class HelioEnv(_EnvBase):
         self.ideal_normals = ideal
         return {"img": img, "aux": torch.cat([self.sun_pos, ideal.flatten(1)], dim=1)}
 
+    def __getstate__(self):
+        # compiled step contexts and caches keyed on object identity are rebuilt on demand
+        state = dict(self.__dict__)
+        for name in ("_step_ctx", "_step_ctx_key", "_consts_cache", "_pending_check", "_ref_cache"):
+            if name in state:
+                state[name] = None
+        return state
+
     def step(self, action):
         """Render ``action`` on the noisy field and score it (:402-516).
 

@@ -120,6 +120,21 @@ class HelioField:
         if name != "_fast":
             object.__setattr__(self, "_fast", None)
 
+    # compiled contexts, cached tables and scratch are rebuilt on demand: a copy / a pickle carries none of them
+    _TRANSIENT = ("_render_ctx", "_ctx_key", "_fast", "_ops", "_fast_render", "_ray_ws")
+
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        for name in self._TRANSIENT:
+            state[name] = None
+        state["_trig_cache"] = {}
+        state["_plane"] = None
+        return state
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
+        self.__dict__["_plane"] = native.Plane(*self._plane_vectors, self._sigma_scale)
+
     @property
     def sigma_scale(self) -> float:
         return self._sigma_scale

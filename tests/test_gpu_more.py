@@ -1540,3 +1540,35 @@ def test_shards_reproduce_the_whole_batch_across_kernel_regimes(N, B, R, rows):
     a_rows = act_d[r0:r1].clone().requires_grad_(True)
     part_g, _, _ = f.render_rows(sun_d[r0:r1], a_rows, r0, B)
     assert torch.equal(part_g.detach(), img_g.detach()[r0:r1])
+
+
+def test_field_and_env_copy_and_pickle_without_their_compiled_state():
+    """copy.deepcopy / pickle of a field or an env that has rendered (compiled contexts, cached trig tables,
+    scratch buffers bound): the copy carries none of that, rebuilds it on demand and renders the same bits."""
+    import copy
+    import pickle
+    from doodle_amd.env import HelioEnv
+    f, _, suns, _, act = make_case(N=9, B=4, R=40, seed=12)
+    sun_d, act_d = suns.to(DEV), act.to(DEV)
+    f.render(sun_d, act_d, None)
+    want, want_actual = f.render(sun_d, act_d, None)
+    assert f._fast is not None and f._render_ctx is not None
+    for g in (copy.deepcopy(f), pickle.loads(pickle.dumps(f))):
+        assert g._fast is None and g._render_ctx is None and g._trig_cache == {}
+        img, actual = g.render(sun_d, act_d, None)
+        assert torch.equal(img, want) and torch.equal(actual, want_actual)
+        g.sigma_scale = 0.05                       # independent of the original
+    assert torch.equal(f.render(sun_d, act_d, None)[0], want)
+    torch.manual_seed(3)
+    hp = torch.rand(5, 3, device=DEV) * 10 + 80
+    hp[:, 2] = 0
+    env = HelioEnv(hp, torch.tensor([0., -5., 0.], device=DEV), (15., 15.), torch.tensor([0., 1., 0.], device=DEV),
+                   sigma_scale=0.05, error_scale_mrad=3.0, resolution=32, batch_size=6, device=DEV)
+    env.reset()
+    a = env.ideal_normals.reshape(6, -1).clone()
+    with torch.no_grad():
+        env.step(a)
+        o1, m1, _ = env.step(a)
+        twin = copy.deepcopy(env)
+        o2, m2, _ = twin.step(a)
+    assert torch.equal(o1["img"], o2["img"]) and torch.equal(m1["mse"], m2["mse"]) and torch.equal(m1["dist"], m2["dist"])
