@@ -254,7 +254,7 @@ class HelioField:
                 return out
         if (type(sun_position) is torch.Tensor and type(action) is torch.Tensor
                 and not (action.requires_grad and torch.is_grad_enabled())):
-            # launch-bound fast path (config 2 is ≈5.3 µs of GPU per call: every host microsecond shows):
+            # launch-bound fast path (config 2 is ≈3.7 µs of GPU per call: every host microsecond shows):
             # dtype / device / shape fix-ups, allocation and the launch happen inside the compiled binding
             fast = self._fast_render
             if fast is None:
