@@ -27,6 +27,9 @@
 extern "C" {
 #endif
 
+/* Bumped when a signature or the meaning of an argument changes.  Additions that leave every existing call
+ * valid do not bump it; since 1: helio_init_actions, helio_render_fwd_choice, splat variant 9, render variants
+ * 10-13, backward variants 6-8 (and helio_comm_count in helio_comm.h). */
 #define HELIO_ABI_VERSION 1
 
 #define HELIO_OK            0
