@@ -173,7 +173,7 @@ class HelioField:
         """[batch_size, N, 2] fresh error angles in mrad (:243-252)."""
         return torch.randn(batch_size, self.num_heliostats, 2, device=self.device) * self.error_scale_mrad
 
-    def _trig_of(self, errs: torch.Tensor) -> torch.Tensor:
+    def _trig_of(self, errs: torch.Tensor, on_device: bool = False) -> torch.Tensor:
         """(cos_e, sin_e, cos_u, sin_u) of errs·1e-3 (:87-91) WITH TORCH'S CPU BITS, wherever ``errs``
         lives: the 1e-5 image tolerance at sigma_scale = 0.01 leaves no room for a 1-ulp-different
         trig table, so device-sampled errors make one round trip per
@@ -181,7 +181,7 @@ class HelioField:
         path runs), upload — and the table is cached until the tensor changes.  ``device_trig =
         True`` (or HELIO_DEVICE_TRIG=1) keeps everything on the device instead
         (``helio_error_trig``: ≤ 1 ulp from these values, no host synchronisation)."""
-        if errs.is_cuda and self.device_trig:
+        if errs.is_cuda and (self.device_trig or on_device):
             return _get_ops().error_trig(errs).to(self.device)
         ang = errs.detach().to(device="cpu", dtype=torch.float32) * 1e-3
         e, u = ang[..., 0], ang[..., 1]
@@ -213,7 +213,10 @@ class HelioField:
         if batch is not None and B <= batch.shape[0]:
             table = self._cached_trig("batch", batch)           # rows [:B] are a prefix
             return (table if row0 == 0 else table[row0:row0 + rows]), 4 * N
-        return self._trig_of(self._sample_error_angles(rows)), 4 * N
+        # more suns than pre-sampled errors: the reference draws fresh errors on EVERY call (:349-353).  No
+        # fixture can pin a per-call device draw, so its cos/sin are taken by the HIP kernel (the ocml functions
+        # torch's own device kernels call) — no device→host→device round trip per render
+        return self._trig_of(self._sample_error_angles(rows), on_device=True), 4 * N
 
     # ------------------------------------------------------------------ optics
     def calculate_ideal_normals(self, sun_position) -> torch.Tensor:
