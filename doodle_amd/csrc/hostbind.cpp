@@ -182,14 +182,14 @@ struct RenderCtx {
     int64_t plane;
     at::Tensor helios, xs, ys, trig, rays_ws;
     int64_t trig_b_stride, variant;
-    Carver carve;
+    const Carver& carve;           // the device's (made once per process)
     int64_t generation;
     at::Tensor errs;               // the error tensor the trig table was made from (bind_errors), for render_checked
     int64_t errs_version = -1;
     RenderCtx(int64_t plane_, at::Tensor helios_, at::Tensor xs_, at::Tensor ys_, at::Tensor trig_, int64_t stride_,
               int64_t variant_)
         : plane(plane_), helios(std::move(helios_)), xs(std::move(xs_)), ys(std::move(ys_)), trig(std::move(trig_)),
-          trig_b_stride(stride_), variant(variant_), carve(helios), generation(g_generation.load()) {
+          trig_b_stride(stride_), variant(variant_), carve(carver_for(helios)), generation(g_generation.load()) {
         fp(helios, "heliostat_positions"); fp(xs, "xs"); fp(ys, "ys"); fp(trig, "trig");
     }
     void bind_errors(const at::Tensor& e) { errs = e; errs_version = (int64_t)e._version(); }

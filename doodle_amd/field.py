@@ -163,11 +163,23 @@ class HelioField:
             self.batch_error_angles_mrad = self._sample_error_angles(self.max_batch_size)
         else:
             self.batch_error_angles_mrad = None
-        # the trig tables of the new errors, now: the one host round trip of device-sampled errors
-        # belongs to reset_errors(), not to the first render after it (which may be under graph capture)
-        self._cached_trig("single", self.error_angles_mrad)
-        if self.batch_error_angles_mrad is not None:
-            self._cached_trig("batch", self.batch_error_angles_mrad)
+        # the trig tables of the new errors, now: the host round trip of device-sampled errors belongs to
+        # reset_errors(), not to the first render after it (which may be under graph capture) — and it is ONE
+        # round trip for both tensors (HelioEnv.reset() runs this every few steps: test_environment.py:386)
+        self._prime_trig_tables()
+
+    def _prime_trig_tables(self) -> None:
+        single, batch = self.error_angles_mrad, self.batch_error_angles_mrad
+        if batch is None or not single.is_cuda or self.device_trig:
+            self._cached_trig("single", single)
+            if batch is not None:
+                self._cached_trig("batch", batch)
+            return
+        N = self.num_heliostats
+        both = self._trig_of(torch.cat([single.reshape(1, N, 2), batch], dim=0))      # [1 + max_batch, N, 4]
+        for slot, errs, table in (("single", single, both[0]), ("batch", batch, both[1:])):
+            key = (errs.data_ptr(), errs._version, tuple(errs.shape), errs.device)
+            self._trig_cache[slot] = (key, table, errs)
 
     def _sample_error_angles(self, batch_size: int) -> torch.Tensor:
         """[batch_size, N, 2] fresh error angles in mrad (:243-252)."""
