@@ -1574,3 +1574,57 @@ def test_field_and_env_copy_and_pickle_without_their_compiled_state():
         twin = copy.deepcopy(env)
         o2, m2, _ = twin.step(a)
     assert torch.equal(o1["img"], o2["img"]) and torch.equal(m1["mse"], m2["mse"]) and torch.equal(m1["dist"], m2["dist"])
+
+
+def test_render_fast_paths_follow_the_general_path_through_a_random_history():
+    """Stateful fuzz of HelioField.render's host paths (memoised compiled context, per-(trig, stride) context,
+    general path): 300 random events — renders of varying batch size / sun rank / monitor flag / argument
+    form, in-place and out-of-place error edits, sigma_scale and heliostat reassignments, forced variants,
+    reset_errors() — and after every render the result must equal the general path's (render_rows) bit for bit."""
+    from doodle_amd import native
+    rng = np.random.default_rng(11)
+    N, Bmax, R = 7, 6, 36
+    f, _, suns, errs, act = make_case(N, Bmax, R, seed=21)
+    sun_d, act_d = suns.to(DEV), act.to(DEV)
+    f.error_angles_mrad = errs[0].to(DEV).clone()
+    f.batch_error_angles_mrad = errs.to(DEV).clone()
+    ops = native.get_ops()
+    renders = 0
+    for step in range(300):
+        ev = rng.integers(0, 12)
+        if ev == 0:
+            f.batch_error_angles_mrad.mul_(float(rng.uniform(0.5, 1.5)))
+        elif ev == 1:
+            f.error_angles_mrad.add_(0.3)
+        elif ev == 2:
+            f.batch_error_angles_mrad = f.batch_error_angles_mrad * 0.9
+        elif ev == 3:
+            f.sigma_scale = float(rng.uniform(0.02, 0.06))
+        elif ev == 4:
+            f.heliostat_positions = f.heliostat_positions + 0.01
+        elif ev == 5:
+            ops.splat_variant = int(rng.choice([0, 0, 1, 6, 10, 12]))
+        elif ev == 6 and step % 7 == 0:
+            f.reset_errors()
+        else:
+            B = int(rng.integers(1, Bmax + 1))
+            one_d = B == 1 and bool(rng.integers(0, 2))
+            monitor = bool(rng.integers(0, 2))
+            s = sun_d[0] if one_d else sun_d[:B]
+            a = act_d[0] if one_d else act_d[:B]
+            form = rng.integers(0, 4)
+            if form == 1:
+                a = a.reshape(-1, N, 3) if not one_d else a.reshape(N, 3)
+            elif form == 2:
+                a = a.double()
+            with torch.no_grad():
+                got = f.render(s, a, None, monitor=monitor)
+                want = f.render_rows(s.reshape(-1, 3), a.reshape(B, -1), 0, B, monitor)
+            img = got[0] if not one_d else got[0].unsqueeze(0)
+            assert torch.equal(img, want[0]) and torch.equal(got[1], want[1]), (step, B, one_d, monitor, form)
+            if monitor:
+                assert torch.equal(got[2], want[2]), step
+            assert got[0].shape == ((R, R) if one_d else (B, R, R)) and got[1].shape == (B, N, 3)
+            renders += 1
+    ops.splat_variant = 0
+    assert renders > 100
