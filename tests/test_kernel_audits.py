@@ -30,3 +30,19 @@ def test_product_sources_keep_their_stamps_behind_the_diagnostic_macro():
     assert "s_memtime" not in outside and "s_memrealtime" not in outside
     from doodle_amd import build as hb
     assert "-DHELIO_STAMPS" not in hb.FLAGS
+
+
+def test_every_environment_switch_the_product_reads_is_in_the_readme():
+    """HELIO_* variables read with getenv / os.environ in the product are A/B switches a reader must be able
+    to find: each one appears in README.md's table."""
+    import glob
+    import re
+    names = set()
+    for path in glob.glob(os.path.join(ROOT, "doodle_amd", "csrc", "*")) + glob.glob(os.path.join(ROOT, "doodle_amd", "*.py")) \
+            + [os.path.join(ROOT, "bench.py")]:
+        text = open(path, errors="ignore").read()
+        names.update(re.findall(r'getenv\("(HELIO_[A-Z0-9_]+)"\)', text))
+        names.update(re.findall(r'environ(?:\.get)?[\(\[]"(HELIO_[A-Z0-9_]+)"', text))
+    readme = open(os.path.join(ROOT, "README.md")).read()
+    missing = sorted(n for n in names if n not in readme)
+    assert len(names) >= 10 and not missing, missing
