@@ -8,9 +8,10 @@ A "step" is one ``HelioField.render`` forward over one batch of B synthetic sun 
 (``--preheat`` seconds of the same call, default 0.5 — disclosed in the line as ``preheat_s``):
 a fresh host path and a GPU coming out of idle run slow for their first ~0.1 s, and a K = 20
 sample is only ≈0.1 ms long.  Then EXACTLY K steps are timed between barrier + synchronize
-fences, MAX over ranks.  The process binds itself to the CPUs of its GPU's NUMA node first
-(doodle_amd/affinity.py — what ``numactl --cpunodebind`` would do; disclosed as
-``config.host_affinity``; the CPU baseline runs under the original mask).
+fences, MAX over ranks.  The process first binds all its threads — the runtime's helper threads too — to
+one last-level-cache group (CCD) of its GPU's NUMA node (doodle_amd/affinity.py — what ``taskset`` would
+do; measured: tools/core_sweep.py; disclosed as ``config.host_affinity``; the CPU baseline runs under the
+original mask).
 
 With N > 1 (``torch.distributed.run``, one rank per GPU) every rank renders its own B-row shard
 of a global batch of N·B suns (weak scaling).  The suns are independent, so the timed loop has no
@@ -265,7 +266,8 @@ def main():
     # the CPU baseline below runs under the original mask
     from doodle_amd import affinity
     cpu_mask0 = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None
-    numa = affinity.bind_to_gpu_node(local)
+    torch.empty(1, device=dev)                     # the runtime's helper threads exist from here on
+    numa = affinity.bind_to_gpu_ccd(local, slot=local)
     dist = None
     if world > 1 or args.force_dist:
         import torch.distributed as dist
@@ -401,7 +403,8 @@ def main():
                        "timing": f"{args.warmup} warm-up steps, {args.preheat} s time-based preheat (untimed, in bursts of "
                                  f"{args.steps} steps + fence), then {args.steps} timed steps between barrier + synchronize "
                                  "fences, max over ranks",
-                       "host_affinity": (f"process bound to the {numa['cpus']} CPUs of the GPU's NUMA node {numa['numa_node']}"
+                       "host_affinity": (f"all threads of the process bound to one last-level-cache group (CPUs {numa['l3_group']}, "
+                                         f"{numa['cpus']} of them) of the GPU's NUMA node {numa['numa_node']}"
                                          if numa is not None else "scheduler's choice")},
         }
         if dist is not None:
@@ -445,7 +448,7 @@ def main():
                     out["hbm_bound_kernels"] = {"error": repr(e)}
             if not args.no_cpu:
                 if numa is not None:
-                    os.sched_setaffinity(0, cpu_mask0)
+                    affinity.restore(cpu_mask0)
                 out["cpu_baseline"] = cpu_baseline(w, args.seed)
                 out["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
         os.write(json_fd, (json.dumps(out) + "\n").encode())

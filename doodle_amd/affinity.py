@@ -1,4 +1,4 @@
-"""Keep the launching host thread on the CPU socket the GPU hangs off.
+"""Keep the launching host thread near the GPU — and near the runtime's own threads.
 
 A config-2 render is 3.7 µs of GPU work behind a ≈3.4 µs HIP launch: the loop is bound by the host thread's
 doorbell and signal traffic to the card.  On a two-socket MI355X host (2 × 64 cores, the eight GPUs split over
@@ -60,3 +60,61 @@ def bind_to_gpu_node(device_index: int = 0) -> Optional[dict]:
         return None
     os.sched_setaffinity(0, cpus)
     return {"numa_node": node, "cpus": len(cpus)}
+
+
+def _l3_groups(cpus: set) -> list:
+    """The sets of CPUs that share a last-level cache (a CCD on EPYC), restricted to ``cpus``, in CPU order."""
+    seen, groups = set(), []
+    for c in sorted(cpus):
+        if c in seen:
+            continue
+        try:
+            with open(f"/sys/devices/system/cpu/cpu{c}/cache/index3/shared_cpu_list") as fh:
+                grp = _parse_cpulist(fh.read()) & cpus
+        except OSError:
+            grp = {c}
+        if not grp:
+            grp = {c}
+        seen |= grp
+        groups.append(grp)
+    return groups
+
+
+def _set_all_threads(cpus: set) -> None:
+    for tid in os.listdir("/proc/self/task"):
+        try:
+            os.sched_setaffinity(int(tid), cpus)
+        except (OSError, ValueError):
+            pass                                   # a thread that ended meanwhile
+
+
+def bind_to_gpu_ccd(device_index: int = 0, slot: int = 0) -> Optional[dict]:
+    """Restrict EVERY thread of this process to ONE last-level-cache group (CCD) of the device's NUMA node.
+
+    Measured (tools/core_sweep.py, config-2 loop, K = 20 renders + fence, main thread pinned core by core):
+    the cores of exactly one CCD give 90 µs, all others of the same NUMA node 120 µs — and WHICH CCD differs
+    from process to process: it is the one the HIP / ROCr runtime's helper threads happened to start on (every
+    launch hands cache lines — queue pointers, completion signals — between them and the launching thread;
+    inside one L3 that is cheap).  So the binding has to cover the runtime's threads too, not just the caller:
+    call this AFTER the device is initialised (the threads exist) and once; threads created later inherit it.
+    ``slot`` spreads several processes of one node over its CCDs (pass the local rank).
+    → {"numa_node", "cpus", "l3_group"} or None when nothing was changed."""
+    if os.environ.get("HELIO_NUMA_BIND", "1") == "0" or not hasattr(os, "sched_setaffinity"):
+        return None
+    node = gpu_numa_node(device_index)
+    allowed = os.sched_getaffinity(0)
+    cpus = (node_cpus(node) & allowed) if node is not None else set(allowed)
+    if not cpus:
+        return None
+    groups = _l3_groups(cpus)
+    if not groups:
+        return None
+    grp = groups[slot % len(groups)]
+    _set_all_threads(grp)
+    return {"numa_node": node, "cpus": len(grp), "l3_group": f"{min(grp)}-{max(grp)}"}
+
+
+def restore(mask: set) -> None:
+    """Put every thread of the process back on ``mask`` (what ``os.sched_getaffinity(0)`` said before binding)."""
+    if hasattr(os, "sched_setaffinity") and mask:
+        _set_all_threads(set(mask))
