@@ -18,8 +18,10 @@ void launch_geometry_bwd(int, int, int, const float*, const float*, const float*
 void launch_ideal_normals(int, int, const float*, const float*, const float*, float*, hipStream_t);
 void launch_error_trig(long, const float*, float*, hipStream_t);
 void launch_init_actions(long, const float*, const float*, float, float*, hipStream_t);
-int launch_splat_fwd(int, int, int, const float*, const float*, const float*, float*, int, hipStream_t);
-int launch_splat_bwd(int, int, int, const float*, const float*, const float*, const float*, float*, int, hipStream_t);
+int launch_splat_fwd(int, int, int, const float*, const float*, const float*, float*, int, void*, long, hipStream_t);
+int launch_splat_bwd(int, int, int, const float*, const float*, const float*, const float*, float*, int, void*, long, hipStream_t);
+long splat_fwd_scratch_bytes(int, int, int, int);
+long splat_bwd_scratch_bytes(int, int, int, int);
 int splat_bwd_blocks(int);
 bool render_is_fused(int, int, int);
 int render_fwd_choice(int, int, int);
@@ -81,6 +83,8 @@ int fused_form(int variant) { return variant == 10 ? 1 : variant == 11 ? 2 : var
 
 bool sizes_ok(int B, int N) { return B >= 1 && N >= 1 && B <= 65535 && (long)B * N <= (1l << 31) / 4; }
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+// optional device scratch: NULL (with any size) or 256-byte aligned with a non-negative size
+bool scratch_ok(const void* p, long bytes) { return !p || ((reinterpret_cast<uintptr_t>(p) & 255) == 0 && bytes >= 0); }
 }  // namespace
 
 extern "C" {
@@ -114,11 +118,13 @@ int helio_geometry_fwd(int B, int N, const float* helios_d, const float* sun_d, 
 }
 
 int helio_splat_fwd(int B, int N, int R, const float* rays_d, const float* xs_d, const float* ys_d,
-                    float* image_d, int variant, void* stream) {
+                    float* image_d, int variant, void* scratch_d, long scratch_bytes, void* stream) {
     if (!sizes_ok(B, N) || R < 1 || R > 16384) return fail(HELIO_E_INVALID, "splat_fwd: bad sizes B=%d N=%d R=%d", B, N, R);
     if (!rays_d || !xs_d || !ys_d || !image_d) return fail(HELIO_E_INVALID, "splat_fwd: null pointer");
     if (!aligned16(rays_d) || !aligned16(image_d)) return fail(HELIO_E_INVALID, "splat_fwd: rays/image must be 16-byte aligned");
-    if (helio::launch_splat_fwd(B, N, R, rays_d, xs_d, ys_d, image_d, variant, static_cast<hipStream_t>(stream)) != HELIO_OK)
+    if (!scratch_ok(scratch_d, scratch_bytes)) return fail(HELIO_E_INVALID, "splat_fwd: scratch must be 256-byte aligned");
+    if (helio::launch_splat_fwd(B, N, R, rays_d, xs_d, ys_d, image_d, variant, scratch_d, scratch_bytes,
+                                static_cast<hipStream_t>(stream)) != HELIO_OK)
         return fail(HELIO_E_INVALID, "splat_fwd: unknown variant %d", variant);
     return after_launch("splat_fwd");
 }
@@ -126,7 +132,7 @@ int helio_splat_fwd(int B, int N, int R, const float* rays_d, const float* xs_d,
 int helio_render_fwd(int B, int N, int R, const float* helios_d, const float* sun_d, const float* action_d,
                      const float* trig_d, long trig_b_stride, const helio_plane* plane, const float* xs_d,
                      const float* ys_d, float* actual_d, float* refl_d, float* rays_d, float* image_d,
-                     int variant, void* stream) {
+                     int variant, void* scratch_d, long scratch_bytes, void* stream) {
     if (!sizes_ok(B, N) || R < 1 || R > 16384) return fail(HELIO_E_INVALID, "render_fwd: bad sizes B=%d N=%d R=%d", B, N, R);
     if (!helios_d || !sun_d || !action_d || !trig_d || !plane || !xs_d || !ys_d || !actual_d || !image_d)
         return fail(HELIO_E_INVALID, "render_fwd: null pointer");
@@ -134,6 +140,7 @@ int helio_render_fwd(int B, int N, int R, const float* helios_d, const float* su
         return fail(HELIO_E_INVALID, "render_fwd: trig_b_stride must be 0 or 4*N");
     if (!aligned16(trig_d) || (rays_d && !aligned16(rays_d)) || !aligned16(image_d))
         return fail(HELIO_E_INVALID, "render_fwd: trig/rays/image must be 16-byte aligned");
+    if (!scratch_ok(scratch_d, scratch_bytes)) return fail(HELIO_E_INVALID, "render_fwd: scratch must be 256-byte aligned");
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (((variant == 0 || variant == 2) && helio::render_is_fused(B, N, R)) || fused_form(variant)) {
         if (!helio::launch_render_fused(B, N, R, helios_d, sun_d, action_d, trig_d, trig_b_stride, plane, xs_d, ys_d,
@@ -143,7 +150,7 @@ int helio_render_fwd(int B, int N, int R, const float* helios_d, const float* su
     }
     if (!rays_d) return fail(HELIO_E_INVALID, "render_fwd: this problem size needs the rays work buffer");
     helio::launch_geometry_fwd(B, N, helios_d, sun_d, action_d, trig_d, trig_b_stride, plane, actual_d, refl_d, rays_d, st);
-    if (helio::launch_splat_fwd(B, N, R, rays_d, xs_d, ys_d, image_d, variant, st) != HELIO_OK)
+    if (helio::launch_splat_fwd(B, N, R, rays_d, xs_d, ys_d, image_d, variant, scratch_d, scratch_bytes, st) != HELIO_OK)
         return fail(HELIO_E_INVALID, "render_fwd: unknown variant %d", variant);
     return after_launch("render_fwd");
 }
@@ -152,14 +159,28 @@ int helio_render_fwd_launches(int B, int N, int R) {
     return (sizes_ok(B, N) && R >= 1 && helio::render_is_fused(B, N, R)) ? 1 : 2;
 }
 
+long helio_fwd_scratch_bytes(int B, int N, int R, int variant) {
+    if (!sizes_ok(B, N) || R < 1 || R > 16384) return 0;
+    if (((variant == 0 || variant == 2) && helio::render_is_fused(B, N, R)) || fused_form(variant)) return 0;
+    return helio::splat_fwd_scratch_bytes(B, N, R, variant);
+}
+
+long helio_bwd_scratch_bytes(int B, int N, int R, int variant) {
+    if (!sizes_ok(B, N) || R < 1 || R > 16384) return 0;
+    if (variant == 8 || (variant == 0 && helio::render_bwd_is_fused(B, N, R))) return 0;
+    return helio::splat_bwd_scratch_bytes(B, N, R, variant);
+}
+
 int helio_splat_bwd_blocks(int R) { return R >= 1 ? helio::splat_bwd_blocks(R) : 0; }
 
 int helio_splat_bwd(int B, int N, int R, const float* rays_d, const float* xs_d, const float* ys_d,
-                    const float* grad_image_d, float* moments_d, int variant, void* stream) {
+                    const float* grad_image_d, float* moments_d, int variant, void* scratch_d, long scratch_bytes,
+                    void* stream) {
     if (!sizes_ok(B, N) || R < 1 || R > 16384) return fail(HELIO_E_INVALID, "splat_bwd: bad sizes B=%d N=%d R=%d", B, N, R);
     if (!rays_d || !xs_d || !ys_d || !grad_image_d || !moments_d) return fail(HELIO_E_INVALID, "splat_bwd: null pointer");
     if (!aligned16(rays_d) || !aligned16(grad_image_d)) return fail(HELIO_E_INVALID, "splat_bwd: rays/grad_image must be 16-byte aligned");
-    if (helio::launch_splat_bwd(B, N, R, rays_d, xs_d, ys_d, grad_image_d, moments_d, variant,
+    if (!scratch_ok(scratch_d, scratch_bytes)) return fail(HELIO_E_INVALID, "splat_bwd: scratch must be 256-byte aligned");
+    if (helio::launch_splat_bwd(B, N, R, rays_d, xs_d, ys_d, grad_image_d, moments_d, variant, scratch_d, scratch_bytes,
                                 static_cast<hipStream_t>(stream)) != HELIO_OK)
         return fail(HELIO_E_INVALID, "splat_bwd: unknown variant %d", variant);
     return after_launch("splat_bwd");
@@ -185,13 +206,15 @@ int helio_geometry_bwd(int B, int N, int n_blocks, const float* helios_d, const 
 int helio_render_bwd(int B, int N, int R, const float* helios_d, const float* sun_d, const float* action_d,
                      const float* trig_d, long trig_b_stride, const helio_plane* plane, const float* rays_d,
                      const float* xs_d, const float* ys_d, const float* grad_image_d, const float* grad_actual_d,
-                     const float* grad_refl_d, float* moments_d, float* grad_action_d, int variant, void* stream) {
+                     const float* grad_refl_d, float* moments_d, float* grad_action_d, int variant, void* scratch_d,
+                     long scratch_bytes, void* stream) {
     if (!sizes_ok(B, N) || R < 1 || R > 16384) return fail(HELIO_E_INVALID, "render_bwd: bad sizes B=%d N=%d R=%d", B, N, R);
     if (!helios_d || !sun_d || !action_d || !trig_d || !plane || !grad_action_d)
         return fail(HELIO_E_INVALID, "render_bwd: null pointer");
     if (trig_b_stride != 0 && trig_b_stride != 4l * N)
         return fail(HELIO_E_INVALID, "render_bwd: trig_b_stride must be 0 or 4*N");
     if (!aligned16(trig_d)) return fail(HELIO_E_INVALID, "render_bwd: trig must be 16-byte aligned");
+    if (!scratch_ok(scratch_d, scratch_bytes)) return fail(HELIO_E_INVALID, "render_bwd: scratch must be 256-byte aligned");
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (grad_image_d) {
         if (!rays_d || !xs_d || !ys_d || !moments_d) return fail(HELIO_E_INVALID, "render_bwd: null pointer");
@@ -205,7 +228,7 @@ int helio_render_bwd(int B, int N, int R, const float* helios_d, const float* su
                 return fail(HELIO_E_INVALID, "render_bwd: variant 8 does not exist for B=%d N=%d R=%d", B, N, R);
             return after_launch("render_bwd");
         }
-        if (helio::launch_splat_bwd(B, N, R, rays_d, xs_d, ys_d, grad_image_d, moments_d, variant, st) != HELIO_OK)
+        if (helio::launch_splat_bwd(B, N, R, rays_d, xs_d, ys_d, grad_image_d, moments_d, variant, scratch_d, scratch_bytes, st) != HELIO_OK)
             return fail(HELIO_E_INVALID, "render_bwd: unknown variant %d", variant);
     }
     helio::launch_geometry_bwd(B, N, helio::splat_bwd_blocks(R), helios_d, sun_d, action_d, trig_d, trig_b_stride,
@@ -324,8 +347,9 @@ int helio_env_step_fwd(int B, int N, int R, const float* helios_d, const float* 
                        const float target_position[3], const float target_normal[3], float width, float height,
                        int exponential_risk, float error_mask_ratio, float* workspace_d, float* out_d, float* mae_d,
                        float* keep_d, float* align_err_d, float* all_bounds_d, float* aux_d, int* notify, int ticket,
-                       void* stream) {
+                       void* scratch_d, long scratch_bytes, void* stream) {
     if (notify && ticket == 0) return fail(HELIO_E_INVALID, "env_step_fwd: ticket 0 is reserved");
+    if (!scratch_ok(scratch_d, scratch_bytes)) return fail(HELIO_E_INVALID, "env_step_fwd: scratch must be 256-byte aligned");
     if (sizes_ok(B, N) && R >= 1 && R <= 16384 &&
         (((variant == 0 || variant == 2) && helio::render_is_fused(B, N, R)) || fused_form(variant))) {
         if (!helios_d || !sun_d || !action_d || !trig_d || !plane || !xs_d || !ys_d || !actual_d || !image_d ||
@@ -349,7 +373,7 @@ int helio_env_step_fwd(int B, int N, int R, const float* helios_d, const float* 
         return after_launch("env_step_fwd(fused)");
     }
     const int rc = helio_render_fwd(B, N, R, helios_d, sun_d, action_d, trig_d, trig_b_stride, plane, xs_d, ys_d,
-                                    actual_d, refl_d, rays_d, image_d, variant, stream);
+                                    actual_d, refl_d, rays_d, image_d, variant, scratch_d, scratch_bytes, stream);
     if (rc != HELIO_OK) return rc;
     // the two-call form, with the same checks as helio_step_losses_fwd
     if (!target_d || !tx_d || !dmaps_d || !ideal_d || !target_position || !target_normal || !workspace_d || !out_d ||
@@ -412,7 +436,8 @@ int helio_env_step_bwd(int B, int N, int R, const float* helios_d, const float* 
                        const float target_normal[3], float width, float height, int exponential_risk,
                        const float* g_mse_d, const float* g_dist_d, const float* g_bound_d, const float* g_align_d,
                        const float* keep_d, const float* grad_actual_d, const float* grad_refl_d,
-                       float* grad_image_ws_d, float* moments_d, float* grad_action_d, int variant, void* stream) {
+                       float* grad_image_ws_d, float* moments_d, float* grad_action_d, int variant, void* scratch_d,
+                       long scratch_bytes, void* stream) {
     if (!sizes_ok(B, N) || R < 1 || R > 16384) return fail(HELIO_E_INVALID, "env_step_bwd: bad sizes B=%d N=%d R=%d", B, N, R);
     if (!helios_d || !sun_d || !action_d || !trig_d || !plane || !ideal_d || !target_position || !target_normal ||
         !grad_action_d)
@@ -420,6 +445,7 @@ int helio_env_step_bwd(int B, int N, int R, const float* helios_d, const float* 
     if (trig_b_stride != 0 && trig_b_stride != 4l * N)
         return fail(HELIO_E_INVALID, "env_step_bwd: trig_b_stride must be 0 or 4*N");
     if (!aligned16(trig_d)) return fail(HELIO_E_INVALID, "env_step_bwd: trig must be 16-byte aligned");
+    if (!scratch_ok(scratch_d, scratch_bytes)) return fail(HELIO_E_INVALID, "env_step_bwd: scratch must be 256-byte aligned");
     hipStream_t st = static_cast<hipStream_t>(stream);
     const bool through_image = g_mse_d || g_dist_d;
     if (through_image) {
@@ -446,7 +472,7 @@ int helio_env_step_bwd(int B, int N, int R, const float* helios_d, const float* 
                     return fail(HELIO_E_INVALID, "env_step_bwd: variant 8 does not exist for B=%d N=%d R=%d", B, N, R);
                 return after_launch("env_step_bwd");
             }
-            if (helio::launch_splat_bwd(B, N, R, rays_d, xs_d, ys_d, grad_image_ws_d, moments_d, variant, st) != HELIO_OK)
+            if (helio::launch_splat_bwd(B, N, R, rays_d, xs_d, ys_d, grad_image_ws_d, moments_d, variant, scratch_d, scratch_bytes, st) != HELIO_OK)
                 return fail(HELIO_E_INVALID, "env_step_bwd: unknown variant %d", variant);
         }
     }

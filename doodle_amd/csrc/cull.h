@@ -1,0 +1,89 @@
+// Rays whose footprint is EXACTLY zero on a tile — found before the footprint kernels run, skipped by them.
+//
+// The reference evaluates exp(-|P_ij - x|²/2σ²) for every (ray, pixel) pair
+// (newenv_rl_test_multi_error.py:142-148) and so do the dense kernels here.  With orientation errors of
+// tens of mrad most reflections miss the receiver by many σ: their factors underflow and every fused
+// multiply-add they take part in leaves its accumulator unchanged.  Leaving such a ray out of a sum is
+// therefore bit-identical — provided "zero" is decided from what the kernels COMPUTE, not from the real
+// number.  The kernels form a factor in one of three ways (coordinate v, shift s = a or b, cc = c2 or 0):
+//     q-form    exp2(-fma(q, q, cc·k2)),  q = fma(v, √k2, s·√k2)        (MFMA kernels; √k2 correctly rounded)
+//     fused     exp2(-(fma(t, t, cc) · k2)),  t = v + s                 (VALU kernels)
+//     unfused   exp2( ((t·t) + cc) · (-k2) )                            (epilogue of the MFMA backward)
+// Each is a composition of correctly rounded — hence monotone — operations of |q| or |t|, so the smallest
+// exponent over a tile's coordinates [lo, hi] (the true min and max of the tile's xs / ys: no ordering of
+// the coordinate arrays is assumed) is the same expression evaluated at the end nearer to -s, or 0 when
+// the interval straddles it.  exponent_floor() is the least of the three; a NaN anywhere keeps the ray.
+//   * forward: a ray is dropped from a tile when floor_x + floor_y > CULL_EXP2: every product A_i·E_j is
+//     then below 2^-152 (the margin of 2 covers v_exp_f32's error and its handling of denormal results, if
+//     it flushes them the product is 0 outright), less than half an ulp of ANY f32 accumulator, and
+//     fma(A_i, E_j, acc) == acc.
+//   * backward: a ray is dropped from an image when floor_x > CULL_EXP2 or floor_y > CULL_EXP2 over the WHOLE
+//     image: one factor table is then all +0, both contractions and all five moments of the dense kernels
+//     are exactly +0, and zeros are what the compaction kernel writes for it.
+// A plane-parallel ray (k2 = 0) has exponent 0 everywhere and is always kept: it adds 1.0 to every pixel
+// (:141-148).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace helio {
+
+constexpr float CULL_EXP2 = 152.0f;
+
+__device__ __forceinline__ float cull_nanmin(float a, float b) {
+    return (a != a || b != b) ? __builtin_nanf("") : fminf(a, b);
+}
+
+// the point of [lo, hi] nearest to zero, as a magnitude
+__device__ __forceinline__ float cull_nearest(float lo, float hi) { return lo > 0.0f ? lo : (hi < 0.0f ? -hi : 0.0f); }
+
+// smallest exponent (base 2) any of the kernels' factor forms computes for a coordinate in [lo, hi]
+__device__ __forceinline__ float exponent_floor(float lo, float hi, float shift, float k2, float sk, float cc) {
+    const float ssk = shift * sk;
+    const float qm = cull_nearest(__builtin_fmaf(lo, sk, ssk), __builtin_fmaf(hi, sk, ssk));
+    const float eq = __builtin_fmaf(qm, qm, cc * k2);
+    const float tm = cull_nearest(lo + shift, hi + shift);
+    const float ef = __builtin_fmaf(tm, tm, cc) * k2;
+    const float eu = ((tm * tm) + cc) * k2;
+    return cull_nanmin(eq, cull_nanmin(ef, eu));
+}
+
+struct CullBox { float xlo, xhi, ylo, yhi; };
+
+// ray = (a, b, k2, c2)
+__device__ __forceinline__ void cull_floors(const float4 ray, const CullBox& bx, float& fx, float& fy) {
+    const float sk = __builtin_sqrtf(ray.z);
+    fx = exponent_floor(bx.xlo, bx.xhi, ray.x, ray.z, sk, ray.w);
+    fy = exponent_floor(bx.ylo, bx.yhi, ray.y, ray.z, sk, 0.0f);
+}
+__device__ __forceinline__ bool cull_dead_product(const float4 ray, const CullBox& bx) {
+    float fx, fy;
+    cull_floors(ray, bx, fx, fy);
+    return fx + fy > CULL_EXP2;                       // false for NaN: kept
+}
+__device__ __forceinline__ bool cull_dead_strict(const float4 ray, const CullBox& bx) {
+    float fx, fy;
+    cull_floors(ray, bx, fx, fy);
+    return fx > CULL_EXP2 || fy > CULL_EXP2;
+}
+
+// ---- scratch layouts (device memory handed in by the caller; helio_*_scratch_bytes) ----------------
+// forward:  int counts[B·tiles²] (padded to 256 B) | float4 lists[B·tiles²][N]     tile = TE×TE pixels
+// backward: int counts[B]        (padded to 256 B) | int idx[B][N]
+__host__ __device__ inline long cull_pad256(long bytes) { return (bytes + 255) & ~255l; }
+inline long cull_fwd_bytes(int B, int N, int R, int TE) {
+    const long t = (R + TE - 1) / TE;
+    return cull_pad256(4l * B * t * t) + 16l * B * t * t * N;
+}
+inline long cull_bwd_bytes(int B, int N) { return cull_pad256(4l * B) + 4l * B * N; }
+
+struct CullFwd { const int* counts; const float4* lists; };      // counts == nullptr: dense
+struct CullBwd { const int* counts; const int* idx; };
+
+// launchers (cull.hip)
+CullFwd launch_cull_fwd(int B, int N, int R, int TE, const float* rays, const float* xs, const float* ys,
+                        void* scratch, hipStream_t st);
+CullBwd launch_cull_bwd(int B, int N, int R, int JB, const float* rays, const float* xs, const float* ys,
+                        float* moments, void* scratch, hipStream_t st);
+bool cull_enabled();
+
+}  // namespace helio

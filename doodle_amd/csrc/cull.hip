@@ -1,0 +1,142 @@
+// Order-preserving compaction of the rays that are not exactly zero on a tile (forward) or on an image
+// (backward) — see cull.h for why leaving the others out is bit-identical.  One workgroup per list;
+// deterministic (ballot + prefix counts, no atomics): a list keeps the heliostat order, so the footprint
+// kernels add the surviving terms in the order the dense kernels add them.
+#include <hip/hip_runtime.h>
+#include <cstdlib>
+#include "helio.h"
+#include "cull.h"
+
+namespace helio {
+
+constexpr int CULL_THREADS = 256, CULL_WAVES = CULL_THREADS / 64;
+
+// min and max of v[i0 .. i1) over the workgroup (every thread gets both); i1 > i0
+__device__ __forceinline__ void block_minmax(const float* __restrict__ v, int i0, int i1, float* sm, float& lo, float& hi) {
+    float a = __builtin_inff(), b = -__builtin_inff();
+    bool bad = false;
+    for (int i = i0 + (int)threadIdx.x; i < i1; i += CULL_THREADS) {
+        const float x = v[i];
+        bad |= x != x;
+        a = fminf(a, x);
+        b = fmaxf(b, x);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { a = fminf(a, __shfl_xor(a, d)); b = fmaxf(b, __shfl_xor(b, d)); }
+    const bool any_bad = __any(bad);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { sm[3 * wave] = a; sm[3 * wave + 1] = b; sm[3 * wave + 2] = any_bad ? 1.0f : 0.0f; }
+    __syncthreads();
+    lo = sm[0]; hi = sm[1];
+    float nb = sm[2];
+#pragma unroll
+    for (int w = 1; w < CULL_WAVES; ++w) { lo = fminf(lo, sm[3 * w]); hi = fmaxf(hi, sm[3 * w + 1]); nb += sm[3 * w + 2]; }
+    if (nb != 0.0f) lo = hi = __builtin_nanf("");      // a NaN coordinate: every ray of the tile is kept
+    __syncthreads();
+}
+
+// the calling thread's place among the flagged threads of the workgroup, and how many there are
+__device__ __forceinline__ int block_rank(bool flag, int* sw, int& total) {
+    const unsigned long long m = __ballot(flag);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int rank = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) sw[wave] = __popcll(m);
+    __syncthreads();
+    int before = 0;
+    total = 0;
+#pragma unroll
+    for (int w = 0; w < CULL_WAVES; ++w) { const int c = sw[w]; before += w < wave ? c : 0; total += c; }
+    __syncthreads();
+    return before + rank;
+}
+
+// grid (tiles², B): the rays of image b that are not exactly zero on tile (ti, tj) — blockIdx.x = ti·tiles + tj,
+// the tile numbering of the footprint kernels
+__global__ void __launch_bounds__(CULL_THREADS)
+cull_fwd_kernel(int N, int R, int TE, const float4* __restrict__ rays, const float* __restrict__ xs,
+                const float* __restrict__ ys, int* __restrict__ counts, float4* __restrict__ lists) {
+    __shared__ float sm[3 * CULL_WAVES];
+    __shared__ int sw[CULL_WAVES];
+    const int tiles = (R + TE - 1) / TE;
+    const int b = blockIdx.y, ti = blockIdx.x / tiles, tj = blockIdx.x % tiles;
+    CullBox bx;
+    block_minmax(xs, ti * TE, min(R, ti * TE + TE), sm, bx.xlo, bx.xhi);
+    block_minmax(ys, tj * TE, min(R, tj * TE + TE), sm, bx.ylo, bx.yhi);
+    const long list = (long)b * gridDim.x + blockIdx.x;
+    const float4* __restrict__ rb = rays + (long)b * N;
+    float4* __restrict__ out = lists + list * N;
+    int base = 0;
+    for (int n0 = 0; n0 < N; n0 += CULL_THREADS) {
+        const int n = n0 + (int)threadIdx.x;
+        float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+        bool live = false;
+        if (n < N) { q = rb[n]; live = !cull_dead_product(q, bx); }
+        int total;
+        const int at = block_rank(live, sw, total);
+        if (live) out[base + at] = q;
+        base += total;
+    }
+    if (threadIdx.x == 0) counts[list] = base;
+}
+
+// grid (B): the rays of image b with a footprint that is not identically zero on the image, as indices; the
+// moments of the others (all column blocks) are zeroed here — what the dense kernels compute for them
+__global__ void __launch_bounds__(CULL_THREADS)
+cull_bwd_kernel(int N, int R, int JB, const float4* __restrict__ rays, const float* __restrict__ xs,
+                const float* __restrict__ ys, int* __restrict__ counts, int* __restrict__ idx,
+                float* __restrict__ moments) {
+    __shared__ float sm[3 * CULL_WAVES];
+    __shared__ int sw[CULL_WAVES];
+    const int b = blockIdx.x;
+    CullBox bx;
+    block_minmax(xs, 0, R, sm, bx.xlo, bx.xhi);
+    block_minmax(ys, 0, R, sm, bx.ylo, bx.yhi);
+    const float4* __restrict__ rb = rays + (long)b * N;
+    int* __restrict__ out = idx + (long)b * N;
+    int base = 0;
+    for (int n0 = 0; n0 < N; n0 += CULL_THREADS) {
+        const int n = n0 + (int)threadIdx.x;
+        bool live = false;
+        if (n < N) {
+            live = !cull_dead_strict(rb[n], bx);
+            if (!live)
+                for (int jb = 0; jb < JB; ++jb) {
+                    float* o = moments + (((long)b * JB + jb) * N + n) * HELIO_MOMENT_STRIDE;
+#pragma unroll
+                    for (int k = 0; k < HELIO_MOMENT_STRIDE; ++k) o[k] = 0.0f;
+                }
+        }
+        int total;
+        const int at = block_rank(live, sw, total);
+        if (live) out[base + at] = n;
+        base += total;
+    }
+    if (threadIdx.x == 0) counts[b] = base;
+}
+
+// HELIO_CULL=0 switches the stage off (A/B runs): the dense kernels then run whatever scratch is passed
+bool cull_enabled() {
+    static const bool on = [] { const char* e = getenv("HELIO_CULL"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
+CullFwd launch_cull_fwd(int B, int N, int R, int TE, const float* rays, const float* xs, const float* ys,
+                        void* scratch, hipStream_t st) {
+    const int t = (R + TE - 1) / TE;
+    int* counts = static_cast<int*>(scratch);
+    float4* lists = reinterpret_cast<float4*>(static_cast<char*>(scratch) + cull_pad256(4l * B * t * t));
+    hipLaunchKernelGGL(cull_fwd_kernel, dim3(t * t, B), dim3(CULL_THREADS), 0, st, N, R, TE,
+                       reinterpret_cast<const float4*>(rays), xs, ys, counts, lists);
+    return CullFwd{counts, lists};
+}
+
+CullBwd launch_cull_bwd(int B, int N, int R, int JB, const float* rays, const float* xs, const float* ys,
+                        float* moments, void* scratch, hipStream_t st) {
+    int* counts = static_cast<int*>(scratch);
+    int* idx = reinterpret_cast<int*>(static_cast<char*>(scratch) + cull_pad256(4l * B));
+    hipLaunchKernelGGL(cull_bwd_kernel, dim3(B), dim3(CULL_THREADS), 0, st, N, R, JB,
+                       reinterpret_cast<const float4*>(rays), xs, ys, counts, idx, moments);
+    return CullBwd{counts, idx};
+}
+
+}  // namespace helio

@@ -37,6 +37,31 @@ const float* fpo(const c10::optional<at::Tensor>& t, const char* what) { return 
 
 void* cur_stream(const at::Tensor& t) { return (void*)c10::hip::getCurrentHIPStream(t.get_device()).stream(); }
 
+// The optional device scratch of the footprint entry points (include/helio.h, "Device scratch"): a block from
+// torch's caching allocator when the kernels the call will run can use one (large problems: the lists of rays
+// that are not exactly zero on a tile), nothing otherwise — the query is a few integer operations.  The block
+// is free again when the call returns: the allocator's stream ordering covers its reuse.
+// set_use_scratch(false) makes every call run dense (A/B runs, the dense roofline measurement).
+std::atomic<bool> g_use_scratch{true};
+struct Scratch {
+    at::Tensor t;
+    void* p = nullptr;
+    long bytes = 0;
+    Scratch(long n, const at::Tensor& like) {
+        if (n > 0 && g_use_scratch.load(std::memory_order_relaxed)) {
+            t = at::empty({(int64_t)n}, like.options().dtype(at::kByte));
+            p = t.data_ptr();
+            bytes = n;
+        }
+    }
+};
+Scratch fwd_scratch(int64_t B, int64_t N, int64_t R, int64_t variant, const at::Tensor& like) {
+    return Scratch(helio_fwd_scratch_bytes((int)B, (int)N, (int)R, (int)variant), like);
+}
+Scratch bwd_scratch(int64_t B, int64_t N, int64_t R, int64_t variant, const at::Tensor& like) {
+    return Scratch(helio_bwd_scratch_bytes((int)B, (int)N, (int)R, (int)variant), like);
+}
+
 // helio_plane structs live for the life of the process (a field keeps its handle)
 int64_t make_plane(const std::vector<double>& v) {
     TORCH_CHECK(v.size() == 16, "plane needs 16 numbers");
@@ -60,11 +85,12 @@ py::tuple render_fwd(int64_t plane, const at::Tensor& helios, const at::Tensor& 
     at::Tensor refl = want_refl ? at::empty_like(normals) : at::Tensor();
     at::Tensor rays = rays_ws.has_value() ? *rays_ws : at::empty({B, N, HELIO_RAY_STRIDE}, normals.options());
     at::Tensor image = at::empty({B, R, R}, normals.options());
+    const Scratch sc = fwd_scratch(B, N, R, variant, normals);
     check(helio_render_fwd((int)B, (int)N, (int)R, fp(helios, "heliostat_positions"), fp(sun, "sun"), pn,
                            fp(trig, "trig"), (long)trig_b_stride, reinterpret_cast<const helio_plane*>(plane),
                            fp(xs, "xs"), fp(ys, "ys"), actual.data_ptr<float>(),
                            want_refl ? refl.data_ptr<float>() : nullptr, rays.data_ptr<float>(),
-                           image.data_ptr<float>(), (int)variant, cur_stream(normals)));
+                           image.data_ptr<float>(), (int)variant, sc.p, sc.bytes, cur_stream(normals)));
     if (want_refl) return py::make_tuple(image, actual, refl, rays);
     return py::make_tuple(image, actual, py::none(), rays);
 }
@@ -87,11 +113,13 @@ py::tuple render_any(int64_t plane, const at::Tensor& helios, const at::Tensor& 
         at::Tensor rays = (rays_ws.has_value() && rays_ws->size(0) == B && rays_ws->device() == helios.device())
                               ? *rays_ws : at::empty({B, N, HELIO_RAY_STRIDE}, opt);
         at::Tensor image = at::empty({B, R, R}, opt);
+        const Scratch sc = fwd_scratch(B, N, R, variant, helios);
         check(helio_render_fwd((int)B, (int)N, (int)R, helios.data_ptr<float>(), sun_in.data_ptr<float>(),
                                action_in.data_ptr<float>(), fp(trig, "trig"), (long)trig_b_stride,
                                reinterpret_cast<const helio_plane*>(plane), xs.data_ptr<float>(), ys.data_ptr<float>(),
                                actual.data_ptr<float>(), want_refl ? refl.data_ptr<float>() : nullptr,
-                               rays.data_ptr<float>(), image.data_ptr<float>(), (int)variant, cur_stream(helios)));
+                               rays.data_ptr<float>(), image.data_ptr<float>(), (int)variant, sc.p, sc.bytes,
+                               cur_stream(helios)));
         if (want_refl) return py::make_tuple(image, actual, refl, rays);
         return py::make_tuple(image, actual, py::none(), rays);
     }
@@ -239,11 +267,13 @@ struct RenderCtx {
             return py::none();
         Outputs o = outputs(B, N, R, want_refl, batched);
         if (!rays_ws.defined() || rays_ws.size(0) != B) rays_ws = at::empty({B, N, HELIO_RAY_STRIDE}, helios.options());
+        const Scratch sc = fwd_scratch(B, N, R, variant, helios);
         check(helio_render_fwd((int)B, (int)N, (int)R, helios.data_ptr<float>(), sun.data_ptr<float>(),
                                action.data_ptr<float>(), trig.data_ptr<float>(), (long)trig_b_stride,
                                reinterpret_cast<const helio_plane*>(plane), xs.data_ptr<float>(), ys.data_ptr<float>(),
                                o.actual.data_ptr<float>(), want_refl ? o.refl.data_ptr<float>() : nullptr,
-                               rays_ws.data_ptr<float>(), o.image.data_ptr<float>(), (int)variant, cur_stream(helios)));
+                               rays_ws.data_ptr<float>(), o.image.data_ptr<float>(), (int)variant, sc.p, sc.bytes,
+                               cur_stream(helios)));
         if (want_refl) return py::make_tuple(o.image, o.actual, o.refl);
         return py::make_tuple(o.image, o.actual);
     }
@@ -259,11 +289,13 @@ struct RenderCtx {
         if (trig_b_stride != 0 && trig.numel() < B * N * 4) return py::none();
         Outputs o = outputs(B, N, R, want_refl, true);
         if (!rays_ws.defined() || rays_ws.size(0) != B) rays_ws = at::empty({B, N, HELIO_RAY_STRIDE}, helios.options());
+        const Scratch sc = fwd_scratch(B, N, R, variant, helios);
         check(helio_render_fwd((int)B, (int)N, (int)R, helios.data_ptr<float>(), sun.data_ptr<float>(),
                                action.data_ptr<float>(), trig.data_ptr<float>(), (long)trig_b_stride,
                                reinterpret_cast<const helio_plane*>(plane), xs.data_ptr<float>(), ys.data_ptr<float>(),
                                o.actual.data_ptr<float>(), want_refl ? o.refl.data_ptr<float>() : nullptr,
-                               rays_ws.data_ptr<float>(), o.image.data_ptr<float>(), (int)variant, cur_stream(helios)));
+                               rays_ws.data_ptr<float>(), o.image.data_ptr<float>(), (int)variant, sc.p, sc.bytes,
+                               cur_stream(helios)));
         if (want_refl) return py::make_tuple(o.image, o.actual, o.refl.view({B, N, 3}));
         return py::make_tuple(o.image, o.actual);
     }
@@ -297,7 +329,7 @@ struct RenderCtx {
                                    action.data_ptr<float>(), trig.data_ptr<float>(), (long)trig_b_stride,
                                    reinterpret_cast<const helio_plane*>(plane), xs.data_ptr<float>(), ys.data_ptr<float>(),
                                    actual.data_ptr<float>(), nullptr, rays_ws.data_ptr<float>(), image.data_ptr<float>(),
-                                   (int)variant, st));
+                                   (int)variant, nullptr, 0, st));
         d["abi_call_enqueue_ns"] = ns(t0);
         (void)hipStreamSynchronize((hipStream_t)st);
         d["abi_call_with_drain_ns"] = ns(t0);
@@ -341,10 +373,13 @@ struct RenderCtx {
         at::Tensor grad = at::empty({B, N, 3}, opt);
         void* st = cur_stream(helios);
         const helio_plane* pl = reinterpret_cast<const helio_plane*>(plane);
-        check(helio_render_fwd((int)B, (int)N, (int)R, helios.data_ptr<float>(), sun.data_ptr<float>(),
-                               action.data_ptr<float>(), trig.data_ptr<float>(), (long)trig_b_stride, pl,
-                               xs.data_ptr<float>(), ys.data_ptr<float>(), actual.data_ptr<float>(), nullptr,
-                               rays_ws.data_ptr<float>(), image.data_ptr<float>(), (int)variant, st));
+        {
+            const Scratch sc = fwd_scratch(B, N, R, variant, helios);
+            check(helio_render_fwd((int)B, (int)N, (int)R, helios.data_ptr<float>(), sun.data_ptr<float>(),
+                                   action.data_ptr<float>(), trig.data_ptr<float>(), (long)trig_b_stride, pl,
+                                   xs.data_ptr<float>(), ys.data_ptr<float>(), actual.data_ptr<float>(), nullptr,
+                                   rays_ws.data_ptr<float>(), image.data_ptr<float>(), (int)variant, sc.p, sc.bytes, st));
+        }
         float* mom = nullptr;
         if (g_image.has_value()) {
             const int64_t jb = helio_splat_bwd_blocks((int)R);
@@ -352,13 +387,14 @@ struct RenderCtx {
                 moments_ws = at::empty({B, jb, N, HELIO_MOMENT_STRIDE}, opt);
             mom = moments_ws.data_ptr<float>();
         }
+        const Scratch scb = g_image.has_value() ? bwd_scratch(B, N, R, bwd_variant, helios) : Scratch(0, helios);
         check(helio_render_bwd((int)B, (int)N, (int)R, helios.data_ptr<float>(), sun.data_ptr<float>(),
                                action.data_ptr<float>(), trig.data_ptr<float>(), (long)trig_b_stride, pl,
                                rays_ws.data_ptr<float>(), xs.data_ptr<float>(), ys.data_ptr<float>(),
                                g_image.has_value() ? g_image->data_ptr<float>() : nullptr,
                                g_actual.has_value() ? g_actual->data_ptr<float>() : nullptr,
                                g_refl.has_value() ? g_refl->data_ptr<float>() : nullptr, mom, grad.data_ptr<float>(),
-                               (int)bwd_variant, st));
+                               (int)bwd_variant, scb.p, scb.bytes, st));
         return py::make_tuple(image, actual, grad);
     }
 };
@@ -372,12 +408,13 @@ at::Tensor render_bwd(int64_t plane, const at::Tensor& helios, const at::Tensor&
     at::Tensor moments;
     if (g_image.has_value())
         moments = at::empty({B, (int64_t)helio_splat_bwd_blocks((int)R), N, HELIO_MOMENT_STRIDE}, normals.options());
+    const Scratch sc = g_image.has_value() ? bwd_scratch(B, N, R, variant, normals) : Scratch(0, normals);
     check(helio_render_bwd((int)B, (int)N, (int)R, fp(helios, "heliostat_positions"), fp(sun, "sun"),
                            fp(normals, "action"), fp(trig, "trig"), (long)trig_b_stride,
                            reinterpret_cast<const helio_plane*>(plane), fp(rays, "rays"), fp(xs, "xs"), fp(ys, "ys"),
                            fpo(g_image, "grad_image"), fpo(g_actual, "grad_actual"), fpo(g_refl, "grad_refl"),
                            g_image.has_value() ? moments.data_ptr<float>() : nullptr, grad.data_ptr<float>(),
-                           (int)variant, cur_stream(normals)));
+                           (int)variant, sc.p, sc.bytes, cur_stream(normals)));
     return grad;
 }
 
@@ -483,6 +520,7 @@ StepOut step_core(int64_t plane, const at::Tensor& helios, const at::Tensor& sun
         if (want_aux) o.aux = at::empty({B, 3 + 3 * N}, opt);
     }
     o.rays = rays_ws.has_value() ? *rays_ws : at::empty({B, N, HELIO_RAY_STRIDE}, opt);
+    const Scratch sc = fwd_scratch(B, N, R, variant, normals);
     check(helio_env_step_fwd((int)B, (int)N, (int)R, fp(helios, "heliostat_positions"), fp(sun, "sun"), pn,
                              fp(trig, "trig"), (long)trig_b_stride, reinterpret_cast<const helio_plane*>(plane),
                              fp(xs, "xs"), fp(ys, "ys"), o.actual.data_ptr<float>(), o.refl.data_ptr<float>(),
@@ -492,7 +530,7 @@ StepOut step_core(int64_t plane, const at::Tensor& helios, const at::Tensor& sun
                              o.out.data_ptr<float>(), o.mae.data_ptr<float>(), o.keep.data_ptr<float>(),
                              o.align.data_ptr<float>(), o.allb.data_ptr<float>(),
                              want_aux ? o.aux.data_ptr<float>() : nullptr, reinterpret_cast<int*>(notify), (int)ticket,
-                             cur_stream(normals)));
+                             sc.p, sc.bytes, cur_stream(normals)));
     return o;
 }
 
@@ -591,6 +629,7 @@ at::Tensor env_step_bwd(int64_t plane, const at::Tensor& helios, const at::Tenso
         moments = at::empty({B, (int64_t)helio_splat_bwd_blocks((int)R), N, HELIO_MOMENT_STRIDE}, normals.options());
         if (helio_env_step_bwd_image_ws((int)B, (int)N, (int)R) || (variant != 0 && variant != 4)) gws = at::empty_like(image);
     }
+    const Scratch sc = through_image ? bwd_scratch(B, N, R, variant, normals) : Scratch(0, normals);
     check(helio_env_step_bwd((int)B, (int)N, (int)R, fp(helios, "heliostat_positions"), fp(sun, "sun"),
                              fp(normals, "action"), fp(trig, "trig"), (long)trig_b_stride,
                              reinterpret_cast<const helio_plane*>(plane), fp(rays, "rays"), fp(xs, "xs"), fp(ys, "ys"),
@@ -600,7 +639,7 @@ at::Tensor env_step_bwd(int64_t plane, const at::Tensor& helios, const at::Tenso
                              fpo(g_actual, "grad_actual"), fpo(g_refl, "grad_refl"),
                              gws.defined() ? gws.data_ptr<float>() : nullptr,
                              through_image ? moments.data_ptr<float>() : nullptr, grad.data_ptr<float>(), (int)variant,
-                             cur_stream(normals)));
+                             sc.p, sc.bytes, cur_stream(normals)));
     return grad;
 }
 
@@ -632,11 +671,12 @@ class RenderFn : public torch::autograd::Function<RenderFn> {
         at::Tensor actual = at::empty_like(normals), refl = at::empty_like(normals);
         at::Tensor rays = at::empty({B, N, HELIO_RAY_STRIDE}, normals.options());
         at::Tensor image = at::empty({B, R, R}, normals.options());
+        const Scratch sc = fwd_scratch(B, N, R, variant, normals);
         check(helio_render_fwd((int)B, (int)N, (int)R, fp(helios, "heliostat_positions"), fp(sun, "sun"),
                                fp(normals, "action"), fp(trig, "trig"), (long)trig_b_stride,
                                reinterpret_cast<const helio_plane*>(plane), fp(xs, "xs"), fp(ys, "ys"),
                                actual.data_ptr<float>(), refl.data_ptr<float>(), rays.data_ptr<float>(),
-                               image.data_ptr<float>(), (int)variant, cur_stream(normals)));
+                               image.data_ptr<float>(), (int)variant, sc.p, sc.bytes, cur_stream(normals)));
         ctx->save_for_backward({normals, sun, trig, rays, helios, xs, ys});
         ctx->saved_data["plane"] = plane;
         ctx->saved_data["stride"] = trig_b_stride;
@@ -756,6 +796,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("abi_version", []() { return helio_abi_version(); });
     m.def("make_plane", &make_plane);
     m.def("invalidate_contexts", []() { return ++g_generation; });
+    m.def("set_use_scratch", [](bool on) { g_use_scratch.store(on); });
     m.def("current_stream_handle", &current_stream_handle);
     m.def("render_fwd", &render_fwd);
     m.def("render_any", &render_any);

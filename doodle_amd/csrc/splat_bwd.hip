@@ -18,6 +18,7 @@
 #include "helio.h"
 #include "step_loss_math.h"
 #include "geometry_bwd_ray.h"
+#include "cull.h"
 
 namespace helio {
 
@@ -159,7 +160,8 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <int PASS, bool VEC, int WC = 4>
 __global__ void __launch_bounds__(256 * WC)
 splat_bwd_mfma(int B, int N, int R, const float* __restrict__ rays, const float* __restrict__ xs,
-               const float* __restrict__ ys, const float* __restrict__ gimg, float* __restrict__ moments) {
+               const float* __restrict__ ys, const float* __restrict__ gimg, float* __restrict__ moments,
+               const int* __restrict__ live_counts, const int* __restrict__ live_idx) {
     static_assert(!(VEC && PASS == 1), "16-byte staging is pass 0's");
     // Row pitch of the two LDS tables.  Pass 1 writes the slab transposed (lanes ↔ k at stride LD):
     // an odd pitch keeps that conflict-free.  Pass 0 writes it along c and stages it 16 bytes at a time
@@ -181,6 +183,13 @@ splat_bwd_mfma(int B, int N, int R, const float* __restrict__ rays, const float*
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // scalar: nothing of it is kept in (or spilled from) VGPRs
     const int lr = lane & 31, lh = lane >> 5;
     const int c0 = (blockIdx.x % c_tiles) * TC, n0 = (blockIdx.x / c_tiles) * T;
+    // (cull.h) with a list of the image's rays whose footprint is not identically zero, the ray axis of the
+    // tiles runs over the list: L entries, entry p is ray live_idx[b·N + p]; the tiles past the list leave at
+    // once (the moments of the rays not listed were zeroed with the list).  A ray's moments involve no other
+    // ray, so which tile computes them changes nothing.
+    const int L = live_counts ? live_counts[b] : N;
+    if (n0 >= L) return;
+    const int* __restrict__ lidx = live_counts ? live_idx + (long)b * N : nullptr;
     const int wc = (wave >> 2) * 64, wn = (wave & 3) * 64;
     const float* __restrict__ ccoord = PASS == 0 ? ys : xs;   // coordinates along c
     const float* __restrict__ kcoord = PASS == 0 ? xs : ys;   // coordinates along k
@@ -192,7 +201,7 @@ splat_bwd_mfma(int B, int N, int R, const float* __restrict__ rays, const float*
     const int pr = wn + lane;
     const int pk0 = (wave >> 2) * KPT;
     float4 q = make_float4(0.f, 0.f, 1.f, 1e30f);
-    if (n0 + pr < N) q = reinterpret_cast<const float4*>(rays)[(long)b * N + n0 + pr];
+    if (n0 + pr < L) q = reinterpret_cast<const float4*>(rays)[(long)b * N + (lidx ? lidx[n0 + pr] : n0 + pr)];
     const float sk = __builtin_sqrtf(q.z);
     const float fshift = (PASS == 0 ? q.x : q.y) * sk;
     const float fcc = PASS == 0 ? q.w * q.z : 0.0f;
@@ -323,7 +332,8 @@ splat_bwd_mfma(int B, int N, int R, const float* __restrict__ rays, const float*
     const int lr2 = lane2 & 31, lh2 = lane2 >> 5;
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
-        const int n = n0 + wn + 32 * nb + lr2;
+        const int p = n0 + wn + 32 * nb + lr2;
+        const int n = p < L ? (lidx ? lidx[p] : p) : N;
         float4 h = make_float4(0.f, 0.f, 0.f, 0.f);
         if (n < N) h = reinterpret_cast<const float4*>(rays)[(long)b * N + n];
         const float hshift = PASS == 0 ? h.y : h.x;
@@ -726,7 +736,7 @@ static int bwd_small_nrb(int B, int N, int R) {
 
 template <int PASS, bool VEC, int WC>
 static void launch_bwd_mfma_v(int B, int N, int R, const float* rays, const float* xs, const float* ys,
-                              const float* gimg, float* moments, hipStream_t st) {
+                              const float* gimg, float* moments, hipStream_t st, CullBwd cull) {
     constexpr int TC = 64 * WC;
     const size_t lds = (64 * ((PASS == 0 ? TC + 4 : TC + 1) + (PASS == 0 ? 260 : 257)) + TC + 64) * sizeof(float);
     static bool configured = false;
@@ -736,23 +746,24 @@ static void launch_bwd_mfma_v(int B, int N, int R, const float* rays, const floa
         configured = true;
     }
     const int ct = (R + TC - 1) / TC, nt = (N + 255) / 256;
-    hipLaunchKernelGGL((splat_bwd_mfma<PASS, VEC, WC>), dim3(ct * nt, B), dim3(256 * WC), lds, st, B, N, R, rays, xs, ys, gimg, moments);
+    hipLaunchKernelGGL((splat_bwd_mfma<PASS, VEC, WC>), dim3(ct * nt, B), dim3(256 * WC), lds, st, B, N, R, rays, xs, ys, gimg, moments,
+                       cull.counts, cull.idx);
 }
 
 template <int PASS>
 static void launch_bwd_mfma(int B, int N, int R, const float* rays, const float* xs, const float* ys,
-                            const float* gimg, float* moments, hipStream_t st) {
+                            const float* gimg, float* moments, hipStream_t st, CullBwd cull) {
     const bool narrow = R <= 128;          // 128-wide c tiles: a 256-wide one would be at least half padding
     if constexpr (PASS == 0) {
         // 16-byte staging of the grad-image slab needs whole 4-pixel pieces per row (the image base is
         // 16-byte aligned by the ABI's contract)
-        if ((R & 3) == 0) return narrow ? launch_bwd_mfma_v<0, true, 2>(B, N, R, rays, xs, ys, gimg, moments, st)
-                                        : launch_bwd_mfma_v<0, true, 4>(B, N, R, rays, xs, ys, gimg, moments, st);
-        return narrow ? launch_bwd_mfma_v<0, false, 2>(B, N, R, rays, xs, ys, gimg, moments, st)
-                      : launch_bwd_mfma_v<0, false, 4>(B, N, R, rays, xs, ys, gimg, moments, st);
+        if ((R & 3) == 0) return narrow ? launch_bwd_mfma_v<0, true, 2>(B, N, R, rays, xs, ys, gimg, moments, st, cull)
+                                        : launch_bwd_mfma_v<0, true, 4>(B, N, R, rays, xs, ys, gimg, moments, st, cull);
+        return narrow ? launch_bwd_mfma_v<0, false, 2>(B, N, R, rays, xs, ys, gimg, moments, st, cull)
+                      : launch_bwd_mfma_v<0, false, 4>(B, N, R, rays, xs, ys, gimg, moments, st, cull);
     } else {
-        return narrow ? launch_bwd_mfma_v<1, false, 2>(B, N, R, rays, xs, ys, gimg, moments, st)
-                      : launch_bwd_mfma_v<1, false, 4>(B, N, R, rays, xs, ys, gimg, moments, st);
+        return narrow ? launch_bwd_mfma_v<1, false, 2>(B, N, R, rays, xs, ys, gimg, moments, st, cull)
+                      : launch_bwd_mfma_v<1, false, 4>(B, N, R, rays, xs, ys, gimg, moments, st, cull);
     }
 }
 
@@ -1199,16 +1210,30 @@ int splat_bwd_blocks(int R) { return (R + BW_JT - 1) / BW_JT; }
 
 // variant: 0 = by problem size, 1 = VALU kernel, 2 = MFMA kernels (256-tiles), 3 = MFMA small tiles,
 // 4 = few-ray streaming kernel, 5 = split-bf16 MFMA kernels (opt-in), 6 / 7 = the small kernel with 4 / 8 waves
+// the kernel family variant 0 stands for at this size
+static int splat_bwd_choice(int B, int N, int R) {
+    const long wgs = (long)B * ((R + 255) / 256) * ((N + 255) / 256);
+    // tools/sweep_bwd.py, tools/sweep_bwd_mid.py: the LDS-tile kernels (256 rays × 256 c, or × 128 c
+    // for images of at most 128 pixels across) pay off once there are enough tiles; below 65 pixels
+    // even the narrow tile is half padding and the small-tile kernel is its equal
+    return splat_bwd_is_few(B, N) ? 4 : (R > 64 && N >= 96 && wgs >= 128) ? 2 : 3;
+}
+
+// Skipping rays whose footprint is identically zero on the image (cull.h): the LDS-tile kernels walk 256-ray
+// tiles of a per-image list; worth a compaction launch once an image has more than one such tile.
+static bool cull_bwd_wanted(int variant, int B, int N, int R) {
+    if (variant == 0) variant = splat_bwd_choice(B, N, R);
+    return variant == 2 && N > 256 && cull_enabled();
+}
+
+long splat_bwd_scratch_bytes(int B, int N, int R, int variant) {
+    return cull_bwd_wanted(variant, B, N, R) ? cull_bwd_bytes(B, N) : 0;
+}
+
 int launch_splat_bwd(int B, int N, int R, const float* rays, const float* xs, const float* ys,
-                     const float* gimg, float* moments, int variant, hipStream_t st) {
+                     const float* gimg, float* moments, int variant, void* scratch, long scratch_bytes, hipStream_t st) {
     if (variant == 8) variant = 3;       // 8 is helio_render_bwd's single-launch form; its moments alone are the small kernel's
-    if (variant == 0) {
-        const long wgs = (long)B * ((R + 255) / 256) * ((N + 255) / 256);
-        // tools/sweep_bwd.py, tools/sweep_bwd_mid.py: the LDS-tile kernels (256 rays × 256 c, or × 128 c
-        // for images of at most 128 pixels across) pay off once there are enough tiles; below 65 pixels
-        // even the narrow tile is half padding and the small-tile kernel is its equal
-        variant = splat_bwd_is_few(B, N) ? 4 : (R > 64 && N >= 96 && wgs >= 128) ? 2 : 3;
-    }
+    if (variant == 0) variant = splat_bwd_choice(B, N, R);
     if (variant == 5) {
         launch_bwd_bf16x3<0>(B, N, R, rays, xs, ys, gimg, moments, st);
         launch_bwd_bf16x3<1>(B, N, R, rays, xs, ys, gimg, moments, st);
@@ -1248,8 +1273,11 @@ int launch_splat_bwd(int B, int N, int R, const float* rays, const float* xs, co
         return HELIO_OK;
     }
     if (variant == 2) {
-        launch_bwd_mfma<0>(B, N, R, rays, xs, ys, gimg, moments, st);
-        launch_bwd_mfma<1>(B, N, R, rays, xs, ys, gimg, moments, st);
+        CullBwd cull{nullptr, nullptr};
+        if (scratch && cull_bwd_wanted(2, B, N, R) && scratch_bytes >= cull_bwd_bytes(B, N))
+            cull = launch_cull_bwd(B, N, R, splat_bwd_blocks(R), rays, xs, ys, moments, scratch, st);
+        launch_bwd_mfma<0>(B, N, R, rays, xs, ys, gimg, moments, st, cull);
+        launch_bwd_mfma<1>(B, N, R, rays, xs, ys, gimg, moments, st, cull);
         return HELIO_OK;
     }
     if (variant != 1) return HELIO_E_INVALID;

@@ -33,6 +33,7 @@
 #include "helio.h"
 #include "ray_trace.h"
 #include "step_loss_math.h"
+#include "cull.h"
 
 namespace helio {
 
@@ -209,8 +210,9 @@ __device__ __forceinline__ void store_block(float* __restrict__ img, int R, int 
 // padded with rays whose A factor is exactly 0, so the loop has no tail logic.
 template <int MBI, int MBJ, int WI, int WJ, int NC, bool TWO_LEVEL>
 __global__ void __launch_bounds__(256)
-splat_fwd_mfma_regs(int B, int N, int R, const float* __restrict__ rays, const float* __restrict__ xs,
-                    const float* __restrict__ ys, float* __restrict__ image) {
+splat_fwd_mfma_regs(int B, int Nall, int R, const float* __restrict__ rays, const float* __restrict__ xs,
+                    const float* __restrict__ ys, float* __restrict__ image, const int* __restrict__ live_counts,
+                    const float4* __restrict__ live_lists) {
     static_assert(WI * WJ == 4 && NC % 4 == 0, "4 waves per workgroup");
     constexpr int TI = 32 * MBI * WI, TJ = 32 * MBJ * WJ;
     __shared__ float4 sRay[NC + 4];
@@ -240,7 +242,14 @@ splat_fwd_mfma_regs(int B, int N, int R, const float* __restrict__ rays, const f
     //   exp2(-(q² + cc)),  q = fma(coord, √k2, shift)        — 2 VALU + 1 exp per factor.
     // A padded ray: √k2 = 0, cc = 1e30  →  A = exp2(-1e30) = 0 exactly, E = 1
     const float4 pad = make_float4(0.f, 0.f, 0.f, 1e30f);
-    const float4* __restrict__ rb = reinterpret_cast<const float4*>(rays) + (long)b * N;
+    // the tile's rays: all of the image's, or (cull.h) the ordered list of those that are not exactly zero here
+    const float4* __restrict__ rb = reinterpret_cast<const float4*>(rays) + (long)b * Nall;
+    int N = Nall;
+    if (live_counts) {
+        const long t = (long)b * gridDim.x + blockIdx.x;
+        N = live_counts[t];
+        rb = live_lists + t * Nall;
+    }
     for (int n0 = 0; n0 < N; n0 += NC) {
         __syncthreads();
         for (int k = tid; k < NC + 4; k += 256) {
@@ -437,8 +446,9 @@ static bool launch_ksplit(int B, int N, int R, const float* rays, const float* x
 //     from four base registers + 16-bit immediates (no VALU instruction in the loop).
 template <int W, bool TWO_LEVEL>
 __global__ void __launch_bounds__(64 * W * W)
-splat_fwd_mfma_tile(int B, int N, int R, const float* __restrict__ rays, const float* __restrict__ xs,
-                    const float* __restrict__ ys, float* __restrict__ image) {
+splat_fwd_mfma_tile(int B, int Nall, int R, const float* __restrict__ rays, const float* __restrict__ xs,
+                    const float* __restrict__ ys, float* __restrict__ image, const int* __restrict__ live_counts,
+                    const float4* __restrict__ live_lists) {
     // row pitch: odd for the 4-wave form (ds_write_b32 per factor), T+2 for the 16-wave form, whose
     // producer stores factor PAIRS with ds_write_b64 (8-byte aligned rows; 16 lanes × 2 dwords
     // at pitch 258 cover the 32 banks exactly once)
@@ -465,7 +475,14 @@ splat_fwd_mfma_tile(int B, int N, int R, const float* __restrict__ rays, const f
         for (int e = 0; e < 16; ++e) { tot[m][e] = 0.0f; acc[m][e] = 0.0f; }
 
     const float4 pad = make_float4(0.f, 0.f, 1.f, 1e30f);   // A = exp2(-1e30) = 0 exactly
-    const float4* __restrict__ rb = reinterpret_cast<const float4*>(rays) + (long)b * N;
+    // the tile's rays: all of the image's, or (cull.h) the ordered list of those that are not exactly zero here
+    const float4* __restrict__ rb = reinterpret_cast<const float4*>(rays) + (long)b * Nall;
+    int N = Nall;
+    if (live_counts) {
+        const long t = (long)b * gridDim.x + blockIdx.x;
+        N = live_counts[t];
+        rb = live_lists + t * Nall;
+    }
     float4 g = (lane < N) ? rb[lane] : pad;
 
     lds_cf* pa = (lds_cf*)smem + lh * LD + wi + lr;
@@ -1156,16 +1173,16 @@ bool launch_env_step_fused(int B, int N, int R, const float* helios, const float
 
 template <int MBI, int MBJ, int WI, int WJ, int NC, bool TWO_LEVEL>
 static void launch_regs(int B, int N, int R, const float* rays, const float* xs, const float* ys,
-                        float* image, hipStream_t st) {
+                        float* image, hipStream_t st, CullFwd cull = CullFwd{nullptr, nullptr}) {
     constexpr int TI = 32 * MBI * WI, TJ = 32 * MBJ * WJ;
     const int ti = (R + TI - 1) / TI, tj = (R + TJ - 1) / TJ;
     hipLaunchKernelGGL((splat_fwd_mfma_regs<MBI, MBJ, WI, WJ, NC, TWO_LEVEL>), dim3(ti * tj, B), dim3(256), 0, st,
-                       B, N, R, rays, xs, ys, image);
+                       B, N, R, rays, xs, ys, image, cull.counts, cull.lists);
 }
 
 template <int W, bool TWO_LEVEL>
 static void launch_tile(int B, int N, int R, const float* rays, const float* xs, const float* ys,
-                        float* image, hipStream_t st) {
+                        float* image, hipStream_t st, CullFwd cull = CullFwd{nullptr, nullptr}) {
     constexpr int T = 64 * W;
     const int t = (R + T - 1) / T;
     const size_t lds = (2 * 64 * (T + (W == 4 ? 2 : 1)) + 2 * T) * sizeof(float);
@@ -1176,7 +1193,7 @@ static void launch_tile(int B, int N, int R, const float* rays, const float* xs,
         configured = true;
     }
     hipLaunchKernelGGL((splat_fwd_mfma_tile<W, TWO_LEVEL>), dim3(t * t, B), dim3(64 * W * W), lds, st,
-                       B, N, R, rays, xs, ys, image);
+                       B, N, R, rays, xs, ys, image, cull.counts, cull.lists);
 }
 
 
@@ -1450,10 +1467,29 @@ int render_fwd_choice(int B, int N, int R) {
     return splat_fwd_choice(B, N, R);
 }
 
+// Skipping exactly-zero rays (cull.h): the one-level LDS-table / register-operand kernels take a per-tile list of
+// the rays that are not exactly zero on their tile.  (The two-level and part-wise kernels — 64² tiles, k-split —
+// round at chunk boundaries, which a compacted list would move; the split-bf16 kernels align products against
+// the accumulator inside the pipe.  They stay dense.)  → the tile edge of the lists, 0: this call runs dense.
+// From N = 192: below that the compaction launch costs what it saves.
+static int cull_fwd_tile(int variant, int B, int N, int R) {
+    if (variant == 0 || variant == 2) variant = splat_fwd_choice(B, N, R);
+    if (!cull_enabled() || N < 192) return 0;
+    return variant == 5 ? 256 : (variant == 3 || variant == 4) ? 128 : 0;
+}
+
+long splat_fwd_scratch_bytes(int B, int N, int R, int variant) {
+    const int te = cull_fwd_tile(variant, B, N, R);
+    return te ? cull_fwd_bytes(B, N, R, te) : 0;
+}
+
 int launch_splat_fwd(int B, int N, int R, const float* rays, const float* xs, const float* ys,
-                     float* image, int variant, hipStream_t st) {
+                     float* image, int variant, void* scratch, long scratch_bytes, hipStream_t st) {
     const long t128 = (long)B * ((R + 127) / 128) * ((R + 127) / 128);
     if (variant == 0 || variant == 2) variant = splat_fwd_choice(B, N, R);
+    CullFwd cull{nullptr, nullptr};
+    if (const int te = scratch ? cull_fwd_tile(variant, B, N, R) : 0; te && scratch_bytes >= cull_fwd_bytes(B, N, R, te))
+        cull = launch_cull_fwd(B, N, R, te, rays, xs, ys, scratch, st);
     switch (variant) {
     case 9: {       // the k-split block kernel; forced: 16 waves where the rule would not choose it
         const int kp = ksplit_parts(B, N, R);
@@ -1472,9 +1508,9 @@ int launch_splat_fwd(int B, int N, int R, const float* rays, const float* xs, co
         return HELIO_OK;
     // one-level sums everywhere the heliostat loop is long (fewer registers → more waves per SIMD;
     // measured +4 %); the summation error at N = 5000 stays inside the tolerance (GPU tests)
-    case 3: launch_regs<2, 2, 2, 2, 128, false>(B, N, R, rays, xs, ys, image, st); return HELIO_OK;
-    case 4: launch_tile<2, false>(B, N, R, rays, xs, ys, image, st); return HELIO_OK;
-    case 5: launch_tile<4, false>(B, N, R, rays, xs, ys, image, st); return HELIO_OK;
+    case 3: launch_regs<2, 2, 2, 2, 128, false>(B, N, R, rays, xs, ys, image, st, cull); return HELIO_OK;
+    case 4: launch_tile<2, false>(B, N, R, rays, xs, ys, image, st, cull); return HELIO_OK;
+    case 5: launch_tile<4, false>(B, N, R, rays, xs, ys, image, st, cull); return HELIO_OK;
     case 6: launch_regs<1, 1, 2, 2, 128, true>(B, N, R, rays, xs, ys, image, st); return HELIO_OK;
     case 7: launch_bf16x3<true>(B, N, R, rays, xs, ys, image, st); return HELIO_OK;
     case 8: launch_bf16x3<false>(B, N, R, rays, xs, ys, image, st); return HELIO_OK;

@@ -28,9 +28,10 @@ class _Render(torch.autograd.Function):
     """image, actual, refl = render(normals); differentiable w.r.t. ``normals`` only."""
 
     @staticmethod
-    def forward(ctx, normals, field, sun, trig, trig_stride):
+    def forward(ctx, normals, field, sun, trig, trig_stride, variant=None):
         image, actual, refl, rays = _get_ops().render_fwd(
-            field.heliostat_positions, sun, normals, trig, trig_stride, field._plane, field._xs, field._ys)
+            field.heliostat_positions, sun, normals, trig, trig_stride, field._plane, field._xs, field._ys,
+            variant=variant)
         ctx.field, ctx.trig_stride = field, trig_stride
         ctx.save_for_backward(normals, sun, trig, rays)
         ctx.set_materialize_grads(False)          # unused outputs arrive as None, not as zero tensors
@@ -41,11 +42,11 @@ class _Render(torch.autograd.Function):
         normals, sun, trig, rays = ctx.saved_tensors
         field = ctx.field
         if g_image is None and g_actual is None and g_refl is None:
-            return None, None, None, None, None
+            return None, None, None, None, None, None
         c = lambda g: g.contiguous() if g is not None else None  # noqa: E731
         g = _get_ops().render_bwd(field.heliostat_positions, sun, normals, trig, ctx.trig_stride, field._plane,
                                   rays, field._xs, field._ys, c(g_image), c(g_actual), c(g_refl))
-        return g, None, None, None, None
+        return g, None, None, None, None, None
 
 
 class HelioField:
@@ -379,28 +380,25 @@ class HelioField:
         # a piece of a larger batch is rendered by the kernel the WHOLE batch would get (the size rules look at
         # B; every kernel's summation order depends on N and R only): the rows of the unsharded render, bit
         # for bit, whatever the shard size
+        # — passed DOWN with this call (an argument of helio_render_fwd), never written to the process-wide ops
+        # object: another thread rendering meanwhile keeps its own kernel choice.  Only the FORWARD is
+        # bit-identical across shards; the backward's kernel rules look at the shard's own size.
         ops = _get_ops()
-        forced = 0
+        forced = None
         if global_batch != B and getattr(ops, "splat_variant", 0) == 0:
             choose = getattr(ops, "render_choice", None)
-            forced = choose(global_batch, N, self.resolution) if choose is not None else 0
-        if forced:
-            object.__setattr__(ops, "splat_variant", forced)      # (no context is built while it is set)
-        try:
-            if torch.is_grad_enabled() and normals.requires_grad:
-                node = getattr(ops, "render_node", None)
-                out = node(self, sun, normals, trig, stride) if node is not None else None
-                # (the same node as a C++ autograd Function when the compiled binding is built)
-                images, actual, refl = out if out is not None else _Render.apply(normals, self, sun, trig, stride)
-            else:
-                # no autograd: the ray work buffer is scratch, reuse it between calls
-                ws = self._ray_ws
-                if ws is None or ws.shape[0] != B or ws.device != normals.device:
-                    ws = self._ray_ws = torch.empty((B, N, native.RAY_STRIDE), dtype=torch.float32, device=normals.device)
-                images, actual, refl, _ = ops.render_fwd(
-                    self.heliostat_positions, sun, normals, trig, stride, self._plane, self._xs, self._ys,
-                    want_refl=monitor, rays=ws)
-        finally:
-            if forced:
-                object.__setattr__(ops, "splat_variant", 0)
+            forced = (choose(global_batch, N, self.resolution) or None) if choose is not None else None
+        if torch.is_grad_enabled() and normals.requires_grad:
+            node = getattr(ops, "render_node", None)
+            out = node(self, sun, normals, trig, stride, variant=forced) if node is not None else None
+            # (the same node as a C++ autograd Function when the compiled binding is built)
+            images, actual, refl = out if out is not None else _Render.apply(normals, self, sun, trig, stride, forced)
+        else:
+            # no autograd: the ray work buffer is scratch, reuse it between calls
+            ws = self._ray_ws
+            if ws is None or ws.shape[0] != B or ws.device != normals.device:
+                ws = self._ray_ws = torch.empty((B, N, native.RAY_STRIDE), dtype=torch.float32, device=normals.device)
+            images, actual, refl, _ = ops.render_fwd(
+                self.heliostat_positions, sun, normals, trig, stride, self._plane, self._xs, self._ys,
+                want_refl=monitor, rays=ws, variant=forced)
         return images, actual, (refl.view(-1, 3) if refl is not None else None)

@@ -25,8 +25,9 @@ EXPORTS = (
     "helio_distance_maps_workspace", "helio_distance_maps",
     "helio_env_step_workspace", "helio_env_step_launches", "helio_render_fwd_choice", "helio_env_step_fwd",
     "helio_notify_create", "helio_notify_destroy", "helio_notify_wait",
-    "helio_env_step_bwd_image_ws", "helio_env_step_bwd",
+    "helio_env_step_bwd_image_ws", "helio_env_step_bwd", "helio_fwd_scratch_bytes", "helio_bwd_scratch_bytes",
 )
+ABI_VERSION = 2
 
 
 class Plane(ctypes.Structure):
@@ -58,12 +59,14 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
         "helio_device_arch": (_i, [_i, ctypes.c_char_p, _i]),
         "helio_error_trig": (_i, [_l, _vp, _vp, _vp]),
         "helio_geometry_fwd": (_i, [_i, _i, _vp, _vp, _vp, _vp, _l, pp, _vp, _vp, _vp, _vp]),
-        "helio_splat_fwd": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp]),
-        "helio_render_fwd": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _l, pp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
-        "helio_render_bwd": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _l, pp] + [_vp] * 8 + [_i, _vp]),
+        "helio_splat_fwd": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _l, _vp]),
+        "helio_render_fwd": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _l, pp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _l, _vp]),
+        "helio_render_bwd": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _l, pp] + [_vp] * 8 + [_i, _vp, _l, _vp]),
+        "helio_fwd_scratch_bytes": (_l, [_i, _i, _i, _i]),
+        "helio_bwd_scratch_bytes": (_l, [_i, _i, _i, _i]),
         "helio_render_fwd_launches": (_i, [_i, _i, _i]),
         "helio_splat_bwd_blocks": (_i, [_i]),
-        "helio_splat_bwd": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+        "helio_splat_bwd": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _l, _vp]),
         "helio_geometry_bwd": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _l, pp, _vp, _vp, _vp, _vp, _vp]),
         "helio_ideal_normals": (_i, [_i, _i, _vp, _vp, ctypes.c_float * 3, _vp, _vp]),
         "helio_init_actions": (_i, [_l, _vp, _vp, _f, _vp, _vp]),
@@ -76,10 +79,10 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
         "helio_env_step_launches": (_i, [_i, _i, _i]),
         "helio_render_fwd_choice": (_i, [_i, _i, _i]),
         "helio_env_step_fwd": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _l, pp, _vp, _vp, _vp, _vp, _vp, _vp, _i]
-                               + [_vp] * 4 + [_f3, _f3, _f, _f, _i, _f] + [_vp] * 7 + [_vp, _i, _vp]),
+                               + [_vp] * 4 + [_f3, _f3, _f, _f, _i, _f] + [_vp] * 7 + [_vp, _i, _vp, _l, _vp]),
         "helio_env_step_bwd_image_ws": (_i, [_i, _i, _i]),
         "helio_env_step_bwd": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _l, pp] + [_vp] * 8 + [_f3, _f3, _f, _f, _i]
-                               + [_vp] * 10 + [_i, _vp]),
+                               + [_vp] * 10 + [_i, _vp, _l, _vp]),
         "helio_notify_create": (_i, [ctypes.POINTER(_vp)]),
         "helio_notify_destroy": (_i, [_vp]),
         "helio_notify_wait": (_i, [_vp, _i, ctypes.c_double]),
@@ -87,7 +90,7 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     for name, (res, args) in protos.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.restype, fn.argtypes = res, args
-    if lib.helio_abi_version() != 1:
+    if lib.helio_abi_version() != ABI_VERSION:
         raise RuntimeError("libhelio.so ABI version mismatch")
     _lib = lib
     return lib
@@ -123,7 +126,7 @@ def _load_hostbind():
         return None
     try:
         from . import _hostbind
-        return _hostbind if _hostbind.abi_version() == 1 else None
+        return _hostbind if _hostbind.abi_version() == ABI_VERSION else None
     except ImportError:
         return None
 
@@ -148,6 +151,10 @@ class HipOps:
                 if hb is not None and hasattr(hb, "invalidate_contexts"):
                     hb.invalidate_contexts()
         object.__setattr__(self, name, value)
+        if name in ("cull", "hb"):
+            hb = self.__dict__.get("hb")
+            if hb is not None and hasattr(hb, "set_use_scratch"):
+                hb.set_use_scratch(bool(self.__dict__.get("cull", True)))
 
     def __init__(self):
         self.lib = load_library()
@@ -158,6 +165,11 @@ class HipOps:
         self.arch = buf.value.decode()
         if not self.arch.startswith("gfx950"):
             raise RuntimeError(f"libhelio.so is built for gfx950 (MI355X); device is {self.arch}")
+        # hand the footprint kernels a device scratch buffer, with which the large-problem kernels skip the rays
+        # that are exactly zero on a tile (include/helio.h "Device scratch"; identical results either way);
+        # False: every call runs dense — A/B runs and the dense roofline measurement (HELIO_CULL=0 does the
+        # same inside the library)
+        self.cull = True
         self.splat_variant = int(os.environ.get("HELIO_SPLAT_VARIANT", "0"))
         self.bwd_variant = int(os.environ.get("HELIO_BWD_VARIANT", "0"))
         self.hb = _load_hostbind()
@@ -182,22 +194,34 @@ class HipOps:
             rays.data_ptr() if want_rays else None, _stream()))
         return actual, refl, rays
 
-    def render_fwd(self, helios, sun, normals, trig, trig_b_stride, plane, xs, ys, want_refl=True, rays=None):
+    def _scratch(self, query, B, N, R, variant, like, cull=None):
+        """→ (tensor keeping it alive | None, pointer | None, bytes) of the optional device scratch."""
+        n = query(int(B), int(N), int(R), int(variant)) if (self.cull if cull is None else cull) else 0
+        if n <= 0:
+            return None, None, 0
+        t = torch.empty(n, dtype=torch.uint8, device=like.device)
+        return t, t.data_ptr(), n
+
+    def render_fwd(self, helios, sun, normals, trig, trig_b_stride, plane, xs, ys, want_refl=True, rays=None,
+                   variant=None):
         """geometry + splat in ONE C call (one fused launch for small problems).
-        ``rays``: a caller-provided [B,N,4] work buffer to reuse, else a fresh one."""
+        ``rays``: a caller-provided [B,N,4] work buffer to reuse, else a fresh one.
+        ``variant``: a forced kernel for this call (None: ``self.splat_variant``)."""
+        variant = self.splat_variant if variant is None else int(variant)
         if self.hb is not None:
             return self.hb.render_fwd(_plane_handle(self.hb, plane), helios, sun, normals, trig, trig_b_stride,
-                                      xs, ys, rays, want_refl, self.splat_variant)
+                                      xs, ys, rays, want_refl, variant)
         B, N, R = normals.shape[0], normals.shape[1], xs.shape[0]
         actual = torch.empty_like(normals)
         refl = torch.empty_like(normals) if want_refl else None
         if rays is None:
             rays = torch.empty((B, N, RAY_STRIDE), dtype=torch.float32, device=normals.device)
         image = torch.empty((B, R, R), dtype=torch.float32, device=normals.device)
+        _keep, sp, sn = self._scratch(self.lib.helio_fwd_scratch_bytes, B, N, R, variant, normals)
         _check(self.lib, self.lib.helio_render_fwd(
             B, N, R, _dev(helios), _dev(sun), _dev(normals), _dev(trig), trig_b_stride, plane,
             _dev(xs), _dev(ys), actual.data_ptr(), refl.data_ptr() if want_refl else None,
-            rays.data_ptr(), image.data_ptr(), self.splat_variant, _stream()))
+            rays.data_ptr(), image.data_ptr(), variant, sp, sn, _stream()))
         return image, actual, refl, rays
 
     def render_choice(self, B, N, R):
@@ -270,12 +294,13 @@ class HipOps:
         ws = new(self.lib.helio_env_step_workspace(B, N, R))
         out, mae, keep, align, allb = new(5), new(B), new(B), new(B, N), new(B, N)
         aux = new(B, 3 + 3 * N) if want_aux else None
+        _keep, sp, sn = self._scratch(self.lib.helio_fwd_scratch_bytes, B, N, R, self.splat_variant, normals)
         _check(self.lib, self.lib.helio_env_step_fwd(
             B, N, R, _dev(helios), _dev(sun), _dev(normals), _dev(trig), trig_b_stride, plane, _dev(xs), _dev(ys),
             actual.data_ptr(), refl.data_ptr(), rays.data_ptr(), image.data_ptr(), self.splat_variant,
             _dev(c.target), _dev(c.tx), _dev(c.dmaps), _dev(c.ideal), c.tp, c.tn, c.W, c.H, int(c.exp_risk),
             c.mask_ratio, ws.data_ptr(), out.data_ptr(), mae.data_ptr(), keep.data_ptr(), align.data_ptr(),
-            allb.data_ptr(), aux.data_ptr() if want_aux else None, rec or None, ticket, _stream()))
+            allb.data_ptr(), aux.data_ptr() if want_aux else None, rec or None, ticket, sp, sn, _stream()))
         return image, actual, refl, rays, out, mae, align, allb, keep, aux, ticket
 
     def env_step_bwd(self, helios, sun, normals, trig, trig_b_stride, plane, rays, xs, ys, image, c, g_mse, g_dist,
@@ -296,20 +321,24 @@ class HipOps:
             if self.lib.helio_env_step_bwd_image_ws(B, N, R) or self.bwd_variant not in (0, 4):
                 gws = torch.empty_like(image)
         ptr = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
+        _keep, sp, sn = (self._scratch(self.lib.helio_bwd_scratch_bytes, B, N, R, self.bwd_variant, normals)
+                         if moments is not None else (None, None, 0))
         _check(self.lib, self.lib.helio_env_step_bwd(
             B, N, R, _dev(helios), _dev(sun), _dev(normals), _dev(trig), trig_b_stride, plane, _dev(rays), _dev(xs),
             _dev(ys), _dev(image), _dev(c.target), _dev(c.tx), _dev(c.dmaps), _dev(c.ideal), c.tp, c.tn, c.W, c.H,
             int(c.exp_risk), ptr(g_mse), ptr(g_dist), ptr(g_bound), ptr(g_align), ptr(keep), ptr(g_actual),
-            ptr(g_refl), ptr(gws), ptr(moments), grad.data_ptr(), self.bwd_variant, _stream()))
+            ptr(g_refl), ptr(gws), ptr(moments), grad.data_ptr(), self.bwd_variant, sp, sn, _stream()))
         return grad
 
     # -- the two autograd nodes as C++ torch::autograd::Function (compiled binding only) ------------
-    def render_node(self, field, sun, normals, trig, trig_b_stride):
-        """``_Render.apply`` of field.py without the Python Function (None: binding not built)."""
+    def render_node(self, field, sun, normals, trig, trig_b_stride, variant=None):
+        """``_Render.apply`` of field.py without the Python Function (None: binding not built).
+        ``variant``: a forced forward kernel for this call (None: ``self.splat_variant``)."""
         if self.hb is None:
             return None
         return self.hb.render_autograd(_plane_handle(self.hb, field._plane), field.heliostat_positions, sun, normals,
-                                       trig, trig_b_stride, field._xs, field._ys, self.splat_variant, self.bwd_variant)
+                                       trig, trig_b_stride, field._xs, field._ys,
+                                       self.splat_variant if variant is None else int(variant), self.bwd_variant)
 
     def env_step_node(self, field, sun, normals, trig, trig_b_stride, c, notify=False):
         """``_EnvStep.apply`` of losses.py without the Python Function (None: binding not built).
@@ -355,22 +384,26 @@ class HipOps:
         field._ray_ws = r[3]
         return (*r[:3], *r[4:], ticket)
 
-    def splat_fwd(self, rays, xs, ys, variant=None):
+    def splat_fwd(self, rays, xs, ys, variant=None, cull=None):
+        """``cull``: hand over the device scratch (None: ``self.cull``) — False runs the dense kernel."""
         B, N, R = rays.shape[0], rays.shape[1], xs.shape[0]
+        variant = self.splat_variant if variant is None else variant
         image = torch.empty((B, R, R), dtype=torch.float32, device=rays.device)
+        _keep, sp, sn = self._scratch(self.lib.helio_fwd_scratch_bytes, B, N, R, variant, rays, cull)
         _check(self.lib, self.lib.helio_splat_fwd(
-            B, N, R, _dev(rays), _dev(xs), _dev(ys), image.data_ptr(),
-            self.splat_variant if variant is None else variant, _stream()))
+            B, N, R, _dev(rays), _dev(xs), _dev(ys), image.data_ptr(), variant, sp, sn, _stream()))
         return image
 
     # -- backward --------------------------------------------------------------------------
-    def splat_bwd(self, rays, xs, ys, grad_image, variant=None):
+    def splat_bwd(self, rays, xs, ys, grad_image, variant=None, cull=None):
         B, N, R = rays.shape[0], rays.shape[1], xs.shape[0]
+        variant = self.bwd_variant if variant is None else variant
         jb = self.lib.helio_splat_bwd_blocks(R)
         moments = torch.empty((B, jb, N, MOMENT_STRIDE), dtype=torch.float32, device=rays.device)
+        _keep, sp, sn = self._scratch(self.lib.helio_bwd_scratch_bytes, B, N, R, variant, rays, cull)
         _check(self.lib, self.lib.helio_splat_bwd(
-            B, N, R, _dev(rays), _dev(xs), _dev(ys), _dev(grad_image), moments.data_ptr(),
-            self.bwd_variant if variant is None else variant, _stream()))
+            B, N, R, _dev(rays), _dev(xs), _dev(ys), _dev(grad_image), moments.data_ptr(), variant, sp, sn,
+            _stream()))
         return moments
 
     def render_bwd(self, helios, sun, normals, trig, trig_b_stride, plane, rays, xs, ys, grad_image, grad_actual,
@@ -386,10 +419,12 @@ class HipOps:
             moments = torch.empty((B, self.lib.helio_splat_bwd_blocks(R), N, MOMENT_STRIDE), dtype=torch.float32,
                                   device=normals.device)
         ptr = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
+        _keep, sp, sn = (self._scratch(self.lib.helio_bwd_scratch_bytes, B, N, R, self.bwd_variant, normals)
+                         if moments is not None else (None, None, 0))
         _check(self.lib, self.lib.helio_render_bwd(
             B, N, R, _dev(helios), _dev(sun), _dev(normals), _dev(trig), trig_b_stride, plane, _dev(rays),
             _dev(xs), _dev(ys), ptr(grad_image), ptr(grad_actual), ptr(grad_refl), ptr(moments), grad.data_ptr(),
-            self.bwd_variant, _stream()))
+            self.bwd_variant, sp, sn, _stream()))
         return grad
 
     def geometry_bwd(self, helios, sun, normals, trig, trig_b_stride, plane, moments, grad_actual, grad_refl):

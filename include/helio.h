@@ -28,9 +28,10 @@ extern "C" {
 #endif
 
 /* Bumped when a signature or the meaning of an argument changes.  Additions that leave every existing call
- * valid do not bump it; since 1: helio_init_actions, helio_render_fwd_choice, splat variant 9, render variants
- * 10-13, backward variants 6-8 (and helio_comm_count in helio_comm.h). */
-#define HELIO_ABI_VERSION 1
+ * valid do not bump it.  2: the footprint entry points (helio_splat_fwd/bwd, helio_render_fwd/bwd,
+ * helio_env_step_fwd/bwd) take an optional device scratch buffer (scratch_d, scratch_bytes) in front of the
+ * stream — see "Device scratch" below; helio_fwd_scratch_bytes / helio_bwd_scratch_bytes size it. */
+#define HELIO_ABI_VERSION 2
 
 #define HELIO_OK            0
 #define HELIO_E_INVALID    -1   /* bad size / null pointer                       */
@@ -61,6 +62,22 @@ typedef struct helio_plane {
 #define HELIO_RAY_STRIDE 4
 /* Floats per ray and per column block in the moment buffer (splat backward). */
 #define HELIO_MOMENT_STRIDE 5
+
+/*
+ * Device scratch (optional, every footprint entry point): `scratch_d` is caller-owned device memory of
+ * `scratch_bytes` bytes, 256-byte aligned, free for the library to overwrite during the call and of no meaning
+ * afterwards; NULL = none.  With at least helio_fwd_scratch_bytes(B,N,R,variant) (forward calls) or
+ * helio_bwd_scratch_bytes(B,N,R,variant) (backward calls) bytes the large-problem kernels first compact, per
+ * image tile, the rays whose footprint is not EXACTLY zero there and walk only those.  The reference evaluates
+ * every (ray, pixel) pair (:142-148); with tens of mrad of orientation error about half of the rays of a large
+ * field miss the receiver by so many sigma that every one of their products underflows below half an ulp of
+ * any f32 accumulator — leaving them out changes no bit of any output (doodle_amd/csrc/cull.h states the
+ * criterion, which is evaluated on what the kernels compute, with a margin).  Results are IDENTICAL with and
+ * without scratch, with a buffer that is too small (the dense kernels run) and with HELIO_CULL=0; a query
+ * returns 0 when the kernel the call would run takes no scratch.
+ */
+long helio_fwd_scratch_bytes(int B, int N, int R, int variant);
+long helio_bwd_scratch_bytes(int B, int N, int R, int variant);
 
 int         helio_abi_version(void);
 const char *helio_last_error_string(void);
@@ -120,7 +137,7 @@ int helio_geometry_fwd(int B, int N,
  */
 int helio_splat_fwd(int B, int N, int R,
                     const float *rays_d, const float *xs_d, const float *ys_d,
-                    float *image_d, int variant, void *stream);
+                    float *image_d, int variant, void *scratch_d, long scratch_bytes, void *stream);
 
 /*
  * The whole forward of HelioField.render (:356-406) in one call: helio_geometry_fwd followed
@@ -134,7 +151,7 @@ int helio_render_fwd(int B, int N, int R,
                      const float *trig_d, long trig_b_stride, const helio_plane *plane,
                      const float *xs_d, const float *ys_d,
                      float *actual_d, float *refl_d, float *rays_d, float *image_d,
-                     int variant, void *stream);
+                     int variant, void *scratch_d, long scratch_bytes, void *stream);
 
 /* Kernel launches helio_render_fwd(variant 0) issues for this size: 1 (fused) or 2. */
 int helio_render_fwd_launches(int B, int N, int R);
@@ -170,7 +187,8 @@ int helio_splat_bwd_blocks(int R);
  */
 int helio_splat_bwd(int B, int N, int R,
                     const float *rays_d, const float *xs_d, const float *ys_d,
-                    const float *grad_image_d, float *moments_d, int variant, void *stream);
+                    const float *grad_image_d, float *moments_d, int variant,
+                    void *scratch_d, long scratch_bytes, void *stream);
 
 /*
  * Backward of helio_geometry_fwd: chains d(image)/d(ray parameters) (from the
@@ -203,7 +221,8 @@ int helio_render_bwd(int B, int N, int R,
                      const float *trig_d, long trig_b_stride, const helio_plane *plane,
                      const float *rays_d, const float *xs_d, const float *ys_d,
                      const float *grad_image_d, const float *grad_actual_d, const float *grad_refl_d,
-                     float *moments_d, float *grad_action_d, int variant, void *stream);
+                     float *moments_d, float *grad_action_d, int variant,
+                     void *scratch_d, long scratch_bytes, void *stream);
 
 /*
  * Replaces calculate_ideal_normals, :256-278:
@@ -306,7 +325,8 @@ int helio_env_step_fwd(int B, int N, int R,
                        const float target_position[3], const float target_normal[3],
                        float width, float height, int exponential_risk, float error_mask_ratio,
                        float *workspace_d, float *out_d, float *mae_d, float *keep_d, float *align_err_d,
-                       float *all_bounds_d, float *aux_d, int *notify, int ticket, void *stream);
+                       float *all_bounds_d, float *aux_d, int *notify, int ticket,
+                       void *scratch_d, long scratch_bytes, void *stream);
 
 /*
  * Backward of helio_env_step_fwd w.r.t. the action in one call: the cotangents of the four
@@ -332,7 +352,8 @@ int helio_env_step_bwd(int B, int N, int R,
                        float width, float height, int exponential_risk,
                        const float *g_mse_d, const float *g_dist_d, const float *g_bound_d, const float *g_align_d,
                        const float *keep_d, const float *grad_actual_d, const float *grad_refl_d,
-                       float *grad_image_ws_d, float *moments_d, float *grad_action_d, int variant, void *stream);
+                       float *grad_image_ws_d, float *moments_d, float *grad_action_d, int variant,
+                       void *scratch_d, long scratch_bytes, void *stream);
 
 #ifdef __cplusplus
 }

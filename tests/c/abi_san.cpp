@@ -44,6 +44,7 @@ int main() {
     float* const P = reinterpret_cast<float*>(uintptr_t(0x7f0000001000));
     float* const P1 = reinterpret_cast<float*>(uintptr_t(0x7f0000001004));
     void* const WS = P;
+    void* const SCR = reinterpret_cast<void*>(uintptr_t(0x7f0000004000));     // 256-byte aligned "device scratch"
     int* const REC = reinterpret_cast<int*>(uintptr_t(0x7f0000002000));
     helio_plane plane;
     memset(&plane, 0, sizeof plane);
@@ -88,56 +89,78 @@ int main() {
     EXPECT_LAUNCH(helio_geometry_fwd(B, N, P, P, P, P, 0, &plane, P, P, P, nullptr));
 
     // ---- helio_splat_fwd
-    EXPECT_INVALID(helio_splat_fwd(B, N, 0, P, P, P, P, 0, nullptr));
-    EXPECT_INVALID(helio_splat_fwd(B, N, 20000, P, P, P, P, 0, nullptr));
-    EXPECT_INVALID(helio_splat_fwd(-1, N, R, P, P, P, P, 0, nullptr));
-    EXPECT_INVALID(helio_splat_fwd(B, N, R, nullptr, P, P, P, 0, nullptr));
-    EXPECT_INVALID(helio_splat_fwd(B, N, R, P, nullptr, P, P, 0, nullptr));
-    EXPECT_INVALID(helio_splat_fwd(B, N, R, P, P, nullptr, P, 0, nullptr));
-    EXPECT_INVALID(helio_splat_fwd(B, N, R, P, P, P, nullptr, 0, nullptr));
-    EXPECT_INVALID(helio_splat_fwd(B, N, R, P1, P, P, P, 0, nullptr));
-    EXPECT_INVALID(helio_splat_fwd(B, N, R, P, P, P, P1, 0, nullptr));
-    EXPECT_LAUNCH(helio_splat_fwd(B, N, R, P, P, P, P, 0, nullptr));
+    EXPECT_INVALID(helio_splat_fwd(B, N, 0, P, P, P, P, 0, nullptr, 0, nullptr));
+    EXPECT_INVALID(helio_splat_fwd(B, N, 20000, P, P, P, P, 0, nullptr, 0, nullptr));
+    EXPECT_INVALID(helio_splat_fwd(-1, N, R, P, P, P, P, 0, nullptr, 0, nullptr));
+    EXPECT_INVALID(helio_splat_fwd(B, N, R, nullptr, P, P, P, 0, nullptr, 0, nullptr));
+    EXPECT_INVALID(helio_splat_fwd(B, N, R, P, nullptr, P, P, 0, nullptr, 0, nullptr));
+    EXPECT_INVALID(helio_splat_fwd(B, N, R, P, P, nullptr, P, 0, nullptr, 0, nullptr));
+    EXPECT_INVALID(helio_splat_fwd(B, N, R, P, P, P, nullptr, 0, nullptr, 0, nullptr));
+    EXPECT_INVALID(helio_splat_fwd(B, N, R, P1, P, P, P, 0, nullptr, 0, nullptr));
+    EXPECT_INVALID(helio_splat_fwd(B, N, R, P, P, P, P1, 0, nullptr, 0, nullptr));
+    EXPECT_LAUNCH(helio_splat_fwd(B, N, R, P, P, P, P, 0, nullptr, 0, nullptr));
+    // the optional device scratch: NULL with any size is "none"; otherwise 256-byte aligned and a size >= 0; a
+    // buffer that is too small is not an error (the dense kernels run)
+    EXPECT_INVALID(helio_splat_fwd(B, N, R, P, P, P, P, 0, P1, 1 << 20, nullptr));
+    EXPECT_INVALID(helio_splat_fwd(B, N, R, P, P, P, P, 0, reinterpret_cast<float*>(uintptr_t(0x7f0000001010)), 1 << 20, nullptr));
+    EXPECT_INVALID(helio_splat_fwd(B, N, R, P, P, P, P, 0, SCR, -1, nullptr));
+    EXPECT_LAUNCH(helio_splat_fwd(B, N, R, P, P, P, P, 0, nullptr, 12345, nullptr));
+    EXPECT_LAUNCH(helio_splat_fwd(B, N, R, P, P, P, P, 0, SCR, 1 << 20, nullptr));
+    EXPECT_LAUNCH(helio_splat_fwd(512, 2000, 512, P, P, P, P, 5, SCR, 16, nullptr));
+    EXPECT_LAUNCH(helio_splat_fwd(512, 2000, 512, P, P, P, P, 5, SCR, helio_fwd_scratch_bytes(512, 2000, 512, 5), nullptr));
+    if (helio_fwd_scratch_bytes(B, N, R, 0) != 0 || helio_fwd_scratch_bytes(0, N, R, 0) != 0 || helio_fwd_scratch_bytes(512, 2000, 512, 5) <= 0 ||
+        helio_fwd_scratch_bytes(512, 2000, 512, 12) != 0 || helio_bwd_scratch_bytes(B, N, R, 0) != 0 ||
+        helio_bwd_scratch_bytes(512, 2000, 0, 2) != 0 || helio_bwd_scratch_bytes(512, 2000, 512, 2) <= 0 ||
+        helio_bwd_scratch_bytes(512, 2000, 512, 8) != 0) { printf("FAIL scratch sizes\n"); ++failures; }
 
     // ---- helio_render_fwd
-    EXPECT_INVALID(helio_render_fwd(B, N, 0, P, P, P, P, S, &plane, P, P, P, P, P, P, 0, nullptr));
-    EXPECT_INVALID(helio_render_fwd(0, N, R, P, P, P, P, S, &plane, P, P, P, P, P, P, 0, nullptr));
-    EXPECT_INVALID(helio_render_fwd(B, N, R, nullptr, P, P, P, S, &plane, P, P, P, P, P, P, 0, nullptr));
-    EXPECT_INVALID(helio_render_fwd(B, N, R, P, P, P, P, S, &plane, nullptr, P, P, P, P, P, 0, nullptr));
-    EXPECT_INVALID(helio_render_fwd(B, N, R, P, P, P, P, S, &plane, P, nullptr, P, P, P, P, 0, nullptr));
-    EXPECT_INVALID(helio_render_fwd(B, N, R, P, P, P, P, S, &plane, P, P, nullptr, P, P, P, 0, nullptr));
-    EXPECT_INVALID(helio_render_fwd(B, N, R, P, P, P, P, S, &plane, P, P, P, P, P, nullptr, 0, nullptr));
-    EXPECT_INVALID(helio_render_fwd(B, N, R, P, P, P, P, 3, &plane, P, P, P, P, P, P, 0, nullptr));
-    EXPECT_INVALID(helio_render_fwd(B, N, R, P, P, P, P, S, &plane, P, P, P, P, P, P1, 0, nullptr));
-    EXPECT_INVALID(helio_render_fwd(B, N, R, P, P, P, P, S, &plane, P, P, P, P, P1, P, 0, nullptr));
-    EXPECT_LAUNCH(helio_render_fwd(B, N, R, P, P, P, P, S, &plane, P, P, P, nullptr, P, P, 0, nullptr));
+    EXPECT_INVALID(helio_render_fwd(B, N, 0, P, P, P, P, S, &plane, P, P, P, P, P, P, 0, nullptr, 0, nullptr));
+    EXPECT_INVALID(helio_render_fwd(0, N, R, P, P, P, P, S, &plane, P, P, P, P, P, P, 0, nullptr, 0, nullptr));
+    EXPECT_INVALID(helio_render_fwd(B, N, R, nullptr, P, P, P, S, &plane, P, P, P, P, P, P, 0, nullptr, 0, nullptr));
+    EXPECT_INVALID(helio_render_fwd(B, N, R, P, P, P, P, S, &plane, nullptr, P, P, P, P, P, 0, nullptr, 0, nullptr));
+    EXPECT_INVALID(helio_render_fwd(B, N, R, P, P, P, P, S, &plane, P, nullptr, P, P, P, P, 0, nullptr, 0, nullptr));
+    EXPECT_INVALID(helio_render_fwd(B, N, R, P, P, P, P, S, &plane, P, P, nullptr, P, P, P, 0, nullptr, 0, nullptr));
+    EXPECT_INVALID(helio_render_fwd(B, N, R, P, P, P, P, S, &plane, P, P, P, P, P, nullptr, 0, nullptr, 0, nullptr));
+    EXPECT_INVALID(helio_render_fwd(B, N, R, P, P, P, P, 3, &plane, P, P, P, P, P, P, 0, nullptr, 0, nullptr));
+    EXPECT_INVALID(helio_render_fwd(B, N, R, P, P, P, P, S, &plane, P, P, P, P, P, P1, 0, nullptr, 0, nullptr));
+    EXPECT_INVALID(helio_render_fwd(B, N, R, P, P, P, P, S, &plane, P, P, P, P, P1, P, 0, nullptr, 0, nullptr));
+    EXPECT_LAUNCH(helio_render_fwd(B, N, R, P, P, P, P, S, &plane, P, P, P, nullptr, P, P, 0, nullptr, 0, nullptr));
     // a large problem takes geometry + splat and then NEEDS the ray work buffer
-    EXPECT_INVALID(helio_render_fwd(512, 2000, 512, P, P, P, P, 8000, &plane, P, P, P, P, nullptr, P, 0, nullptr));
-    EXPECT_LAUNCH(helio_render_fwd(512, 2000, 512, P, P, P, P, 8000, &plane, P, P, P, P, P, P, 0, nullptr));
+    EXPECT_INVALID(helio_render_fwd(512, 2000, 512, P, P, P, P, 8000, &plane, P, P, P, P, nullptr, P, 0, nullptr, 0, nullptr));
+    EXPECT_LAUNCH(helio_render_fwd(512, 2000, 512, P, P, P, P, 8000, &plane, P, P, P, P, P, P, 0, nullptr, 0, nullptr));
+    EXPECT_INVALID(helio_render_fwd(512, 2000, 512, P, P, P, P, 8000, &plane, P, P, P, P, P, P, 0, P1, 1 << 20, nullptr));
+    EXPECT_INVALID(helio_render_fwd(512, 2000, 512, P, P, P, P, 8000, &plane, P, P, P, P, P, P, 0, SCR, -5, nullptr));
+    EXPECT_LAUNCH(helio_render_fwd(512, 2000, 512, P, P, P, P, 8000, &plane, P, P, P, P, P, P, 0, SCR, 1l << 30, nullptr));
     if (helio_render_fwd_launches(B, N, R) != 1 || helio_render_fwd_launches(512, 2000, 512) != 2) { printf("FAIL launches\n"); ++failures; }
     if (helio_render_fwd_choice(B, N, R) != 12 || helio_render_fwd_choice(512, 2000, 512) != 6 || helio_render_fwd_choice(0, N, R) != 0 ||
         helio_render_fwd_choice(B, N, 0) != 0) { printf("FAIL choice\n"); ++failures; }
 
     // ---- helio_splat_bwd / helio_geometry_bwd / helio_render_bwd
-    EXPECT_INVALID(helio_splat_bwd(B, N, 0, P, P, P, P, P, 0, nullptr));
-    EXPECT_INVALID(helio_splat_bwd(B, N, R, nullptr, P, P, P, P, 0, nullptr));
-    EXPECT_INVALID(helio_splat_bwd(B, N, R, P, P, P, nullptr, P, 0, nullptr));
-    EXPECT_INVALID(helio_splat_bwd(B, N, R, P, P, P, P, nullptr, 0, nullptr));
-    EXPECT_INVALID(helio_splat_bwd(B, N, R, P, P, P, P1, P, 0, nullptr));
-    EXPECT_LAUNCH(helio_splat_bwd(B, N, R, P, P, P, P, P, 0, nullptr));
+    EXPECT_INVALID(helio_splat_bwd(B, N, 0, P, P, P, P, P, 0, nullptr, 0, nullptr));
+    EXPECT_INVALID(helio_splat_bwd(B, N, R, nullptr, P, P, P, P, 0, nullptr, 0, nullptr));
+    EXPECT_INVALID(helio_splat_bwd(B, N, R, P, P, P, nullptr, P, 0, nullptr, 0, nullptr));
+    EXPECT_INVALID(helio_splat_bwd(B, N, R, P, P, P, P, nullptr, 0, nullptr, 0, nullptr));
+    EXPECT_INVALID(helio_splat_bwd(B, N, R, P, P, P, P1, P, 0, nullptr, 0, nullptr));
+    EXPECT_LAUNCH(helio_splat_bwd(B, N, R, P, P, P, P, P, 0, nullptr, 0, nullptr));
+    EXPECT_INVALID(helio_splat_bwd(B, N, R, P, P, P, P, P, 0, P1, 1 << 20, nullptr));
+    EXPECT_INVALID(helio_splat_bwd(B, N, R, P, P, P, P, P, 0, SCR, -1, nullptr));
+    EXPECT_LAUNCH(helio_splat_bwd(512, 2000, 512, P, P, P, P, P, 2, SCR, 1l << 30, nullptr));
+    EXPECT_LAUNCH(helio_splat_bwd(512, 2000, 512, P, P, P, P, P, 2, SCR, 8, nullptr));
     if (helio_splat_bwd_blocks(0) != 0 || helio_splat_bwd_blocks(129) < 1) { printf("FAIL bwd blocks\n"); ++failures; }
     EXPECT_INVALID(helio_geometry_bwd(B, N, 1, P, P, P, P, S, &plane, P, P, P, nullptr, nullptr));
     EXPECT_INVALID(helio_geometry_bwd(B, N, 0, P, P, P, P, S, &plane, P, P, P, P, nullptr));
     EXPECT_INVALID(helio_geometry_bwd(B, N, 1, P, P, P, P, 5, &plane, P, P, P, P, nullptr));
     EXPECT_INVALID(helio_geometry_bwd(B, N, 1, P, P, P, P1, S, &plane, P, P, P, P, nullptr));
     EXPECT_LAUNCH(helio_geometry_bwd(B, N, 0, P, P, P, P, S, &plane, nullptr, P, nullptr, P, nullptr));
-    EXPECT_INVALID(helio_render_bwd(B, N, R, P, P, P, P, S, &plane, P, P, P, P, P, P, nullptr, P, 0, nullptr));
-    EXPECT_INVALID(helio_render_bwd(B, N, R, P, P, P, P, S, &plane, nullptr, P, P, P, P, P, P, P, 0, nullptr));
-    EXPECT_INVALID(helio_render_bwd(B, N, R, P, P, P, P, S, &plane, P, P, P, P1, P, P, P, P, 0, nullptr));
-    EXPECT_INVALID(helio_render_bwd(B, N, R, P, P, P, P, S, &plane, P, P, P, P, P, P, P, nullptr, 0, nullptr));
-    EXPECT_INVALID(helio_render_bwd(B, 0, R, P, P, P, P, S, &plane, P, P, P, P, P, P, P, P, 0, nullptr));
-    EXPECT_LAUNCH(helio_render_bwd(B, N, R, P, P, P, P, S, &plane, P, P, P, P, P, P, P, P, 0, nullptr));
-    EXPECT_LAUNCH(helio_render_bwd(B, N, R, P, P, P, P, S, &plane, nullptr, nullptr, nullptr, nullptr, P, nullptr, nullptr, P, 0, nullptr));
+    EXPECT_INVALID(helio_render_bwd(B, N, R, P, P, P, P, S, &plane, P, P, P, P, P, P, nullptr, P, 0, nullptr, 0, nullptr));
+    EXPECT_INVALID(helio_render_bwd(B, N, R, P, P, P, P, S, &plane, nullptr, P, P, P, P, P, P, P, 0, nullptr, 0, nullptr));
+    EXPECT_INVALID(helio_render_bwd(B, N, R, P, P, P, P, S, &plane, P, P, P, P1, P, P, P, P, 0, nullptr, 0, nullptr));
+    EXPECT_INVALID(helio_render_bwd(B, N, R, P, P, P, P, S, &plane, P, P, P, P, P, P, P, nullptr, 0, nullptr, 0, nullptr));
+    EXPECT_INVALID(helio_render_bwd(B, 0, R, P, P, P, P, S, &plane, P, P, P, P, P, P, P, P, 0, nullptr, 0, nullptr));
+    EXPECT_LAUNCH(helio_render_bwd(B, N, R, P, P, P, P, S, &plane, P, P, P, P, P, P, P, P, 0, nullptr, 0, nullptr));
+    EXPECT_LAUNCH(helio_render_bwd(B, N, R, P, P, P, P, S, &plane, nullptr, nullptr, nullptr, nullptr, P, nullptr, nullptr, P, 0, nullptr, 0, nullptr));
+    EXPECT_INVALID(helio_render_bwd(B, N, R, P, P, P, P, S, &plane, P, P, P, P, P, P, P, P, 0, P1, 64, nullptr));
+    EXPECT_LAUNCH(helio_render_bwd(512, 2000, 512, P, P, P, P, 8000, &plane, P, P, P, P, P, P, P, P, 0, SCR, 1l << 30, nullptr));
 
     // ---- helio_ideal_normals / helio_distance_maps
     EXPECT_INVALID(helio_ideal_normals(B, N, nullptr, P, t3, P, nullptr));
@@ -171,9 +194,10 @@ int main() {
     EXPECT_LAUNCH(helio_step_losses_bwd(B, N, R, P, P, P, P, P, P, P, P, t3, n3, 15.f, 15.f, 0, P, nullptr, nullptr, nullptr, nullptr, P, nullptr, nullptr, nullptr));
 
     // ---- env step (fused small problem and the composed large one)
-#define STEP_FWD(Bv, Nv, Rv, helios, stride, ws, ratio, rec, ticket)                                                   \
+#define STEP_FWD(Bv, Nv, Rv, helios, stride, ws, ratio, rec, ticket) STEP_FWD_S(Bv, Nv, Rv, helios, stride, ws, ratio, rec, ticket, nullptr, 0)
+#define STEP_FWD_S(Bv, Nv, Rv, helios, stride, ws, ratio, rec, ticket, scratch, sbytes)                                                 \
     helio_env_step_fwd(Bv, Nv, Rv, helios, P, P, P, stride, &plane, P, P, P, P, P, P, 0, P, P, P, P, t3, n3, 15.f, 15.f, 0, \
-                       ratio, ws, P, P, P, P, P, P, rec, ticket, nullptr)
+                       ratio, ws, P, P, P, P, P, P, rec, ticket, scratch, sbytes, nullptr)
     EXPECT_INVALID(STEP_FWD(B, N, R, P, S, P, -1.f, REC, 0));                 // ticket 0 is reserved
     EXPECT_INVALID(STEP_FWD(B, N, R, nullptr, S, P, -1.f, nullptr, 0));
     EXPECT_INVALID(STEP_FWD(B, N, R, P, S + 4, P, -1.f, nullptr, 0));
@@ -183,10 +207,14 @@ int main() {
     EXPECT_INVALID(STEP_FWD(B, N, 0, P, S, P, -1.f, nullptr, 0));
     EXPECT_LAUNCH(STEP_FWD(B, N, R, P, S, P, 0.2f, REC, 7));
     EXPECT_LAUNCH(STEP_FWD(512, 2000, 512, P, 8000, P, -1.f, nullptr, 0));
+    EXPECT_INVALID(STEP_FWD_S(B, N, R, P, S, P, -1.f, nullptr, 0, P1, 64));
+    EXPECT_INVALID(STEP_FWD_S(512, 2000, 512, P, 8000, P, -1.f, nullptr, 0, SCR, -1));
+    EXPECT_LAUNCH(STEP_FWD_S(512, 2000, 512, P, 8000, P, -1.f, nullptr, 0, SCR, 1l << 30));
     if (helio_env_step_launches(B, N, R) != 2 || helio_env_step_launches(512, 2000, 512) != 4) { printf("FAIL step launches\n"); ++failures; }
-#define STEP_BWD(Bv, Nv, Rv, stride, rays, gmse, gws, mom, grad)                                                        \
+#define STEP_BWD(Bv, Nv, Rv, stride, rays, gmse, gws, mom, grad) STEP_BWD_S(Bv, Nv, Rv, stride, rays, gmse, gws, mom, grad, nullptr, 0)
+#define STEP_BWD_S(Bv, Nv, Rv, stride, rays, gmse, gws, mom, grad, scratch, sbytes)                                                     \
     helio_env_step_bwd(Bv, Nv, Rv, P, P, P, P, stride, &plane, rays, P, P, P, P, P, P, P, t3, n3, 15.f, 15.f, 0, gmse, \
-                       nullptr, nullptr, P, nullptr, nullptr, nullptr, gws, mom, grad, 0, nullptr)
+                       nullptr, nullptr, P, nullptr, nullptr, nullptr, gws, mom, grad, 0, scratch, sbytes, nullptr)
     EXPECT_INVALID(STEP_BWD(B, N, R, S, P, P, P, P, nullptr));
     EXPECT_INVALID(STEP_BWD(B, N, R, S, nullptr, P, P, P, P));
     EXPECT_INVALID(STEP_BWD(B, N, R, S, P, P, P, nullptr, P));
@@ -197,6 +225,8 @@ int main() {
     EXPECT_LAUNCH(STEP_BWD(B, N, R, S, P, P, P, P, P));
     EXPECT_LAUNCH(STEP_BWD(40, 300, 256, 1200, P, P, P, P, P));
     EXPECT_LAUNCH(STEP_BWD(B, N, R, S, nullptr, nullptr, nullptr, nullptr, P));  // alignment only: no image path
+    EXPECT_INVALID(STEP_BWD_S(B, N, R, S, P, P, P, P, P, P1, 64));
+    EXPECT_LAUNCH(STEP_BWD_S(512, 2000, 512, 8000, P, P, P, P, P, SCR, 1l << 30));
 
     // ---- completion record
     EXPECT_INVALID(helio_notify_create(nullptr));

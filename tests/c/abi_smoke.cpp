@@ -83,9 +83,26 @@ int main(int argc, char** argv) {
     int worst = 0;
     const int variants[] = {0, 1, 3, 4, 5, 6};
     for (int variant : variants) {
+        // the optional device scratch (helio.h "Device scratch"): with it the large-problem kernels skip the rays
+        // that are exactly zero on a tile; 0 bytes where the kernel this call runs takes none
+        const long sbytes = helio_fwd_scratch_bytes(B, N, R, variant);
+        void* d_scratch = nullptr;
+        if (sbytes > 0) HIP_OK(hipMalloc(&d_scratch, (size_t)sbytes));
         ABI_OK(helio_render_fwd(B, N, R, d_h, d_s, d_a, d_t, 4l * N, &plane, d_x, d_y, d_actual, d_refl, d_rays, d_img,
-                                variant, st));
+                                variant, d_scratch, sbytes, st));
         HIP_OK(hipStreamSynchronize(st));
+        if (d_scratch) {            // and the same call without scratch gives the same bits
+            std::vector<float> with(img.size()), without(img.size());
+            HIP_OK(hipMemcpy(with.data(), d_img, 4ul * B * R * R, hipMemcpyDeviceToHost));
+            ABI_OK(helio_render_fwd(B, N, R, d_h, d_s, d_a, d_t, 4l * N, &plane, d_x, d_y, d_actual, d_refl, d_rays, d_img,
+                                    variant, nullptr, 0, st));
+            HIP_OK(hipStreamSynchronize(st));
+            HIP_OK(hipMemcpy(without.data(), d_img, 4ul * B * R * R, hipMemcpyDeviceToHost));
+            const bool same = memcmp(with.data(), without.data(), 4ul * B * R * R) == 0;
+            printf("variant %d: %ld bytes of scratch, image %s the dense kernel's\n", variant, sbytes, same ? "bit-identical with" : "DIFFERS from");
+            worst |= !same;
+            HIP_OK(hipFree(d_scratch));
+        }
         HIP_OK(hipMemcpy(actual.data(), d_actual, 12ul * B * N, hipMemcpyDeviceToHost));
         HIP_OK(hipMemcpy(refl.data(), d_refl, 12ul * B * N, hipMemcpyDeviceToHost));
         HIP_OK(hipMemcpy(img.data(), d_img, 4ul * B * R * R, hipMemcpyDeviceToHost));
@@ -124,10 +141,10 @@ int main(int argc, char** argv) {
         HIP_OK(hipMalloc(&d_allb, 4ul * B * N)); HIP_OK(hipMalloc(&d_img2, 4ul * B * R * R));
         int* record = nullptr;
         ABI_OK(helio_notify_create(&record));
-        ABI_OK(helio_render_fwd(B, N, R, d_h, d_s, d_a, d_t, 4l * N, &plane, d_x, d_y, d_actual, d_refl, d_rays, d_img, 0, st));
+        ABI_OK(helio_render_fwd(B, N, R, d_h, d_s, d_a, d_t, 4l * N, &plane, d_x, d_y, d_actual, d_refl, d_rays, d_img, 0, nullptr, 0, st));
         ABI_OK(helio_env_step_fwd(B, N, R, d_h, d_s, d_a, d_t, 4l * N, &plane, d_x, d_y, d_actual, d_refl, d_rays, d_img2, 0,
                                   d_target, d_tx, d_dm, d_ideal, tp, tn, 15.0f, 15.0f, 0, -1.0f, d_ws, d_out, d_mae, d_keep,
-                                  d_align, d_allb, nullptr, record, 7, st));
+                                  d_align, d_allb, nullptr, record, 7, nullptr, 0, st));
         const int flag = helio_notify_wait(record, 7, 10.0);       // returns once the finishing workgroup has published
         std::vector<float> img2((size_t)B * R * R), mae(B);
         float out[5];
@@ -160,8 +177,8 @@ int main(int argc, char** argv) {
         ABI_OK(helio_notify_destroy(record));
     }
     // error behaviour: invalid arguments are refused before any launch
-    if (helio_render_fwd(0, N, R, d_h, d_s, d_a, d_t, 4l * N, &plane, d_x, d_y, d_actual, d_refl, d_rays, d_img, 0, st) != HELIO_E_INVALID) worst = 1;
-    if (helio_render_fwd(B, N, R, nullptr, d_s, d_a, d_t, 4l * N, &plane, d_x, d_y, d_actual, d_refl, d_rays, d_img, 0, st) != HELIO_E_INVALID) worst = 1;
+    if (helio_render_fwd(0, N, R, d_h, d_s, d_a, d_t, 4l * N, &plane, d_x, d_y, d_actual, d_refl, d_rays, d_img, 0, nullptr, 0, st) != HELIO_E_INVALID) worst = 1;
+    if (helio_render_fwd(B, N, R, nullptr, d_s, d_a, d_t, 4l * N, &plane, d_x, d_y, d_actual, d_refl, d_rays, d_img, 0, nullptr, 0, st) != HELIO_E_INVALID) worst = 1;
     printf(worst ? "ABI SMOKE FAILED\n" : "ABI SMOKE OK\n");
     return worst;
 }

@@ -47,7 +47,8 @@ class OracleOps:
             actual, refl, rays = self._forward(helios, sun, normals, trig, trig_b_stride, plane)
         return actual.contiguous(), (refl.contiguous() if want_refl else None), (rays.contiguous() if want_rays else None)
 
-    def render_fwd(self, helios, sun, normals, trig, trig_b_stride, plane, xs, ys, want_refl=True, rays=None):
+    def render_fwd(self, helios, sun, normals, trig, trig_b_stride, plane, xs, ys, want_refl=True, rays=None,
+                   variant=None):
         actual, refl, r = self.geometry_fwd(helios, sun, normals, trig, trig_b_stride, plane, want_refl, True)
         return self.splat_fwd(r, xs, ys), actual, refl, r
 

@@ -1,0 +1,287 @@
+"""Skipping exactly-zero rays (doodle_amd/csrc/cull.h) changes NO bit: the culled kernels against the dense
+ones through the C ABI — forward images, backward moments, gradients — on seeded fields at odd sizes, on
+hand-made rays that sit on the criterion's threshold, and at BASELINE.json's full config-4 / config-5
+launches, where the LAST suns of the batch are also held to the oracle (the launches bench.py times).
+The reference evaluates every (ray, pixel) pair: newenv_rl_test_multi_error.py:142-148, :404-406.
+Run with ``-m gpu``."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import torch_oracle as to
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def bits(t):
+    return t.contiguous().view(torch.int32)
+
+
+def same_bits(a, b):
+    return torch.equal(bits(a), bits(b))
+
+
+def field_and_rays(N, B, R, sigma, err, seed=0, normal=(0.0, 1.0, 0.0), span=10.0):
+    """A seeded synthetic field, its suns / actions, and the (a, b, k2, c2) rays the geometry kernel makes."""
+    from doodle_amd import HelioField, native, synthetic
+    w = synthetic.Workload("t", N=N, B=B, R=R, sigma_scale=sigma, error_scale_mrad=err, span=span)
+    helios, suns, errs, noise = synthetic.make_inputs(w, seed)
+    f = HelioField(helios, synthetic.TARGET_POSITION, synthetic.TARGET_AREA, normal, error_scale_mrad=err,
+                   sigma_scale=sigma, resolution=R, device=DEV, max_batch_size=max(B, 2))
+    f.error_angles_mrad = errs[0]
+    f.batch_error_angles_mrad = errs if B > 1 else errs.repeat(2, 1, 1)
+    ideal = f.calculate_ideal_normals(suns)
+    act = ideal + noise.to(DEV)
+    act = (act / act.norm(dim=2, keepdim=True)).contiguous()
+    ops = native.get_ops()
+    trig, stride = f._select_trig(B)
+    _, _, rays = ops.geometry_fwd(f.heliostat_positions, suns.to(DEV), act, trig, stride, f._plane)
+    return f, suns.to(DEV), act, rays
+
+
+def splat_with_counts(rays, xs, ys, variant):
+    """helio_splat_fwd with a scratch buffer of the test's own → (image, live counts per (image, tile) | None)."""
+    from doodle_amd import native
+    ops = native.get_ops()
+    B, N, R = rays.shape[0], rays.shape[1], xs.shape[0]
+    n = ops.lib.helio_fwd_scratch_bytes(B, N, R, variant)
+    image = torch.empty((B, R, R), dtype=torch.float32, device=rays.device)
+    scratch = torch.full((max(n, 1),), 0x7F, dtype=torch.uint8, device=rays.device)
+    rc = ops.lib.helio_splat_fwd(B, N, R, rays.data_ptr(), xs.data_ptr(), ys.data_ptr(), image.data_ptr(), variant,
+                                 scratch.data_ptr() if n else None, n, native._stream())
+    assert rc == 0, ops.lib.helio_last_error_string()
+    if not n:
+        return image, None
+    tiles = {5: 256, 3: 128, 4: 128}[variant]
+    t = -(-R // tiles)
+    return image, scratch[:4 * B * t * t].view(torch.int32).view(B, t * t).clone()
+
+
+@pytest.mark.parametrize("N,B,R", [(257, 3, 260), (333, 2, 200), (700, 2, 512), (192, 5, 129)])
+@pytest.mark.parametrize("sigma,err", [(0.01, 90.0), (0.01, 180.0), (0.01, 0.0), (0.1, 90.0), (0.002, 20.0)])
+def test_culled_forward_kernels_equal_the_dense_ones_bit_for_bit(N, B, R, sigma, err):
+    from doodle_amd import native
+    ops = native.get_ops()
+    normal = (0.0, 1.0, 0.0) if (N + B) % 2 else (0.2, 0.95, -0.1)
+    f, suns, act, rays = field_and_rays(N, B, R, sigma, err, seed=N + R, normal=normal, span=30.0)
+    for variant in (3, 4, 5):
+        dense = ops.splat_fwd(rays, f._xs, f._ys, variant=variant, cull=False)
+        culled, counts = splat_with_counts(rays, f._xs, f._ys, variant)
+        assert counts is not None and int(counts.min()) >= 0 and int(counts.max()) <= N
+        assert same_bits(culled, dense), (variant, (culled - dense).abs().max().item())
+        assert same_bits(ops.splat_fwd(rays, f._xs, f._ys, variant=variant, cull=True), dense)
+        if err == 0.0 or sigma == 0.1:
+            assert int(counts.min()) == N                    # every footprint reaches the receiver: nothing to skip
+        if sigma == 0.01 and err >= 90.0:
+            assert int(counts.sum()) < 0.8 * counts.numel() * N      # and here a good part of the field misses it
+    # the kernels that round at chunk or part boundaries, and the split-bf16 ones, take no list
+    for variant in (1, 6, 7, 8, 9):
+        assert ops.lib.helio_fwd_scratch_bytes(B, N, R, variant) == 0
+
+
+def threshold_rays(N, B, R, seed):
+    """Hand-made (a, b, k2, c2): footprints whose smallest exponent over the image lies within a few units of the
+    criterion's threshold (152) on either side — products around 2^-150, denormal and zero pixels —, plus rays on
+    the receiver, plane-parallel rays (k2 = 0: 1.0 everywhere), huge and NaN parameters."""
+    g = torch.Generator().manual_seed(seed)
+    half = 7.5
+    k2 = 10.0 ** (torch.rand(B, N, generator=g) * 6 - 3)                    # 1e-3 … 1e3
+    want = 130.0 + 40.0 * torch.rand(B, N, generator=g)                     # target exponent of the nearest pixel
+    share = torch.rand(B, N, generator=g)                                   # how it splits between the two axes
+    dx, dy = torch.sqrt(want * share / k2), torch.sqrt(want * (1 - share) / k2)
+    sx = torch.where(torch.rand(B, N, generator=g) < 0.5, -1.0, 1.0)
+    sy = torch.where(torch.rand(B, N, generator=g) < 0.5, -1.0, 1.0)
+    a, b = sx * (half + dx), sy * (half + dy)                               # xs + a is nearest to 0 at one edge of the image
+    c2 = torch.where(torch.rand(B, N, generator=g) < 0.3, torch.rand(B, N, generator=g) * 5.0 / k2, torch.zeros(B, N))
+    rays = torch.stack([a, b, k2, c2], dim=2)
+    kind = torch.randint(0, 12, (B, N), generator=g)
+    rays[kind == 0] = torch.tensor([0.3, -1.2, 0.8, 0.01])                  # a spot on the receiver
+    rays[kind == 1] = torch.tensor([1.0e4, -2.0e4, 0.0, 3.0])               # plane-parallel: adds exactly 1.0 per pixel
+    rays[kind == 2] = torch.tensor([3.0e18, 1.0, 1.0e6, 0.0])               # q² overflows: factor exactly 0
+    rays[0, 5] = torch.tensor([float("nan"), 0.0, 1.0, 0.0])                # (image 0 only: a NaN ray makes its image NaN)
+    rays[0, 7] = torch.tensor([0.0, 0.0, float("nan"), 0.0])
+    return rays.contiguous()
+
+
+@pytest.mark.parametrize("N,B,R,seed", [(256, 2, 260, 0), (500, 3, 512, 1), (1024, 2, 129, 2)])
+def test_rays_on_the_threshold_of_the_criterion(N, B, R, seed):
+    from doodle_amd import native
+    ops = native.get_ops()
+    rays = threshold_rays(N, B, R, seed).to(DEV)
+    xs = torch.linspace(-7.5, 7.5, R).to(DEV)
+    ys = torch.linspace(-7.5, 7.5, R).to(DEV)
+    for variant in (3, 4, 5):
+        dense = ops.splat_fwd(rays, xs, ys, variant=variant, cull=False)
+        culled, counts = splat_with_counts(rays, xs, ys, variant)
+        both_nan = torch.isnan(dense) & torch.isnan(culled)
+        assert torch.equal(bits(culled)[~both_nan], bits(dense)[~both_nan]), variant
+        assert torch.equal(torch.isnan(dense), torch.isnan(culled))
+        assert 0 < int(counts.sum()) < counts.numel() * N              # some are dropped, some are kept
+    # … and the backward's criterion (a factor table that is all zero) on the same rays; NaN rays aside
+    finite = rays.clone()
+    finite[torch.isnan(finite).any(dim=2)] = torch.tensor([0.1, 0.2, 0.5, 0.0], device=DEV)
+    G = torch.randn(B, R, R, device=DEV, generator=torch.Generator(device=DEV).manual_seed(seed)) * 1e6
+    dense_m = ops.splat_bwd(finite, xs, ys, G, variant=2, cull=False)
+    culled_m = ops.splat_bwd(finite, xs, ys, G, variant=2, cull=True)
+    assert same_bits(culled_m, dense_m)
+
+
+@pytest.mark.parametrize("N,B,R", [(257, 3, 260), (700, 2, 512), (1000, 2, 128), (300, 4, 200)])
+@pytest.mark.parametrize("sigma,err", [(0.01, 90.0), (0.01, 180.0), (0.1, 90.0)])
+def test_culled_backward_moments_equal_the_dense_ones_bit_for_bit(N, B, R, sigma, err):
+    from doodle_amd import native
+    ops = native.get_ops()
+    f, suns, act, rays = field_and_rays(N, B, R, sigma, err, seed=N + R + 1, span=30.0)
+    G = torch.randn(B, R, R, device=DEV, generator=torch.Generator(device=DEV).manual_seed(3))
+    assert ops.lib.helio_bwd_scratch_bytes(B, N, R, 2) == ((4 * B + 255) // 256) * 256 + 4 * B * N
+    dense = ops.splat_bwd(rays, f._xs, f._ys, G, variant=2, cull=False)
+    culled = ops.splat_bwd(rays, f._xs, f._ys, G, variant=2, cull=True)
+    assert same_bits(culled, dense), (culled - dense).abs().max().item()
+    if sigma == 0.01:                                    # some rays ARE dropped: their moments read exactly +0
+        dead = (culled.abs().sum(dim=(1, 3)) == 0)
+        assert dead.any()
+        assert not (bits(culled)[dead[:, None, :, None].expand_as(culled)] != 0).any()
+    for variant in (1, 3, 4, 5, 6, 7):
+        assert ops.lib.helio_bwd_scratch_bytes(B, N, R, variant) == 0
+
+
+def test_render_autograd_and_env_step_are_unchanged_by_the_culling():
+    """Through the Python surface at a size whose kernels take the lists (128² forward tiles, 256-ray backward
+    tiles): render, its autograd gradient and HelioEnv.step with dist.backward(), scratch on and off."""
+    from doodle_amd import native
+    from doodle_amd.env import HelioEnv
+    ops = native.get_ops()
+    N, B, R = 600, 48, 256
+    f, suns, act, _ = field_and_rays(N, B, R, 0.01, 90.0, seed=11, span=40.0)
+    assert ops.lib.helio_fwd_scratch_bytes(B, N, R, 0) > 0 and ops.lib.helio_bwd_scratch_bytes(B, N, R, 0) > 0
+    G = torch.randn(B, R, R, device=DEV, generator=torch.Generator(device=DEV).manual_seed(1))
+    out = {}
+    for cull in (True, False):
+        ops.cull = cull
+        try:
+            a = act.reshape(B, -1).clone().requires_grad_(True)
+            img, actual, refl = f.render(suns, a, None, monitor=True)
+            (grad,) = torch.autograd.grad((img * G).sum() + actual.sum(), a)
+            with torch.no_grad():
+                img_ng, _ = f.render(suns, a.detach(), None)
+            vg = f.render_value_and_grad(suns, a.detach(), grad_image=G)
+            out[cull] = (img.detach(), actual.detach(), refl.detach(), grad, img_ng, vg[0], vg[2])
+        finally:
+            ops.cull = True
+    for x, y in zip(out[True], out[False]):
+        assert same_bits(x, y)
+    assert same_bits(out[True][0], out[True][4]) and same_bits(out[True][3], out[True][6])
+
+    env = HelioEnv(f.heliostat_positions, torch.tensor([0.0, -5.0, 0.0], device=DEV), (15.0, 15.0),
+                   torch.tensor([0.0, 1.0, 0.0], device=DEV), sigma_scale=0.01, error_scale_mrad=90.0, resolution=R,
+                   batch_size=B, device=DEV, new_errors_every_reset=False)
+    env.set_sun_pos(suns)
+    env.reset()
+    res = {}
+    for cull in (True, False):
+        ops.cull = cull
+        try:
+            a = act.reshape(B, -1).clone().requires_grad_(True)
+            obs, metrics, _ = env.step(a)
+            (ga,) = torch.autograd.grad(metrics["dist"] + metrics["mse"], a)
+            res[cull] = (obs["img"].detach(), metrics["dist"].detach(), metrics["mse"].detach(), ga)
+        finally:
+            ops.cull = True
+    for x, y in zip(res[True], res[False]):
+        assert same_bits(x, y)
+
+
+def _full_batch(cfg, seed, b_offset=0):
+    from doodle_amd import HelioField, synthetic
+    w = synthetic.CONFIGS[cfg]
+    B = 512
+    helios, suns, errs, noise = synthetic.make_inputs(w, seed, b_offset=b_offset, b_count=B)
+    f = HelioField(helios, synthetic.TARGET_POSITION, synthetic.TARGET_AREA, synthetic.TARGET_NORMAL,
+                   error_scale_mrad=w.error_scale_mrad, sigma_scale=w.sigma_scale, resolution=w.R, device=DEV,
+                   max_batch_size=B)
+    f.batch_error_angles_mrad = errs
+    sc = to.Scene.build(helios, synthetic.TARGET_POSITION, synthetic.TARGET_AREA, synthetic.TARGET_NORMAL, w.R, w.sigma_scale)
+    ideal = to.ideal_normals(helios, sc.target_position, suns)
+    act = ideal + noise
+    act = (act / act.norm(dim=2, keepdim=True)).reshape(B, -1)
+    return w, f, sc, suns, errs, act
+
+
+@pytest.mark.parametrize("cfg,seed,b_offset,last", [("cfg4", 0, 0, (509, 510, 511)), ("cfg5", 0, 1024, (511,))])
+def test_the_full_batch_launches_bench_times_are_held_to_the_oracle(cfg, seed, b_offset, last):
+    """BASELINE config 4 (N=2000, R=512) and one rank's shard of config 5 (N=5000, R=256) at the FULL batch of 512
+    suns — the launches bench.py times: 2048 / 512 workgroups of splat_fwd_mfma_tile<4>, image offsets up to
+    537 MB, blockIdx.y up to 511.  (a) the culled and the dense launch agree bit for bit on all 512 images;
+    (b) rows [0:24] are the bits of a 24-sun launch forced to the same kernel; (c) the LAST suns of the batch
+    meet the oracle (rtol 1e-5 / atol 1e-8 and max|Δ| ≤ 1e-5·peak); (d) the full-batch backward
+    (splat_bwd_mfma<0/1>, culled and dense bit-identical) gives the oracle's gradient for sun 511
+    (max|Δ| ≤ 2e-4·max|grad|; oracle chunked over heliostats, newenv_rl_test_multi_error.py:404-406)."""
+    from doodle_amd import native
+    ops = native.get_ops()
+    w, f, sc, suns, errs, act = _full_batch(cfg, seed, b_offset)
+    B, N, R = 512, w.N, w.R
+    assert ops.lib.helio_render_fwd_choice(B, N, R) == 5 and ops.lib.helio_fwd_scratch_bytes(B, N, R, 0) > 0
+    a_dev = act.to(DEV).requires_grad_(True)
+    img, actual = f.render(suns, a_dev, None)                                     # default: culled tile<4>
+    ops.cull = False
+    try:
+        with torch.no_grad():
+            img_dense, _ = f.render(suns, a_dev.detach(), None)
+    finally:
+        ops.cull = True
+    assert same_bits(img.detach(), img_dense)                                     # (a)
+    with torch.no_grad():
+        img24, _, _ = f.render_rows(suns[:24], a_dev.detach()[:24], 0, B)          # forced to the whole batch's kernel
+    assert same_bits(img24, img_dense[:24])                                       # (b)
+    del img_dense, img24
+    rows = list(last)
+    img_o, actual_o = to.render_chunked(sc, suns[rows], act[rows], errs[rows], b_chunk=1, n_chunk=50)
+    assert np.array_equal(actual.detach()[rows].cpu().numpy(), actual_o.numpy())
+    got = img.detach()[rows].cpu()
+    np.testing.assert_allclose(got.numpy(), img_o.numpy(), rtol=1e-5, atol=1e-8)  # (c)
+    for k in range(len(rows)):
+        assert (got[k] - img_o[k]).abs().max().item() <= 1e-5 * img_o[k].max().item()
+
+    gen = torch.Generator().manual_seed(5)
+    G_last, H_last = torch.randn(1, R, R, generator=gen), torch.randn(1, N, 3, generator=gen)
+    G = torch.randn(B, R, R, device=DEV, generator=torch.Generator(device=DEV).manual_seed(2))
+    H = torch.randn(B, N, 3, device=DEV, generator=torch.Generator(device=DEV).manual_seed(3))
+    G[511], H[511] = G_last[0].to(DEV), H_last[0].to(DEV)
+    loss = (img * G).sum() + (actual * H).sum()
+    assert ops.lib.helio_bwd_scratch_bytes(B, N, R, 0) > 0
+    (grad,) = torch.autograd.grad(loss, a_dev, retain_graph=True)
+    ops.cull = False
+    try:
+        (grad_dense,) = torch.autograd.grad(loss, a_dev)
+    finally:
+        ops.cull = True
+    assert same_bits(grad, grad_dense)
+    assert torch.isfinite(grad).all()
+    grad_o = to.grad_action_chunked(sc, suns[511:], act[511:], errs[511:], G_last, H_last, n_chunk=25)
+    err = (grad[511:].cpu().reshape(grad_o.shape) - grad_o).abs().max().item()
+    assert err <= 2e-4 * grad_o.abs().max().item(), err / grad_o.abs().max().item()   # (d)
+
+
+def test_scratch_that_is_missing_or_too_small_runs_the_dense_kernels():
+    from doodle_amd import native
+    ops = native.get_ops()
+    f, suns, act, rays = field_and_rays(400, 3, 260, 0.01, 90.0, seed=4, span=30.0)
+    B, N, R = 3, 400, 260
+    need = ops.lib.helio_fwd_scratch_bytes(B, N, R, 5)
+    dense = ops.splat_fwd(rays, f._xs, f._ys, variant=5, cull=False)
+    for nbytes in (0, 256, need - 256, need, need + 4096):
+        image = torch.empty_like(dense)
+        scratch = torch.full((max(nbytes, 1),), 0xAB, dtype=torch.uint8, device=DEV)
+        guard = scratch.clone()
+        rc = ops.lib.helio_splat_fwd(B, N, R, rays.data_ptr(), f._xs.data_ptr(), f._ys.data_ptr(), image.data_ptr(), 5,
+                                     scratch.data_ptr(), nbytes, native._stream())
+        assert rc == 0 and same_bits(image, dense)
+        if nbytes < need:
+            assert torch.equal(scratch, guard)           # a buffer that is too small is not touched
+    misaligned = torch.empty(need + 512, dtype=torch.uint8, device=DEV)
+    rc = ops.lib.helio_splat_fwd(B, N, R, rays.data_ptr(), f._xs.data_ptr(), f._ys.data_ptr(), dense.data_ptr(), 5,
+                                 ctypes.c_void_p(misaligned.data_ptr() + 16), need, native._stream())
+    assert rc == -1 and b"256-byte" in ops.lib.helio_last_error_string()

@@ -37,7 +37,7 @@ def test_library_exports_every_declared_symbol():
     lib = native.load_library()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.helio_abi_version() == 1
+    assert lib.helio_abi_version() == native.ABI_VERSION
     assert lib.helio_splat_bwd_blocks(128) == 2 and lib.helio_splat_bwd_blocks(100) == 2
 
 
@@ -58,7 +58,7 @@ def test_abi_rejects_bad_arguments_without_launching():
     plane = native.Plane()
     assert lib.helio_geometry_fwd(0, 5, None, None, None, None, 0, plane, None, None, None, None) == -1
     assert b"bad sizes" in lib.helio_last_error_string()
-    assert lib.helio_splat_fwd(1, 1, 8, None, None, None, None, 0, None) == -1
+    assert lib.helio_splat_fwd(1, 1, 8, None, None, None, None, 0, None, 0, None) == -1
     assert lib.helio_render_fwd_launches(25, 50, 128) == 1 and lib.helio_render_fwd_launches(512, 2000, 512) == 2
     assert b"null pointer" in lib.helio_last_error_string()
     # the env-step entry points: size queries and argument checks are host code
@@ -68,9 +68,16 @@ def test_abi_rejects_bad_arguments_without_launching():
     assert lib.helio_env_step_bwd_image_ws(500, 1, 128) == 0 and lib.helio_env_step_bwd_image_ws(25, 50, 128) == 1
     f3 = (ctypes.c_float * 3)()
     assert lib.helio_env_step_fwd(25, 50, 128, *([None] * 4), 0, plane, *([None] * 6), 0, *([None] * 4), f3, f3, 15.0, 15.0,
-                                  0, -1.0, *([None] * 7), None, 0, None) == -1
+                                  0, -1.0, *([None] * 7), None, 0, None, 0, None) == -1
     assert lib.helio_env_step_bwd(25, 50, 128, *([None] * 4), 0, plane, *([None] * 8), f3, f3, 15.0, 15.0, 0,
-                                  *([None] * 10), 0, None) == -1
+                                  *([None] * 10), 0, None, 0, None) == -1
+    # the optional device scratch (helio.h "Device scratch"): sized by host code; nothing for the small problems
+    assert lib.helio_fwd_scratch_bytes(25, 50, 128, 0) == 0 and lib.helio_bwd_scratch_bytes(25, 50, 128, 0) == 0
+    t = 4 * 512 * 4                       # int counts[B · tiles²], tiles² = 4 at R = 512 with 256² tiles
+    assert lib.helio_fwd_scratch_bytes(512, 2000, 512, 0) == t + 16 * 512 * 4 * 2000
+    assert lib.helio_fwd_scratch_bytes(512, 2000, 512, 6) == 0 and lib.helio_fwd_scratch_bytes(512, 2000, 512, 7) == 0
+    assert lib.helio_bwd_scratch_bytes(512, 2000, 512, 0) == 4 * 512 + 4 * 512 * 2000
+    assert lib.helio_bwd_scratch_bytes(512, 2000, 512, 5) == 0 and lib.helio_bwd_scratch_bytes(512, 200, 512, 0) == 0
     assert lib.helio_notify_wait(None, 1, 0.0) == -1 and lib.helio_notify_destroy(None) == 0
 
 

@@ -19,7 +19,10 @@ _, _, rays = ops.geometry_fwd(f.heliostat_positions, suns_d, normals, trig, stri
 G = torch.randn(w.B, w.R, w.R, device=dev)
 lib = ops.lib
 mom = torch.empty(w.B, lib.helio_splat_bwd_blocks(w.R), w.N, 5, device=dev)
-args = (w.B, w.N, w.R, rays.data_ptr(), f._xs.data_ptr(), f._ys.data_ptr(), G.data_ptr(), mom.data_ptr(), 2, native._stream())
+nb = lib.helio_bwd_scratch_bytes(w.B, w.N, w.R, 2) if os.environ.get("CULL", "1") == "1" else 0
+scratch = torch.empty(max(nb, 1), dtype=torch.uint8, device=dev)
+args = (w.B, w.N, w.R, rays.data_ptr(), f._xs.data_ptr(), f._ys.data_ptr(), G.data_ptr(), mom.data_ptr(), 2,
+        scratch.data_ptr() if nb else None, nb, native._stream())
 t = time_kernel(lambda: lib.helio_splat_bwd(*args), iters)
 fl = 2 * 2.0 * w.B * w.N * w.R * w.R
-print(f"{w.name}: splat_bwd_mfma (two passes) {t*1e6:.1f} us = {fl/t/1e12:.1f} TFLOP/s = {fl/t/1e12/157.3:.3f} of the f32 MFMA peak")
+print(f"{w.name} ({'culled' if nb else 'dense'}): splat_bwd_mfma (two passes) {t*1e6:.1f} us = {fl/t/1e12:.1f} TFLOP/s = {fl/t/1e12/157.3:.3f} of the f32 MFMA peak")

@@ -18,7 +18,7 @@ for name, N, B, R in (("cfg2", 50, 25, 128), ("cfg1", 50, 1, 128), ("ttt", 1, 50
     normals = act.reshape(B, N, 3).contiguous()
     actual = torch.empty_like(normals); rays = torch.empty(B, N, 4, device=dev); img = torch.empty(B, R, R, device=dev)
     args = (B, N, R, f.heliostat_positions.data_ptr(), suns_d.data_ptr(), normals.data_ptr(), trig.data_ptr(), stride, f._plane,
-            f._xs.data_ptr(), f._ys.data_ptr(), actual.data_ptr(), None, rays.data_ptr(), img.data_ptr(), 0, st)
+            f._xs.data_ptr(), f._ys.data_ptr(), actual.data_ptr(), None, rays.data_ptr(), img.data_ptr(), 0, None, 0, st)
     assert lib.helio_render_fwd_launches(B, N, R) == 1
     t = min(time_kernel(lambda: lib.helio_render_fwd(*args), 3000, warm=300) for _ in range(3))
     out.append(f"{name}(N={N},B={B},R={R}) {t*1e6:6.2f} us")

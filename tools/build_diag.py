@@ -1,12 +1,15 @@
 #!/usr/bin/env python3
-"""Build doodle_amd/libhelio_diag.so: the same sources as libhelio.so with -DHELIO_STAMPS, i.e. with
+"""Build libhelio_diag.so (in the temporary directory, never in the tree): the same sources as libhelio.so with -DHELIO_STAMPS, i.e. with
 s_memtime stamps compiled into the fused small-problem kernel (csrc/splat_fwd.hip).  A diagnostic
 build only: the product library never carries a stamp (cdna_hip_programming.md §7)."""
 import os, subprocess, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from doodle_amd import build as hb
 
-OUT = os.path.join(hb.HERE, "libhelio_diag.so")
+import tempfile
+
+# built on demand, OUTSIDE the tree: a diagnostic library must not travel with the product
+OUT = os.path.join(tempfile.gettempdir(), "libhelio_diag.so")
 
 
 def build():

@@ -39,7 +39,7 @@ print("data_ptr                 %.2f" % t(lambda: normals.data_ptr()))
 print("is_grad_enabled+req      %.2f" % t(lambda: torch.is_grad_enabled() and normals.requires_grad))
 ga = (B, N, f.heliostat_positions.data_ptr(), s.data_ptr(), normals.data_ptr(), trig.data_ptr(), stride, f._plane, actual.data_ptr(), None, rays.data_ptr(), st)
 print("ctypes geometry_fwd      %.2f" % t(lambda: lib.helio_geometry_fwd(*ga), 5000))
-sa = (B, N, R, rays.data_ptr(), f._xs.data_ptr(), f._ys.data_ptr(), img.data_ptr(), 0, st)
+sa = (B, N, R, rays.data_ptr(), f._xs.data_ptr(), f._ys.data_ptr(), img.data_ptr(), 0, None, 0, st)
 print("ctypes splat_fwd         %.2f" % t(lambda: lib.helio_splat_fwd(*sa), 5000))
 def both():
     lib.helio_geometry_fwd(*ga); lib.helio_splat_fwd(*sa)

@@ -19,7 +19,7 @@ trig, stride = f._select_trig(w.B)
 normals = act.reshape(w.B, w.N, 3).contiguous()
 actual = torch.empty_like(normals); rays = torch.empty(w.B, w.N, 4, device=dev); img = torch.empty(w.B, w.R, w.R, device=dev)
 args = (w.B, w.N, w.R, f.heliostat_positions.data_ptr(), suns_d.data_ptr(), normals.data_ptr(), trig.data_ptr(), stride, f._plane,
-        f._xs.data_ptr(), f._ys.data_ptr(), actual.data_ptr(), None, rays.data_ptr(), img.data_ptr(), 0, st)
+        f._xs.data_ptr(), f._ys.data_ptr(), actual.data_ptr(), None, rays.data_ptr(), img.data_ptr(), 0, None, 0, st)
 t_r = time_kernel(lambda: lib.helio_render_fwd(*args), 5000, warm=200)
 print(f"config-2 fused render through the C ABI alone, back-to-back: {t_r*1e6:.2f} us per launch")
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Where the config-2 render kernel spends its cycles: s_memtime stamps of the fused small-problem
-kernel (diagnostic build, tools/build_diag.py → doodle_amd/libhelio_diag.so).
+kernel (diagnostic build, tools/build_diag.py → $TMPDIR/libhelio_diag.so, built on demand).
 
     python tools/stamps_fused.py [cfg] > profiles/r02_fused_stamps.txt
 
@@ -18,11 +18,12 @@ from bench import build_field, make_action, time_kernel
 cfg = sys.argv[1] if len(sys.argv) > 1 else "cfg2"
 w = synthetic.CONFIGS[cfg]
 dev = torch.device("cuda")
-path = os.path.join(os.path.dirname(native.LIB_PATH), "libhelio_diag.so")
+import build_diag            # the diagnostic library is built on demand, outside the tree (hipcc, ≈30 s)
+path = build_diag.OUT if os.path.exists(build_diag.OUT) else build_diag.build()
 diag = ctypes.CDLL(path)
 vp, i, l = ctypes.c_void_p, ctypes.c_int, ctypes.c_long
 diag.helio_render_fwd.restype = i
-diag.helio_render_fwd.argtypes = [i, i, i, vp, vp, vp, vp, l, ctypes.POINTER(native.Plane), vp, vp, vp, vp, vp, vp, i, vp]
+diag.helio_render_fwd.argtypes = [i, i, i, vp, vp, vp, vp, l, ctypes.POINTER(native.Plane), vp, vp, vp, vp, vp, vp, i, vp, l, vp]
 diag.helio_diag_set_stamps.restype = i
 diag.helio_diag_set_stamps.argtypes = [vp]
 
@@ -37,7 +38,7 @@ rays = torch.empty(w.B, w.N, 4, device=dev)
 img = torch.empty(w.B, w.R, w.R, device=dev)
 st = native._stream()
 args = (w.B, w.N, w.R, f.heliostat_positions.data_ptr(), suns_d.data_ptr(), normals.data_ptr(), trig.data_ptr(), stride,
-        f._plane, f._xs.data_ptr(), f._ys.data_ptr(), actual.data_ptr(), None, rays.data_ptr(), img.data_ptr(), 0, st)
+        f._plane, f._xs.data_ptr(), f._ys.data_ptr(), actual.data_ptr(), None, rays.data_ptr(), img.data_ptr(), 0, None, 0, st)
 diag.helio_diag_fused_kg.restype = i
 diag.helio_diag_fused_kg.argtypes = [i, i, i]
 blocks = ((w.R + 31) // 32) ** 2
