@@ -66,18 +66,34 @@ __device__ __forceinline__ bool cull_dead_strict(const float4 ray, const CullBox
     return fx > CULL_EXP2 || fy > CULL_EXP2;
 }
 
+// ---- work order ---------------------------------------------------------------------------------------
+// The chip hands workgroups to its 8 XCDs round-robin by linear id and in order: when consecutive ids carry
+// unequal work the dispatcher waits on the busiest XCD and the others idle (measured: a compacted backward
+// whose empty tiles were interleaved with the full ones took as long as the dense one).  So the kernels do
+// not take their tile from blockIdx directly but from a small table made with the lists:
+//   forward  — order[w]: the (image, tile) lists sorted by length, longest first (neighbouring ids: nearly
+//              equal work; long ones early: a short tail);
+//   backward — map[w]: the (image, 256-ray tile) items that are not empty, image-major (equal work each), and
+//              their number; ids past it leave at once, all at the END of the grid.
+// Which workgroup computes a tile does not enter any result.
+//
 // ---- scratch layouts (device memory handed in by the caller; helio_*_scratch_bytes) ----------------
-// forward:  int counts[B·tiles²] (padded to 256 B) | float4 lists[B·tiles²][N]     tile = TE×TE pixels
-// backward: int counts[B]        (padded to 256 B) | int idx[B][N]
+// forward:  int counts[T] | int order[T] | float4 lists[T][N]          T = B·tiles², tile = TE×TE pixels
+// backward: int counts[B] | int idx[B][N] | int total (+pad) | int2 map[B·⌈N/256⌉]
+// (every section padded to 256 bytes)
 __host__ __device__ inline long cull_pad256(long bytes) { return (bytes + 255) & ~255l; }
 inline long cull_fwd_bytes(int B, int N, int R, int TE) {
-    const long t = (R + TE - 1) / TE;
-    return cull_pad256(4l * B * t * t) + 16l * B * t * t * N;
+    const long t = (R + TE - 1) / TE, T = (long)B * t * t;
+    return 2 * cull_pad256(4 * T) + 16 * T * N;
 }
-inline long cull_bwd_bytes(int B, int N) { return cull_pad256(4l * B) + 4l * B * N; }
+constexpr int CULL_BWD_TILE = 256;           // rays per tile of splat_bwd_mfma
+inline long cull_bwd_bytes(int B, int N) {
+    const long nt = (N + CULL_BWD_TILE - 1) / CULL_BWD_TILE;
+    return cull_pad256(4l * B) + cull_pad256(4l * B * N) + 256 + 8l * B * nt;
+}
 
-struct CullFwd { const int* counts; const float4* lists; };      // counts == nullptr: dense
-struct CullBwd { const int* counts; const int* idx; };
+struct CullFwd { const int* counts; const int* order; const float4* lists; };      // counts == nullptr: dense
+struct CullBwd { const int* counts; const int* idx; const int* total; const int2* map; };
 
 // launchers (cull.hip)
 CullFwd launch_cull_fwd(int B, int N, int R, int TE, const float* rays, const float* xs, const float* ys,

@@ -114,6 +114,64 @@ cull_bwd_kernel(int N, int R, int JB, const float4* __restrict__ rays, const flo
     if (threadIdx.x == 0) counts[b] = base;
 }
 
+// ---- work order (cull.h): one workgroup each -----------------------------------------------------------
+constexpr int ORDER_THREADS = 1024, ORDER_WAVES = ORDER_THREADS / 64;
+
+// inclusive prefix sum of one int per thread over the workgroup; `total` = the sum (all threads)
+__device__ __forceinline__ int block_scan_incl(int v, int* sw, int& total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int y = __shfl_up(x, d);
+        if (lane >= d) x += y;
+    }
+    if (lane == 63) sw[wave] = x;
+    __syncthreads();
+    int before = 0;
+    total = 0;
+#pragma unroll
+    for (int w = 0; w < ORDER_WAVES; ++w) { const int c = sw[w]; before += w < wave ? c : 0; total += c; }
+    __syncthreads();
+    return before + x;
+}
+
+// order[] = the T lists sorted by length, longest first: a counting sort on 1024 length classes (the order
+// inside a class is whatever the atomics give — it decides which workgroup computes a tile, nothing else)
+__global__ void __launch_bounds__(ORDER_THREADS)
+cull_order_fwd_kernel(int T, int N, const int* __restrict__ counts, int* __restrict__ order) {
+    __shared__ int cls[ORDER_THREADS];
+    __shared__ int sw[ORDER_WAVES];
+    const int tid = threadIdx.x;
+    auto klass = [&](int c) { return 1023 - (int)min(1023l, (long)c * 1023 / max(N, 1)); };     // 0 = the longest
+    cls[tid] = 0;
+    __syncthreads();
+    for (int i = tid; i < T; i += ORDER_THREADS) atomicAdd(&cls[klass(counts[i])], 1);
+    __syncthreads();
+    const int mine = cls[tid];
+    int total;
+    const int incl = block_scan_incl(mine, sw, total);
+    cls[tid] = incl - mine;                                   // where the class starts
+    __syncthreads();
+    for (int i = tid; i < T; i += ORDER_THREADS) order[atomicAdd(&cls[klass(counts[i])], 1)] = i;
+}
+
+// map[] = (image, ray tile) of every tile of the per-image lists that holds a ray, image-major; *total = how many
+__global__ void __launch_bounds__(ORDER_THREADS)
+cull_map_bwd_kernel(int B, const int* __restrict__ counts, int* __restrict__ total_out, int2* __restrict__ map) {
+    __shared__ int sw[ORDER_WAVES];
+    int running = 0;
+    for (int b0 = 0; b0 < B; b0 += ORDER_THREADS) {
+        const int b = b0 + (int)threadIdx.x;
+        const int t = b < B ? (counts[b] + CULL_BWD_TILE - 1) / CULL_BWD_TILE : 0;
+        int total;
+        const int start = running + block_scan_incl(t, sw, total) - t;
+        for (int k = 0; k < t; ++k) map[start + k] = make_int2(b, k);
+        running += total;
+    }
+    if (threadIdx.x == 0) *total_out = running;
+}
+
 // HELIO_CULL=0 switches the stage off (A/B runs): the dense kernels then run whatever scratch is passed
 bool cull_enabled() {
     static const bool on = [] { const char* e = getenv("HELIO_CULL"); return !(e && e[0] == '0'); }();
@@ -123,20 +181,28 @@ bool cull_enabled() {
 CullFwd launch_cull_fwd(int B, int N, int R, int TE, const float* rays, const float* xs, const float* ys,
                         void* scratch, hipStream_t st) {
     const int t = (R + TE - 1) / TE;
-    int* counts = static_cast<int*>(scratch);
-    float4* lists = reinterpret_cast<float4*>(static_cast<char*>(scratch) + cull_pad256(4l * B * t * t));
+    const long T = (long)B * t * t;
+    char* base = static_cast<char*>(scratch);
+    int* counts = reinterpret_cast<int*>(base);
+    int* order = reinterpret_cast<int*>(base + cull_pad256(4 * T));
+    float4* lists = reinterpret_cast<float4*>(base + 2 * cull_pad256(4 * T));
     hipLaunchKernelGGL(cull_fwd_kernel, dim3(t * t, B), dim3(CULL_THREADS), 0, st, N, R, TE,
                        reinterpret_cast<const float4*>(rays), xs, ys, counts, lists);
-    return CullFwd{counts, lists};
+    hipLaunchKernelGGL(cull_order_fwd_kernel, dim3(1), dim3(ORDER_THREADS), 0, st, (int)T, N, counts, order);
+    return CullFwd{counts, order, lists};
 }
 
 CullBwd launch_cull_bwd(int B, int N, int R, int JB, const float* rays, const float* xs, const float* ys,
                         float* moments, void* scratch, hipStream_t st) {
-    int* counts = static_cast<int*>(scratch);
-    int* idx = reinterpret_cast<int*>(static_cast<char*>(scratch) + cull_pad256(4l * B));
+    char* base = static_cast<char*>(scratch);
+    int* counts = reinterpret_cast<int*>(base);
+    int* idx = reinterpret_cast<int*>(base + cull_pad256(4l * B));
+    int* total = reinterpret_cast<int*>(base + cull_pad256(4l * B) + cull_pad256(4l * B * N));
+    int2* map = reinterpret_cast<int2*>(reinterpret_cast<char*>(total) + 256);
     hipLaunchKernelGGL(cull_bwd_kernel, dim3(B), dim3(CULL_THREADS), 0, st, N, R, JB,
                        reinterpret_cast<const float4*>(rays), xs, ys, counts, idx, moments);
-    return CullBwd{counts, idx};
+    hipLaunchKernelGGL(cull_map_bwd_kernel, dim3(1), dim3(ORDER_THREADS), 0, st, B, counts, total, map);
+    return CullBwd{counts, idx, total, map};
 }
 
 }  // namespace helio

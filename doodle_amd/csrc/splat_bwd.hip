@@ -161,7 +161,8 @@ template <int PASS, bool VEC, int WC = 4>
 __global__ void __launch_bounds__(256 * WC)
 splat_bwd_mfma(int B, int N, int R, const float* __restrict__ rays, const float* __restrict__ xs,
                const float* __restrict__ ys, const float* __restrict__ gimg, float* __restrict__ moments,
-               const int* __restrict__ live_counts, const int* __restrict__ live_idx) {
+               const int* __restrict__ live_counts, const int* __restrict__ live_idx, const int* __restrict__ live_total,
+               const int2* __restrict__ live_map) {
     static_assert(!(VEC && PASS == 1), "16-byte staging is pass 0's");
     // Row pitch of the two LDS tables.  Pass 1 writes the slab transposed (lanes ↔ k at stride LD):
     // an odd pitch keeps that conflict-free.  Pass 0 writes it along c and stages it 16 bytes at a time
@@ -178,17 +179,25 @@ splat_bwd_mfma(int B, int N, int R, const float* __restrict__ rays, const float*
     float* __restrict__ sCc = smem + KC * (LDG + LD);
 
     const int c_tiles = (R + TC - 1) / TC;
-    const int b = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // scalar: nothing of it is kept in (or spilled from) VGPRs
     const int lr = lane & 31, lh = lane >> 5;
-    const int c0 = (blockIdx.x % c_tiles) * TC, n0 = (blockIdx.x / c_tiles) * T;
     // (cull.h) with a list of the image's rays whose footprint is not identically zero, the ray axis of the
-    // tiles runs over the list: L entries, entry p is ray live_idx[b·N + p]; the tiles past the list leave at
-    // once (the moments of the rays not listed were zeroed with the list).  A ray's moments involve no other
-    // ray, so which tile computes them changes nothing.
+    // tiles runs over the list: L entries, entry p is ray live_idx[b·N + p] (the moments of the rays not
+    // listed were zeroed with the list).  A ray's moments involve no other ray, so which tile computes them
+    // changes nothing.  The workgroup's (image, ray tile) then comes from the table of non-empty tiles, in id
+    // order, and the ids past the table leave at once — all at the end of the grid (cull.h, "work order").
+    int b = blockIdx.y, bx = blockIdx.x;
+    if (live_counts) {
+        const unsigned w = blockIdx.x + gridDim.x * blockIdx.y;
+        const unsigned item = w / (unsigned)c_tiles;
+        if (item >= (unsigned)*live_total) return;
+        const int2 e = live_map[item];
+        b = e.x;
+        bx = e.y * c_tiles + (int)(w % (unsigned)c_tiles);
+    }
+    const int c0 = (bx % c_tiles) * TC, n0 = (bx / c_tiles) * T;
     const int L = live_counts ? live_counts[b] : N;
-    if (n0 >= L) return;
     const int* __restrict__ lidx = live_counts ? live_idx + (long)b * N : nullptr;
     const int wc = (wave >> 2) * 64, wn = (wave & 3) * 64;
     const float* __restrict__ ccoord = PASS == 0 ? ys : xs;   // coordinates along c
@@ -747,7 +756,7 @@ static void launch_bwd_mfma_v(int B, int N, int R, const float* rays, const floa
     }
     const int ct = (R + TC - 1) / TC, nt = (N + 255) / 256;
     hipLaunchKernelGGL((splat_bwd_mfma<PASS, VEC, WC>), dim3(ct * nt, B), dim3(256 * WC), lds, st, B, N, R, rays, xs, ys, gimg, moments,
-                       cull.counts, cull.idx);
+                       cull.counts, cull.idx, cull.total, cull.map);
 }
 
 template <int PASS>
@@ -1273,7 +1282,7 @@ int launch_splat_bwd(int B, int N, int R, const float* rays, const float* xs, co
         return HELIO_OK;
     }
     if (variant == 2) {
-        CullBwd cull{nullptr, nullptr};
+        CullBwd cull{nullptr, nullptr, nullptr, nullptr};
         if (scratch && cull_bwd_wanted(2, B, N, R) && scratch_bytes >= cull_bwd_bytes(B, N))
             cull = launch_cull_bwd(B, N, R, splat_bwd_blocks(R), rays, xs, ys, moments, scratch, st);
         launch_bwd_mfma<0>(B, N, R, rays, xs, ys, gimg, moments, st, cull);

@@ -212,17 +212,25 @@ template <int MBI, int MBJ, int WI, int WJ, int NC, bool TWO_LEVEL>
 __global__ void __launch_bounds__(256)
 splat_fwd_mfma_regs(int B, int Nall, int R, const float* __restrict__ rays, const float* __restrict__ xs,
                     const float* __restrict__ ys, float* __restrict__ image, const int* __restrict__ live_counts,
-                    const float4* __restrict__ live_lists) {
+                    const int* __restrict__ live_order, const float4* __restrict__ live_lists) {
     static_assert(WI * WJ == 4 && NC % 4 == 0, "4 waves per workgroup");
     constexpr int TI = 32 * MBI * WI, TJ = 32 * MBJ * WJ;
     __shared__ float4 sRay[NC + 4];
 
     const int tiles_j = (R + TJ - 1) / TJ;
-    const int b = blockIdx.y;
+    // the workgroup's (image, tile): its place in the grid, or — with lists (cull.h) — the entry of the work
+    // order at its linear id (longest list first)
+    int b = blockIdx.y, tile = blockIdx.x;
+    long list = 0;
+    if (live_counts) {
+        list = live_order[blockIdx.x + gridDim.x * blockIdx.y];
+        b = (int)(list / gridDim.x);
+        tile = (int)(list % gridDim.x);
+    }
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int lr = lane & 31, lh = lane >> 5;
-    const int i0 = (blockIdx.x / tiles_j) * TI + (wave / WJ) * 32 * MBI;
-    const int j0 = (blockIdx.x % tiles_j) * TJ + (wave % WJ) * 32 * MBJ;
+    const int i0 = (tile / tiles_j) * TI + (wave / WJ) * 32 * MBI;
+    const int j0 = (tile % tiles_j) * TJ + (wave % WJ) * 32 * MBJ;
 
     float xv[MBI], yv[MBJ];
 #pragma unroll
@@ -246,9 +254,8 @@ splat_fwd_mfma_regs(int B, int Nall, int R, const float* __restrict__ rays, cons
     const float4* __restrict__ rb = reinterpret_cast<const float4*>(rays) + (long)b * Nall;
     int N = Nall;
     if (live_counts) {
-        const long t = (long)b * gridDim.x + blockIdx.x;
-        N = live_counts[t];
-        rb = live_lists + t * Nall;
+        N = live_counts[list];
+        rb = live_lists + list * Nall;
     }
     for (int n0 = 0; n0 < N; n0 += NC) {
         __syncthreads();
@@ -448,7 +455,7 @@ template <int W, bool TWO_LEVEL>
 __global__ void __launch_bounds__(64 * W * W)
 splat_fwd_mfma_tile(int B, int Nall, int R, const float* __restrict__ rays, const float* __restrict__ xs,
                     const float* __restrict__ ys, float* __restrict__ image, const int* __restrict__ live_counts,
-                    const float4* __restrict__ live_lists) {
+                    const int* __restrict__ live_order, const float4* __restrict__ live_lists) {
     // row pitch: odd for the 4-wave form (ds_write_b32 per factor), T+2 for the 16-wave form, whose
     // producer stores factor PAIRS with ds_write_b64 (8-byte aligned rows; 16 lanes × 2 dwords
     // at pitch 258 cover the 32 banks exactly once)
@@ -459,10 +466,18 @@ splat_fwd_mfma_tile(int B, int Nall, int R, const float* __restrict__ rays, cons
     float* __restrict__ sXY = smem + 2 * NC * LD;
 
     const int tiles_j = (R + T - 1) / T;
-    const int b = blockIdx.y;
+    // the workgroup's (image, tile): its place in the grid, or — with lists (cull.h) — the entry of the work
+    // order at its linear id (longest list first)
+    int b = blockIdx.y, tile = blockIdx.x;
+    long list = 0;
+    if (live_counts) {
+        list = live_order[blockIdx.x + gridDim.x * blockIdx.y];
+        b = (int)(list / gridDim.x);
+        tile = (int)(list % gridDim.x);
+    }
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int lr = lane & 31, lh = lane >> 5;
-    const int ti0 = (blockIdx.x / tiles_j) * T, tj0 = (blockIdx.x % tiles_j) * T;
+    const int ti0 = (tile / tiles_j) * T, tj0 = (tile % tiles_j) * T;
     const int wi = (wave / W) * 64, wj = (wave % W) * 64;
 
     for (int k = tid; k < 2 * T; k += 64 * NW)
@@ -479,9 +494,8 @@ splat_fwd_mfma_tile(int B, int Nall, int R, const float* __restrict__ rays, cons
     const float4* __restrict__ rb = reinterpret_cast<const float4*>(rays) + (long)b * Nall;
     int N = Nall;
     if (live_counts) {
-        const long t = (long)b * gridDim.x + blockIdx.x;
-        N = live_counts[t];
-        rb = live_lists + t * Nall;
+        N = live_counts[list];
+        rb = live_lists + list * Nall;
     }
     float4 g = (lane < N) ? rb[lane] : pad;
 
@@ -1173,16 +1187,16 @@ bool launch_env_step_fused(int B, int N, int R, const float* helios, const float
 
 template <int MBI, int MBJ, int WI, int WJ, int NC, bool TWO_LEVEL>
 static void launch_regs(int B, int N, int R, const float* rays, const float* xs, const float* ys,
-                        float* image, hipStream_t st, CullFwd cull = CullFwd{nullptr, nullptr}) {
+                        float* image, hipStream_t st, CullFwd cull = CullFwd{nullptr, nullptr, nullptr}) {
     constexpr int TI = 32 * MBI * WI, TJ = 32 * MBJ * WJ;
     const int ti = (R + TI - 1) / TI, tj = (R + TJ - 1) / TJ;
     hipLaunchKernelGGL((splat_fwd_mfma_regs<MBI, MBJ, WI, WJ, NC, TWO_LEVEL>), dim3(ti * tj, B), dim3(256), 0, st,
-                       B, N, R, rays, xs, ys, image, cull.counts, cull.lists);
+                       B, N, R, rays, xs, ys, image, cull.counts, cull.order, cull.lists);
 }
 
 template <int W, bool TWO_LEVEL>
 static void launch_tile(int B, int N, int R, const float* rays, const float* xs, const float* ys,
-                        float* image, hipStream_t st, CullFwd cull = CullFwd{nullptr, nullptr}) {
+                        float* image, hipStream_t st, CullFwd cull = CullFwd{nullptr, nullptr, nullptr}) {
     constexpr int T = 64 * W;
     const int t = (R + T - 1) / T;
     const size_t lds = (2 * 64 * (T + (W == 4 ? 2 : 1)) + 2 * T) * sizeof(float);
@@ -1193,7 +1207,7 @@ static void launch_tile(int B, int N, int R, const float* rays, const float* xs,
         configured = true;
     }
     hipLaunchKernelGGL((splat_fwd_mfma_tile<W, TWO_LEVEL>), dim3(t * t, B), dim3(64 * W * W), lds, st,
-                       B, N, R, rays, xs, ys, image, cull.counts, cull.lists);
+                       B, N, R, rays, xs, ys, image, cull.counts, cull.order, cull.lists);
 }
 
 
@@ -1487,7 +1501,7 @@ int launch_splat_fwd(int B, int N, int R, const float* rays, const float* xs, co
                      float* image, int variant, void* scratch, long scratch_bytes, hipStream_t st) {
     const long t128 = (long)B * ((R + 127) / 128) * ((R + 127) / 128);
     if (variant == 0 || variant == 2) variant = splat_fwd_choice(B, N, R);
-    CullFwd cull{nullptr, nullptr};
+    CullFwd cull{nullptr, nullptr, nullptr};
     if (const int te = scratch ? cull_fwd_tile(variant, B, N, R) : 0; te && scratch_bytes >= cull_fwd_bytes(B, N, R, te))
         cull = launch_cull_fwd(B, N, R, te, rays, xs, ys, scratch, st);
     switch (variant) {

@@ -73,8 +73,10 @@ def test_culled_forward_kernels_equal_the_dense_ones_bit_for_bit(N, B, R, sigma,
         assert counts is not None and int(counts.min()) >= 0 and int(counts.max()) <= N
         assert same_bits(culled, dense), (variant, (culled - dense).abs().max().item())
         assert same_bits(ops.splat_fwd(rays, f._xs, f._ys, variant=variant, cull=True), dense)
-        if err == 0.0 or sigma == 0.1:
-            assert int(counts.min()) == N                    # every footprint reaches the receiver: nothing to skip
+        if sigma == 0.1:
+            assert int(counts.min()) == N                    # every footprint covers the receiver: nothing to skip
+        if err == 0.0:
+            assert int(counts.sum()) > 0.9 * counts.numel() * N      # aimed at the centre (bar the action noise)
         if sigma == 0.01 and err >= 90.0:
             assert int(counts.sum()) < 0.8 * counts.numel() * N      # and here a good part of the field misses it
     # the kernels that round at chunk or part boundaries, and the split-bf16 ones, take no list
@@ -136,7 +138,8 @@ def test_culled_backward_moments_equal_the_dense_ones_bit_for_bit(N, B, R, sigma
     ops = native.get_ops()
     f, suns, act, rays = field_and_rays(N, B, R, sigma, err, seed=N + R + 1, span=30.0)
     G = torch.randn(B, R, R, device=DEV, generator=torch.Generator(device=DEV).manual_seed(3))
-    assert ops.lib.helio_bwd_scratch_bytes(B, N, R, 2) == ((4 * B + 255) // 256) * 256 + 4 * B * N
+    pad = lambda n: (n + 255) // 256 * 256      # noqa: E731  counts | idx | total | map (csrc/cull.h)
+    assert ops.lib.helio_bwd_scratch_bytes(B, N, R, 2) == pad(4 * B) + pad(4 * B * N) + 256 + 8 * B * ((N + 255) // 256)
     dense = ops.splat_bwd(rays, f._xs, f._ys, G, variant=2, cull=False)
     culled = ops.splat_bwd(rays, f._xs, f._ys, G, variant=2, cull=True)
     assert same_bits(culled, dense), (culled - dense).abs().max().item()
@@ -167,7 +170,7 @@ def test_render_autograd_and_env_step_are_unchanged_by_the_culling():
             (grad,) = torch.autograd.grad((img * G).sum() + actual.sum(), a)
             with torch.no_grad():
                 img_ng, _ = f.render(suns, a.detach(), None)
-            vg = f.render_value_and_grad(suns, a.detach(), grad_image=G)
+            vg = f.render_value_and_grad(suns, a.detach(), grad_image=G, grad_actual=torch.ones(B, N, 3, device=DEV))
             out[cull] = (img.detach(), actual.detach(), refl.detach(), grad, img_ng, vg[0], vg[2])
         finally:
             ops.cull = True

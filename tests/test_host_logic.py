@@ -73,10 +73,10 @@ def test_abi_rejects_bad_arguments_without_launching():
                                   *([None] * 10), 0, None, 0, None) == -1
     # the optional device scratch (helio.h "Device scratch"): sized by host code; nothing for the small problems
     assert lib.helio_fwd_scratch_bytes(25, 50, 128, 0) == 0 and lib.helio_bwd_scratch_bytes(25, 50, 128, 0) == 0
-    t = 4 * 512 * 4                       # int counts[B · tiles²], tiles² = 4 at R = 512 with 256² tiles
-    assert lib.helio_fwd_scratch_bytes(512, 2000, 512, 0) == t + 16 * 512 * 4 * 2000
+    t = 4 * 512 * 4                       # int counts[B · tiles²] and int order[…], tiles² = 4 at R = 512 with 256² tiles
+    assert lib.helio_fwd_scratch_bytes(512, 2000, 512, 0) == 2 * t + 16 * 512 * 4 * 2000
     assert lib.helio_fwd_scratch_bytes(512, 2000, 512, 6) == 0 and lib.helio_fwd_scratch_bytes(512, 2000, 512, 7) == 0
-    assert lib.helio_bwd_scratch_bytes(512, 2000, 512, 0) == 4 * 512 + 4 * 512 * 2000
+    assert lib.helio_bwd_scratch_bytes(512, 2000, 512, 0) == 4 * 512 + 4 * 512 * 2000 + 256 + 8 * 512 * 8
     assert lib.helio_bwd_scratch_bytes(512, 2000, 512, 5) == 0 and lib.helio_bwd_scratch_bytes(512, 200, 512, 0) == 0
     assert lib.helio_notify_wait(None, 1, 0.0) == -1 and lib.helio_notify_destroy(None) == 0
 
