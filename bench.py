@@ -29,6 +29,10 @@ Extra objects in the line (N = 1):
   roofline        the dominant kernel of the run by GPU time: the splat forward at BASELINE
                   config 4 (N=2000, B=512, R=512), timed live with HIP events on the launch
                   stream, ≥ 20 launches (f32 MFMA roofline; the HBM view is given beside it).
+                  ``achieved`` / ``frac`` are those of the DENSE kernel (no device scratch: every (ray,
+                  pixel) pair issued, a fraction of issued work ≤ 1); ``roofline.culled`` is the default
+                  path — the rays that are exactly zero on a tile skipped, bit-identical images — with its
+                  live fraction, time and speed-up; ``render_ms`` and the backward figures use the default.
                   ``traffic`` comes from the committed PMC passes (profiles/*_traffic.json) and is
                   tied to the kernel by name AND by the hash of its source file: a stale entry
                   is refused (null).
@@ -61,7 +65,7 @@ from doodle_amd import native, synthetic  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 F32_MFMA_PEAK_TF = 157.3     # dense f32 MFMA = f32 vector peak (spec)
-TRAFFIC_FILES = ("r02_traffic.json", "r01_traffic.json")     # newest first
+TRAFFIC_FILES = ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json")     # newest first
 KERNEL_SOURCE = {"splat_fwd_mfma_tile": "splat_fwd.hip", "render_fwd_fused_small": "splat_fwd.hip"}
 
 
@@ -95,6 +99,25 @@ def time_kernel(fn, iters, warm=3):
     e1.record()
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) * 1e-3 / iters
+
+
+def time_interleaved(fns, iters, warm=2):
+    """Average duration (s) of each of ``fns``, run in turn ``iters`` times — A, B, C, A, B, C … — every call
+    bracketed by its own pair of HIP events on the launch stream: figures that are compared with each other
+    (a kernel and the call that contains it) see the same clocks."""
+    for _ in range(warm):
+        for fn in fns:
+            fn()
+    pairs = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)] for _ in fns]
+    torch.cuda.synchronize()
+    for i in range(iters):
+        for k, fn in enumerate(fns):
+            e0, e1 = pairs[k][i]
+            e0.record()
+            fn()
+            e1.record()
+    torch.cuda.synchronize()
+    return [sum(e0.elapsed_time(e1) for e0, e1 in ps) * 1e-3 / iters for ps in pairs]
 
 
 def preheat(fn, seconds, burst=None, fence=None):
@@ -139,7 +162,7 @@ def measured_traffic(kernel, N, B, R):
     return None, "no PMC pass committed for this kernel at this size"
 
 
-def splat_roofline(field, suns, action, iters, variant=None):
+def splat_roofline(field, suns, action, iters, variant=None, timer=None):
     """Roofline entry for the dominant kernel of one render on (field, suns): the fused
     render kernel when the problem takes the single-launch path, else the splat-forward
     kernel.  One launch per timed iteration, HIP events on the launch stream."""
@@ -156,13 +179,14 @@ def splat_roofline(field, suns, action, iters, variant=None):
         kernel = "render_fwd_fused_small"
         args = (B, N, R, field.heliostat_positions.data_ptr(), suns.data_ptr(), normals.data_ptr(), trig.data_ptr(),
                 stride, field._plane, field._xs.data_ptr(), field._ys.data_ptr(), actual.data_ptr(), None,
-                rays.data_ptr(), image.data_ptr(), var, st)
+                rays.data_ptr(), image.data_ptr(), var, None, 0, st)
         t = time_kernel(lambda: lib.helio_render_fwd(*args), iters, warm=max(3, iters // 10))
         bytes_alg = 4.0 * B * R * R + 32.0 * B * N + 16.0 * B * N + 12.0 * N + 12.0 * B + 8.0 * R
     else:
         kernel = "splat_fwd"
-        args = (B, N, R, rays.data_ptr(), field._xs.data_ptr(), field._ys.data_ptr(), image.data_ptr(), var, st)
-        t = time_kernel(lambda: lib.helio_splat_fwd(*args), iters)
+        # no device scratch: the DENSE kernel, every (ray, pixel) pair issued — the roofline of record
+        args = (B, N, R, rays.data_ptr(), field._xs.data_ptr(), field._ys.data_ptr(), image.data_ptr(), var, None, 0, st)
+        t = time_kernel(lambda: lib.helio_splat_fwd(*args), iters) if timer is None else timer(lambda: lib.helio_splat_fwd(*args))
         bytes_alg = 4.0 * B * R * R + 16.0 * B * N + 8.0 * R   # image store + ray parameters + xs/ys
     flops = 2.0 * B * N * R * R                       # one FMA per (ray, pixel)
     traffic, note = measured_traffic(kernel if fused else "splat_fwd_mfma_tile", N, B, R)
@@ -174,6 +198,124 @@ def splat_roofline(field, suns, action, iters, variant=None):
         "hbm_achieved_GBs": round(bytes_alg / t / 1e9, 1), "hbm_frac": round(bytes_alg / t / 1e9 / HBM_PEAK_GBS, 4),
         "algorithmic_bytes": bytes_alg, "algorithmic_flops": flops,
     }
+
+
+def sigma_pixels(field, suns, action):
+    """Footprint sigma of the field's rays in pixels (min / median / max over the rays that hit the plane):
+    sigma = sqrt(log2(e) / (2 k2)) from the ray parameters the geometry kernel writes, pixel pitch W / (R - 1)."""
+    ops = native.get_ops()
+    B, N = suns.shape[0], field.num_heliostats
+    trig, stride = field._select_trig(B)
+    _, _, rays = ops.geometry_fwd(field.heliostat_positions, suns, action.reshape(B, N, 3).contiguous(), trig, stride,
+                                  field._plane)
+    k2 = rays[..., 2].flatten()
+    k2 = k2[k2 > 0]
+    pitch = field.target_width / max(field.resolution - 1, 1)
+    sig = torch.sqrt(1.4426950408889634 / (2.0 * k2)) / pitch
+    return {"min": round(float(sig.min()), 3), "median": round(float(sig.median()), 3), "max": round(float(sig.max()), 3),
+            "pixel_pitch_m": round(pitch, 5)}
+
+
+def culled_splat(field, suns, action, variant):
+    """The default splat call — device scratch handed over, exactly-zero rays skipped (csrc/cull.h) — as a closure
+    for the timers, the fraction of (ray, tile) pairs it keeps, and whether its image equals the dense one's bits."""
+    ops = native.get_ops()
+    lib, st = ops.lib, native._stream()
+    B, N, R = suns.shape[0], field.num_heliostats, field.resolution
+    trig, stride = field._select_trig(B)
+    _, _, rays = ops.geometry_fwd(field.heliostat_positions, suns, action.reshape(B, N, 3).contiguous(), trig, stride,
+                                  field._plane)
+    nb = lib.helio_fwd_scratch_bytes(B, N, R, variant)
+    if nb <= 0:
+        return None
+    scratch = torch.empty(nb, dtype=torch.uint8, device=suns.device)
+    image = torch.empty((B, R, R), dtype=torch.float32, device=suns.device)
+    args = (B, N, R, rays.data_ptr(), field._xs.data_ptr(), field._ys.data_ptr(), image.data_ptr(), variant,
+            scratch.data_ptr(), nb, st)
+    native._check(lib, lib.helio_splat_fwd(*args))
+    t = -(-R // 256)
+    live = scratch[:4 * B * t * t].view(torch.int32).double().sum().item() / (B * t * t * N)
+    dense = ops.splat_fwd(rays, field._xs, field._ys, variant=variant, cull=False)
+    same = bool(torch.equal(image.view(torch.int32), dense.view(torch.int32)))
+    return (lambda: lib.helio_splat_fwd(*args)), live, same, (scratch, image, rays)
+
+
+def value_sweep(dev, w, steps, seeds=(0, 1, 2), sigmas=(0.01, 0.1)):
+    """the headline loop — K bare ``field.render`` calls + fence, after a burst preheat — for seeds
+    0..2 at the training sigma_scale (0.01) and at the README default (0.1): frames/s per seed, median, spread."""
+    import gc
+    out = {"steps": steps, "what": "frames/s of K field.render calls + synchronize (the timed region of `value`), one fresh "
+                                   "field per (seed, sigma_scale); spread = (max - min) / median"}
+    for sg in sigmas:
+        vals = []
+        for seed in seeds:
+            ws = synthetic.Workload(w.name, w.N, w.B, w.R, sg, w.error_scale_mrad, w.span)
+            helios, suns, errs, noise = synthetic.make_inputs(ws, seed)
+            f = build_field(ws, helios, errs, dev)
+            suns_d = suns.to(dev)
+            a = make_action(f, suns_d, noise)
+            with torch.no_grad():
+                preheat(lambda: f.render(suns_d, a, None), 0.25, burst=steps, fence=torch.cuda.synchronize)
+                gc_was = gc.isenabled()
+                gc.disable()
+                try:
+                    best = float("inf")
+                    for _ in range(3):
+                        t0 = time.perf_counter()
+                        for _ in range(steps):
+                            f.render(suns_d, a, None)
+                        torch.cuda.synchronize()
+                        best = min(best, time.perf_counter() - t0)
+                finally:
+                    if gc_was:
+                        gc.enable()
+            vals.append(round(ws.B * steps / best, 1))
+        med = sorted(vals)[len(vals) // 2]
+        out[f"sigma_scale={sg}"] = {"frames_per_s_by_seed": dict(zip(map(str, seeds), vals)), "median": med,
+                                    "spread": round((max(vals) - min(vals)) / med, 4)}
+    return out
+
+
+def cpu_baseline_extra(seed):
+    """the oracle on this host at config 1 (N=50, B=1: the reference's own CPU-runnable case), forward,
+    and at config 3 (N=50, B=25) forward + backward (L = (img*G).sum() + actual.sum(), torch autograd)."""
+    from oracle import torch_oracle as to
+    out = {}
+    threads0 = torch.get_num_threads()
+    try:
+        torch.set_num_threads(min(8, os.cpu_count() or 8))
+        for key, cfg, bwd in (("cfg1_forward", "cfg1", False), ("cfg3_forward_backward", "cfg2", True)):
+            w = synthetic.CONFIGS[cfg]
+            helios, suns, errs, noise = synthetic.make_inputs(w, seed)
+            sc = to.Scene.build(helios, synthetic.TARGET_POSITION, synthetic.TARGET_AREA, synthetic.TARGET_NORMAL, w.R, w.sigma_scale)
+            ideal = to.ideal_normals(helios, sc.target_position, suns)
+            a = ideal + noise
+            a = (a / a.norm(dim=2, keepdim=True)).reshape(w.B, -1)
+            e = errs if w.B > 1 else errs[:1]
+            G = torch.randn(w.B, w.R, w.R, generator=torch.Generator().manual_seed(0))
+
+            def call():
+                if not bwd:
+                    with torch.no_grad():
+                        to.render(sc, suns, a, e)
+                    return
+                x = a.clone().requires_grad_(True)
+                img, actual = to.render(sc, suns, x, e)
+                torch.autograd.grad((img * G).sum() + actual.sum(), x)
+
+            call()
+            n, t0 = 0, time.perf_counter()
+            while True:
+                call()
+                n += 1
+                el = time.perf_counter() - t0
+                if el > 3.0 or n >= 40:
+                    break
+            out[key] = {"frames_per_s": round(w.B * n / el, 2), "ms_per_call": round(el / n * 1e3, 2), "calls": n,
+                        "threads": torch.get_num_threads(), "workload": w.name + (" forward+backward" if bwd else " forward")}
+    finally:
+        torch.set_num_threads(threads0)
+    return out
 
 
 def cpu_baseline(w, seed, budget_s=10.0):
@@ -423,6 +565,16 @@ def main():
             out["all_gather_error"] = gather_error
         if shard is not None:
             out["multi_gpu_of_record"] = shard
+            if "frames_per_s" in shard:
+                # lifted next to `value`: `value` (BASELINE's metric, config 2) has NO data-path collective and scales
+                # N x by construction; the figure that exercises the interconnect is this one
+                out["scaling_of_record"] = {"frames_per_s": shard["frames_per_s"], "ms_per_step": shard["ms_per_step"],
+                                            "n_gpus": world, "rccl_ranks": shard.get("rccl_ranks"),
+                                            "workload": shard["workload"]}
+                out["config"]["scaling_curve"] = ("`value` is BASELINE's metric (config 2, images stay on their rank: no "
+                                                  "collective, N x by construction); a scaling curve of the path AS THE NORTH "
+                                                  "STAR STATES IT (shard B, all-gather the images over xGMI) must use "
+                                                  "scaling_of_record.frames_per_s (config 5 shard, render + all-gather every step)")
         iters = 2000 if w.B * w.N * w.R * w.R < 1e10 else 20
         small = splat_roofline(field, suns_d, action.detach(), iters)
         small["workload"] = w.name
@@ -446,11 +598,22 @@ def main():
                     out["hbm_bound_kernels"] = hbm_leg(dev)
                 except Exception as e:  # noqa: BLE001
                     out["hbm_bound_kernels"] = {"error": repr(e)}
+            if not args.no_large and not args.no_extras and args.mode == "fwd":
+                try:
+                    out["value_by_seed_and_sigma"] = value_sweep(dev, w, args.steps if args.steps <= 1000 else 1000)
+                    out["sigma_px"] = {w.name: sigma_pixels(field, suns_d, action.detach())}
+                except Exception as e:  # noqa: BLE001
+                    out["value_by_seed_and_sigma"] = {"error": repr(e)}
             if not args.no_cpu:
                 if numa is not None:
                     affinity.restore(cpu_mask0)
                 out["cpu_baseline"] = cpu_baseline(w, args.seed)
                 out["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+                if not args.no_extras:
+                    try:
+                        out["cpu_baseline_other_configs"] = cpu_baseline_extra(args.seed)
+                    except Exception as e:  # noqa: BLE001
+                        out["cpu_baseline_other_configs"] = {"error": repr(e)}
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()                 # rank 0 runs extra single-GPU legs; tear down together
@@ -580,7 +743,7 @@ def hbm_leg(dev, B=512, N=2000, R=512, iters=20):
             B, Nf, R, h1.data_ptr(), sun.data_ptr(), act1.data_ptr(), trig.data_ptr(), 4 * Nf, plane, rays.data_ptr(),
             xs.data_ptr(), ys.data_ptr(), img.data_ptr(), target.data_ptr(), c.tx.data_ptr(), dm.data_ptr(),
             ideal1.data_ptr(), c.tp, c.tn, 15.0, 15.0, 0, None, one.data_ptr(), None, None, None, None, None, None,
-            mom.data_ptr(), grad.data_ptr(), 0, native._stream()))
+            mom.data_ptr(), grad.data_ptr(), 0, None, 0, native._stream()))
 
     t = time_kernel(fused, iters)
     out["env_step_bwd_few_ray(N=1)"] = entry(t, 12.0 * B * R * R, "img + target + distance map read once (2 launches)")
@@ -636,7 +799,12 @@ def cfg5_shard_leg(dev, rank, world, gather, dist, seed, b_local=512, steps=20):
         t = torch.tensor([el], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
-    return {"workload": f"BASELINE config 5 shard: N={w.N}, R={w.R}, {b_local} suns per GPU "
+    try:
+        sig = sigma_pixels(field, suns_d, action)
+    except Exception as e:  # noqa: BLE001
+        sig = {"error": repr(e)}
+    return {"sigma_px": sig,
+            "workload": f"BASELINE config 5 shard: N={w.N}, R={w.R}, {b_local} suns per GPU "
                         f"(global batch {world * b_local}), render + all-gather of all images every step",
             "n_gpus": world, "steps": steps, "warmup": 3,
             "frames_per_s": round(world * b_local * steps / el, 1), "ms_per_step": round(el / steps * 1e3, 3),
@@ -648,26 +816,71 @@ def cfg5_shard_leg(dev, rank, world, gather, dist, seed, b_local=512, steps=20):
 
 
 def large_leg(dev, seed, iters=20):
-    """Splat-forward roofline and whole-render rate at BASELINE config 4."""
+    """Splat-forward roofline and whole-render rate at BASELINE config 4.  The dense kernel (the roofline of
+    record), the default culled splat call and the whole ``field.render`` are timed in ONE interleaved,
+    event-bracketed loop (A, B, C, A, B, C …), so the three figures see the same clocks; the backward
+    (``render_value_and_grad``: forward + backward kernels for given cotangents) in a second one."""
     w = synthetic.CONFIGS["cfg4"]
     helios, suns, errs, noise = synthetic.make_inputs(w, seed)
     field = build_field(w, helios, errs, dev)
     suns_d = suns.to(dev)
     action = make_action(field, suns_d, noise)
-    r = splat_roofline(field, suns_d, action, iters=iters)
-    with torch.no_grad():
-        for _ in range(3):
-            field.render(suns_d, action, None)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(iters):
-            field.render(suns_d, action, None)
-        torch.cuda.synchronize()
-        el = (time.perf_counter() - t0) / iters
+    ops = native.get_ops()
+    timed = {}
+
+    def render():
+        field.render(suns_d, action, None)
+
+    culled = culled_splat(field, suns_d, action, 5)
+
+    def timer(dense_call):
+        with torch.no_grad():
+            ts = time_interleaved([dense_call, render] + ([culled[0]] if culled else []), iters)
+        timed["render"], timed["culled"] = ts[1], (ts[2] if culled else None)
+        return ts[0]
+
+    r = splat_roofline(field, suns_d, action, iters=iters, variant=5, timer=timer)
+    el = timed["render"]
+    if culled:
+        tc, live = timed["culled"], culled[1]
+        r["culled"] = {
+            "what": "the default path: helio_splat_fwd with device scratch — per 256x256 tile, the rays whose every product "
+                    "underflows below half an ulp of any accumulator are compacted out first (cull_fwd_kernel + "
+                    "cull_order_fwd_kernel + splat_fwd_mfma_tile<4> on the lists); csrc/cull.h",
+            "live_fraction": round(live, 4), "splat_us": round(tc * 1e6, 2),
+            "speedup_vs_dense_kernel": round(r["kernel_us"] / (tc * 1e6), 3),
+            "frac_on_live_flops": round(live * r["algorithmic_flops"] / tc / 1e12 / F32_MFMA_PEAK_TF, 4),
+            "dense_equivalent_TFLOPs": round(r["algorithmic_flops"] / tc / 1e12, 1),
+            "image_bit_identical_with_dense": culled[2]}
+    # backward at the same size: forward + backward kernels for given cotangents (no autograd graph), default
+    # (culled) and dense, interleaved
+    try:
+        G = torch.randn((w.B, w.R, w.R), device=dev)
+        ones = torch.ones((w.B, w.N, 3), device=dev)
+
+        def fwd_bwd():
+            return field.render_value_and_grad(suns_d, action, G, ones)
+
+        def fwd_bwd_dense():
+            ops.cull = False
+            try:
+                return field.render_value_and_grad(suns_d, action, G, ones)
+            finally:
+                ops.cull = True
+
+        g_c, g_d = fwd_bwd()[2], fwd_bwd_dense()[2]
+        tb = time_interleaved([fwd_bwd, fwd_bwd_dense], max(5, iters // 2))
+        r["fwd_bwd"] = {"what": "HelioField.render_value_and_grad at config 4: geometry + splat forward, splat backward (two "
+                                "MFMA passes) + geometry backward, for given cotangents; default (culled) and dense",
+                        "ms": round(tb[0] * 1e3, 3), "dense_ms": round(tb[1] * 1e3, 3),
+                        "frames_per_s": round(w.B / tb[0], 1),
+                        "gradient_bit_identical_with_dense": bool(torch.equal(g_c.view(torch.int32), g_d.view(torch.int32)))}
+        del G, ones, g_c, g_d
+    except Exception as e:  # noqa: BLE001
+        r["fwd_bwd"] = {"error": repr(e)}
     # the opt-in split-bf16 kernel (HELIO_SPLAT_VARIANT=7) on the same rays, beside the exact-f32 default:
     # never the roofline entry above, reported so that its speed and its accuracy can be judged together
     try:
-        ops = native.get_ops()
         trig, stride = field._select_trig(w.B)
         normals = action.reshape(w.B, w.N, 3).contiguous()
         _, _, rays = ops.geometry_fwd(field.heliostat_positions, suns_d, normals, trig, stride, field._plane)
@@ -680,7 +893,7 @@ def large_leg(dev, seed, iters=20):
                     "tools/accuracy_splat.py), variant 8 in one"}
         for v, name in ((7, "two_level"), (8, "one_level")):
             args = (w.B, w.N, w.R, rays.data_ptr(), field._xs.data_ptr(), field._ys.data_ptr(), split.data_ptr(), v,
-                    native._stream())
+                    None, 0, native._stream())
             t7 = time_kernel(lambda: ops.lib.helio_splat_fwd(*args), iters)
             rel = ((split - exact).abs() / exact.clamp_min(1e-6 * exact.max())).max().item()
             r["split_bf16_kernel"][name] = {
@@ -691,10 +904,13 @@ def large_leg(dev, seed, iters=20):
                 "max_rel_deviation_from_f32_kernel": float(f"{rel:.3e}")}
     except Exception as e:  # noqa: BLE001
         r["split_bf16_kernel"] = {"error": repr(e)}
-    r["workload"] = w.name + f", span={w.span} m, sigma_scale={w.sigma_scale}"
+    r["workload"] = w.name + f", span={w.span} m, sigma_scale={w.sigma_scale}, err={w.error_scale_mrad} mrad"
+    r["sigma_px"] = sigma_pixels(field, suns_d, action)
     r["render_frames_per_s"] = round(w.B / el, 1)
     r["render_ms"] = round(el * 1e3, 3)
     r["render_calls_timed"] = iters
+    r["timing"] = ("kernel_us (dense kernel), culled.splat_us and render_ms (field.render: geometry + culled splat) from ONE "
+                   "interleaved loop, every call between its own HIP events")
     fwd_bytes = 4.0 * w.B * w.R * w.R + 32.0 * w.B * w.N + 12.0 * w.N + 12.0 * w.B
     r["render_hbm_GBs"] = round(fwd_bytes / el / 1e9, 1)
     r["render_hbm_frac"] = round(fwd_bytes / el / 1e9 / HBM_PEAK_GBS, 4)

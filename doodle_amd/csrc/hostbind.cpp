@@ -133,12 +133,15 @@ py::tuple render_any(int64_t plane, const at::Tensor& helios, const at::Tensor& 
     return render_fwd(plane, helios, sun, normals, trig, trig_b_stride, xs, ys, rays_ws, want_refl, variant);
 }
 
-// Outputs of one launch-bound render: ONE block from torch's caching allocator carved into image | actual
-// (| refl), each a tensor of its own over the shared storage.  Two or three at::empty calls cost 0.72 µs each
-// (dispatcher, device guard, allocator, TensorImpl) next to a 3.3 µs launch and a 3.7 µs kernel; one allocator
-// call and three bare TensorImpls cost about a third of that.  The block goes back to the allocator when the
-// last of the tensors dies — which is why this is only done for small outputs (a caller that keeps `actual`
-// keeps the image's bytes too) — and record_stream() on any of them covers the block, as with at::empty.
+// Outputs of a launch-bound call come from torch's caching allocator through bare TensorImpls over blocks the
+// binding asks the allocator for directly: an at::empty costs 0.72 µs (dispatcher, device guard, allocator,
+// TensorImpl) next to a 3.3 µs launch and a 3.7 µs kernel, a direct allocator call and a TensorImpl about a
+// third of that.  A block goes back to the allocator when the last tensor over it dies, so tensors share a
+// block ONLY when callers keep or drop them together and no member is much smaller than the block: what a
+// rollout buffer retains step after step — the image, the `aux` row, the 0-dim metrics — always has a block
+// of its own (holding `metrics['mse']` for 10 000 steps must cost 10 000 x 256 bytes, not 10 000 images);
+// `actual | refl` and the per-image / per-ray monitor vectors (+ the call's scratch) share one each.
+// record_stream() on any tensor covers its block, as with at::empty.
 constexpr int64_t kCarveMaxBytes = 8 << 20;
 
 struct Carver {
@@ -227,12 +230,15 @@ struct RenderCtx {
     Outputs outputs(int64_t B, int64_t N, int64_t R, bool want_refl, bool batched) const {
         Outputs o;
         const int64_t ni = B * R * R, na = B * N * 3;
-        const int64_t total = Carver::pad(ni) + Carver::pad(na) + (want_refl ? na : 0);
-        if (total * (int64_t)sizeof(float) <= kCarveMaxBytes) {
-            const c10::Storage st = carve.block(total);
-            o.image = batched ? carve.tensor(st, 0, {B, R, R}) : carve.tensor(st, 0, {R, R});
-            o.actual = carve.tensor(st, Carver::pad(ni), {B, N, 3});
-            if (want_refl) o.refl = carve.tensor(st, Carver::pad(ni) + Carver::pad(na), {B * N, 3});
+        const int64_t rays_total = Carver::pad(na) + (want_refl ? na : 0);
+        if ((ni + rays_total) * (int64_t)sizeof(float) <= kCarveMaxBytes) {
+            // the image alone (what a caller keeps as an observation); actual | refl together (same size, both
+            // per-ray monitor outputs)
+            const c10::Storage si = carve.block(ni);
+            o.image = batched ? carve.tensor(si, 0, {B, R, R}) : carve.tensor(si, 0, {R, R});
+            const c10::Storage sr = carve.block(rays_total);
+            o.actual = carve.tensor(sr, 0, {B, N, 3});
+            if (want_refl) o.refl = carve.tensor(sr, Carver::pad(na), {B * N, 3});
         } else {
             const auto opt = helios.options();
             o.actual = at::empty({B, N, 3}, opt);
@@ -491,28 +497,31 @@ StepOut step_core(int64_t plane, const at::Tensor& helios, const at::Tensor& sun
     const auto opt = normals.options();
     const float* pn = fp(normals, "action");
     StepOut o;
-    // workspace, the 5 scalars, the per-image and per-ray vectors — and, while the whole step is small (the
-    // launch-bound regime), image / actual / refl / aux too — are sections of ONE block from the caching
-    // allocator (Carver): an at::empty costs 0.7 µs and a view op 0.3–0.4 µs in front of two 3.4 µs launches
+    // Blocks from the caching allocator through the Carver (an at::empty costs 0.7 µs and a view op 0.3–0.4 µs in
+    // front of two 3.4 µs launches), grouped by who keeps what (see kCarveMaxBytes): the 5 scalars alone (a
+    // 256-byte block: metrics are what training loops append to lists); the call's workspace with the per-image
+    // and per-ray monitor vectors; and, while the step is small (the launch-bound regime), the image alone, the
+    // `aux` row alone, actual | refl together.
     const int64_t nws = helio_env_step_workspace((int)B, (int)N, (int)R);
     const int64_t ni = B * R * R, na = B * N * 3, naux = want_aux ? B * (3 + 3 * N) : 0;
     auto P = Carver::pad;
-    const int64_t f_out = P(nws), f_mae = f_out + 64, f_keep = f_mae + P(B), f_align = f_keep + P(B),
-                  f_allb = f_align + P(B * N), f_small = f_allb + P(B * N);
+    const int64_t f_mae = P(nws), f_keep = f_mae + P(B), f_align = f_keep + P(B), f_allb = f_align + P(B * N),
+                  f_small = f_allb + P(B * N);
     const bool carve_all = (f_small + P(ni) + 2 * P(na) + P(naux)) * (int64_t)sizeof(float) <= kCarveMaxBytes;
     const Carver& cv = carver_for(helios);
-    const c10::Storage st = cv.block(carve_all ? f_small + P(ni) + 2 * P(na) + P(naux) : f_small);
+    o.out = cv.tensor(cv.block(64), 0, {5});
+    const c10::Storage st = cv.block(f_small);
     at::Tensor ws = cv.tensor(st, 0, {nws});
-    o.out = cv.tensor(st, f_out, {5});
     o.mae = cv.tensor(st, f_mae, {B});
     o.keep = cv.tensor(st, f_keep, {B});
     o.align = cv.tensor(st, f_align, {B, N});
     o.allb = cv.tensor(st, f_allb, {B, N});
     if (carve_all) {
-        o.image = cv.tensor(st, f_small, {B, R, R});
-        o.actual = cv.tensor(st, f_small + P(ni), {B, N, 3});
-        o.refl = cv.tensor(st, f_small + P(ni) + P(na), {B, N, 3});
-        if (want_aux) o.aux = cv.tensor(st, f_small + P(ni) + 2 * P(na), {B, 3 + 3 * N});
+        o.image = cv.tensor(cv.block(ni), 0, {B, R, R});
+        const c10::Storage sr = cv.block(2 * P(na));
+        o.actual = cv.tensor(sr, 0, {B, N, 3});
+        o.refl = cv.tensor(sr, P(na), {B, N, 3});
+        if (want_aux) o.aux = cv.tensor(cv.block(naux), 0, {B, 3 + 3 * N});
     } else {
         o.actual = at::empty_like(normals);
         o.refl = at::empty_like(normals);

@@ -196,6 +196,12 @@ class HelioField:
         (``helio_error_trig``: ≤ 1 ulp from these values, no host synchronisation)."""
         if errs.is_cuda and (self.device_trig or on_device):
             return _get_ops().error_trig(errs).to(self.device)
+        if errs.is_cuda and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError(
+                "HelioField: the cos/sin table of device-resident error angles is made with torch's CPU kernels (the "
+                "reference's bits) — a device→host→device round trip that cannot be captured in a HIP graph.  Call "
+                "reset_errors() / assign the error tensors BEFORE the capture (the table is cached until they change), "
+                "or set field.device_trig = True (all-device table, ≤ 1 ulp from the CPU one)")
         ang = errs.detach().to(device="cpu", dtype=torch.float32) * 1e-3
         e, u = ang[..., 0], ang[..., 1]
         t = torch.stack([e.cos(), e.sin(), u.cos(), u.sin()], dim=-1)
@@ -226,10 +232,12 @@ class HelioField:
         if batch is not None and B <= batch.shape[0]:
             table = self._cached_trig("batch", batch)           # rows [:B] are a prefix
             return (table if row0 == 0 else table[row0:row0 + rows]), 4 * N
-        # more suns than pre-sampled errors: the reference draws fresh errors on EVERY call (:349-353).  No
-        # fixture can pin a per-call device draw, so its cos/sin are taken by the HIP kernel (the ocml functions
-        # torch's own device kernels call) — no device→host→device round trip per render
-        return self._trig_of(self._sample_error_angles(rows), on_device=True), 4 * N
+        # more suns than pre-sampled errors: the reference draws fresh errors on EVERY call (:349-353).  Their
+        # cos/sin carry torch's CPU bits like every other table (a 1-ulp-different table is 9e-6…1.7e-5 of the
+        # peak at sigma_scale = 0.01, SURVEY App. B — the whole 1e-5 budget): one host round trip per render
+        # on this branch, which HelioEnv never takes (max_batch_size = batch_size); field.device_trig = True
+        # keeps it on the device.  Pinned by test_fresh_error_branch_holds_the_1e5_bar (seeded device draw).
+        return self._trig_of(self._sample_error_angles(rows)), 4 * N
 
     # ------------------------------------------------------------------ optics
     def calculate_ideal_normals(self, sun_position) -> torch.Tensor:

@@ -68,10 +68,12 @@ class ShardedRenderer:
         if b1 > b0:
             out = f.render_rows(sun[b0:b1], act[b0:b1], b0, B, monitor=True)
             img, actual, refl = out
-        else:   # more ranks than rows: this rank contributes padding only
-            img = torch.zeros((0, R, R), device=f.device)
-            actual = torch.zeros((0, N, 3), device=f.device)
-            refl = torch.zeros((0, 3), device=f.device)
+        else:   # more ranks than rows: this rank contributes padding only — empty row blocks that still hang off
+            # `action` in the autograd graph, so that a replicated loss differentiates on every rank (to zeros here)
+            hook = act[:0].sum(dim=(1, 2))
+            img = hook.view(0, 1, 1).expand(0, R, R)
+            actual = hook.view(0, 1, 1).expand(0, N, 3)
+            refl = hook.view(0, 1).expand(0, 3)
         if self.world == 1:
             images = img
         else:

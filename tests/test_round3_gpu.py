@@ -1,0 +1,188 @@
+"""MI355X tests added in round 3: the fresh-error branch of render (B > max_batch_size) at the 1e-5 bar, output
+blocks that do not pin each other, a shard rendered beside a plain render on another thread, and the graph-capture
+guard of the CPU trig round trip.  Run with ``-m gpu``."""
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import torch_oracle as to
+from test_gpu_more import make_case
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.mark.parametrize("err", [90.0, 180.0])
+def test_fresh_error_branch_holds_the_1e5_bar(err):
+    """newenv_rl_test_multi_error.py:347-353: with more suns than pre-sampled errors the reference draws fresh
+    angles on EVERY call.  Seed the device RNG, render; re-seed and re-draw the same angles with
+    ``_sample_error_angles``; the image must meet the oracle fed those angles at the north-star tolerance
+    (sigma_scale = 0.01: a 1-ulp-different cos/sin table would already use up the budget) —
+    and two calls must differ, as in the reference."""
+    N, B, R = 50, 25, 128
+    f, sc, suns, _, act = make_case(N=N, B=B, R=R, sigma=0.01, err=err, seed=int(err) + 7)
+    f.max_batch_size = 10                               # B = 25 > 10: the fresh-sample branch
+    f.reset_errors()
+    assert f.batch_error_angles_mrad.shape[0] == 10 and not f.device_trig
+    a_dev, s_dev = act.to(DEV), suns.to(DEV)
+    torch.manual_seed(4321)
+    with torch.no_grad():
+        img, actual, refl = f.render(s_dev, a_dev, None, monitor=True)
+    torch.manual_seed(4321)
+    errs = f._sample_error_angles(B).cpu()              # the draw render() made
+    assert errs.shape == (B, N, 2) and errs.abs().max().item() > err
+    img_o, actual_o, refl_o = to.render(sc, suns, act, errs, monitor=True)
+    assert np.array_equal(actual.cpu().numpy(), actual_o.numpy())
+    assert np.array_equal(refl.cpu().numpy(), refl_o.numpy())
+    got, ref = img.cpu().numpy(), img_o.numpy()
+    np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-8)
+    assert np.abs(got - ref).max() <= 1e-5 * ref.max()
+    # the autograd path takes the same branch with the same table
+    torch.manual_seed(4321)
+    a_g = a_dev.clone().requires_grad_(True)
+    img_g, _ = f.render(s_dev, a_g, None)
+    assert torch.equal(img_g.detach(), img)
+    (grad,) = torch.autograd.grad(img_g.sum(), a_g)
+    a_cpu = act.clone().requires_grad_(True)
+    (grad_o,) = torch.autograd.grad(to.render(sc, suns, a_cpu, errs)[0].sum(), a_cpu)
+    assert (grad.cpu() - grad_o).abs().max().item() <= 2e-4 * grad_o.abs().max().item()
+    with torch.no_grad():                                # no re-seed: other errors, another image (:349-353)
+        img2, _ = f.render(s_dev, a_dev, None)
+    assert not torch.equal(img2, img)
+
+
+def test_holding_a_metric_or_the_normals_does_not_pin_the_image():
+    """The outputs of the launch-bound paths come from carved allocator blocks (csrc/hostbind.cpp): what a rollout
+    keeps step after step — a 0-dim metric, the `aux` row, `actual` — must not keep the step's image alive."""
+    from doodle_amd import native, synthetic
+    from doodle_amd.env import HelioEnv
+    if native.get_ops().hb is None:
+        pytest.skip("compiled binding not built")
+    w = synthetic.Workload("t", N=50, B=25, R=128)
+    helios, suns, _, noise = synthetic.make_inputs(w, 0)
+    env = HelioEnv(helios.to(DEV), torch.tensor(synthetic.TARGET_POSITION, device=DEV), synthetic.TARGET_AREA,
+                   torch.tensor(synthetic.TARGET_NORMAL, device=DEV), sigma_scale=0.01, error_scale_mrad=90.0,
+                   resolution=w.R, batch_size=w.B, device=DEV, new_errors_every_reset=False)
+    env.set_sun_pos(suns.to(DEV))
+    env.reset()
+    act = env.ideal_normals.reshape(w.B, -1).clone()
+    image_bytes = 4 * w.B * w.R * w.R
+
+    def grow(keep_fn, steps=200):
+        kept = []
+        with torch.no_grad():
+            for _ in range(5):
+                env.step(act)
+            torch.cuda.synchronize()
+            base = torch.cuda.memory_allocated()
+            for _ in range(steps):
+                kept.append(keep_fn(env.step(act)))
+            torch.cuda.synchronize()
+            return (torch.cuda.memory_allocated() - base) / steps
+
+    assert grow(lambda r: r[1]["mse"]) <= 1024                     # one 0-dim metric per step: a 512-byte block, not 1.6 MB
+    assert grow(lambda r: (r[1]["mse"], r[1]["dist"], r[1]["bound"], r[1]["alignment_loss"])) <= 1024
+    assert grow(lambda r: r[0]["aux"]) <= 4 * w.B * (3 + 3 * w.N) + 1024
+    assert grow(lambda r: r[2]["mae_image"]) < image_bytes / 8
+    f = env.noisy_field
+
+    def grow_render(pick, steps=200):
+        kept = []
+        s_dev = suns.to(DEV)
+        with torch.no_grad():
+            for _ in range(5):
+                f.render(s_dev, act, None)
+            torch.cuda.synchronize()
+            base = torch.cuda.memory_allocated()
+            for _ in range(steps):
+                kept.append(pick(f.render(s_dev, act, None, monitor=True)))
+            torch.cuda.synchronize()
+            return (torch.cuda.memory_allocated() - base) / steps
+
+    assert grow_render(lambda r: r[1]) <= 2 * 12 * w.B * w.N + 1024  # `actual` pins at most actual | refl, never the image
+    assert image_bytes <= grow_render(lambda r: r[0]) <= image_bytes + 1024
+
+
+def test_a_shard_and_a_plain_render_on_two_threads_keep_their_own_kernels():
+    """render_rows forces the whole batch's kernel on its piece by ARGUMENT (helio_render_fwd's variant), not through
+    the process-wide ops object: a plain render of another field on another thread meanwhile keeps its own size
+    rule.  Both stay bit-identical with their single-threaded results, across kernel regimes."""
+    from doodle_amd import native
+    ops = native.get_ops()
+    # field A: shards [3:9] of a 64-sun batch (the whole batch takes another kernel than the 6-sun piece would)
+    fa, _, suns_a, _, act_a = make_case(N=300, B=64, R=256, seed=21)
+    # field B: a small problem (single-launch kernel) and a mid one
+    fb, _, suns_b, _, act_b = make_case(N=50, B=25, R=128, seed=22)
+    sa, aa, sb, ab = suns_a.to(DEV), act_a.to(DEV), suns_b.to(DEV), act_b.to(DEV)
+    assert ops.render_choice(64, 300, 256) != ops.render_choice(6, 300, 256)
+    with torch.no_grad():
+        full_a, _ = fa.render(sa, aa, None)
+        want_a = full_a[3:9].clone()
+        want_b, _ = fb.render(sb, ab, None)
+        want_b = want_b.clone()
+    torch.cuda.synchronize()
+    errors, stop = [], threading.Event()
+
+    def shard_loop():
+        try:
+            stream = torch.cuda.Stream()
+            with torch.cuda.stream(stream), torch.no_grad():
+                for _ in range(300):
+                    img, _, _ = fa.render_rows(sa[3:9], aa[3:9], 3, 64)
+                    stream.synchronize()
+                    if not torch.equal(img, want_a):
+                        errors.append("shard differs")
+                        break
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+        finally:
+            stop.set()
+
+    def plain_loop():
+        try:
+            stream = torch.cuda.Stream()
+            with torch.cuda.stream(stream), torch.no_grad():
+                while not stop.is_set():
+                    img, _ = fb.render(sb, ab, None)
+                    stream.synchronize()
+                    if not torch.equal(img, want_b):
+                        errors.append("plain render differs")
+                        break
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    t1, t2 = threading.Thread(target=shard_loop), threading.Thread(target=plain_loop)
+    t2.start(); t1.start()
+    t1.join(120); stop.set(); t2.join(120)
+    assert not errors, errors
+    assert ops.splat_variant == 0
+
+
+def test_cpu_trig_round_trip_is_refused_under_graph_capture_with_a_clear_message():
+    """reset_errors() on device tensors downloads the angles for torch's CPU cos/sin (the reference's bits): illegal
+    while a HIP graph is being captured — a clear error instead of a broken capture; device_trig = True captures."""
+    f, _, suns, _, act = make_case(N=50, B=25, R=64, seed=5)
+    f.batch_error_angles_mrad = f.batch_error_angles_mrad.to(DEV)
+    f.error_angles_mrad = f.error_angles_mrad.to(DEV)
+    s_dev, a_dev = suns.to(DEV), act.to(DEV)
+    with torch.no_grad():
+        f.render(s_dev, a_dev, None)                   # tables made outside any capture
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        graph = torch.cuda.CUDAGraph()
+        with pytest.raises(RuntimeError, match="cannot be captured"):
+            with torch.cuda.graph(graph, stream=side):
+                f.reset_errors()
+    torch.cuda.synchronize()
+    f.device_trig = True
+    with torch.cuda.stream(side):
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side), torch.no_grad():
+            f.reset_errors()
+            img, _ = f.render(s_dev, a_dev, None)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.isfinite(img).all() and float(img.max()) > 0

@@ -5,6 +5,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -38,7 +39,7 @@ def test_render_rows_equals_full_render(monkeypatch):
     assert np.array_equal(full.numpy(), g["image"]) or np.allclose(full.numpy(), g["image"], rtol=1e-5, atol=1e-8)
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, nsuns):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -46,15 +47,15 @@ def _worker(rank, world, port, out_dir):
         ops = oracle_backend.OracleOps()
         field_mod._get_ops = lambda: ops
         from doodle_amd.sharded import ShardedRenderer
-        g = golden("g8_ragged_n201_b7_r48")          # B = 7: ragged over 2 ranks (4 + 3 rows)
+        g = golden("g8_ragged_n201_b7_r48")          # B = 7: ragged over 2, 3 and 4 ranks
         f = field_from(g)
-        sun = torch.from_numpy(g["sun"])
-        act = torch.from_numpy(g["action"]).clone().requires_grad_(True)
+        sun = torch.from_numpy(g["sun"])[:nsuns]
+        act = torch.from_numpy(g["action"])[:nsuns].clone().requires_grad_(True)
         sr = ShardedRenderer(f)
         images, actual, refl = sr.render(sun, act, monitor=True, gather_geometry=True)
-        G = torch.from_numpy(g["G"])
+        G = torch.from_numpy(g["G"])[:nsuns]
         (ga,) = torch.autograd.grad((images * G).sum(), act)   # replicated loss; no backward collective
-        b0, b1 = sr.local_rows(7)
+        b0, b1 = sr.local_rows(nsuns)
         # second call with the same inputs: sharded renders stay deterministic
         images2, _ = sr.render(sun, act.detach())
         torch.save({"images": images.detach(), "actual": actual.detach(), "refl": refl.detach(),
@@ -64,24 +65,34 @@ def _worker(rank, world, port, out_dir):
         dist.destroy_process_group()
 
 
-def test_gloo_two_ranks_bit_identical_to_unsharded(tmp_path, monkeypatch):
+@pytest.mark.parametrize("world,nsuns,rows", [
+    (2, 7, [(0, 4), (4, 7)]),
+    (3, 7, [(0, 3), (3, 6), (6, 7)]),
+    (4, 7, [(0, 2), (2, 4), (4, 6), (6, 7)]),
+    (3, 2, [(0, 1), (1, 2), (2, 2)]),          # more ranks than suns: the last rank renders nothing (padding only)
+    (4, 5, [(0, 2), (2, 4), (4, 5), (5, 5)]),
+])
+def test_gloo_ranks_bit_identical_to_unsharded(tmp_path, monkeypatch, world, nsuns, rows):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, port, str(tmp_path), nsuns), nprocs=world, join=True)
     oracle_backend.install(monkeypatch)
     g = golden("g8_ragged_n201_b7_r48")
     f = field_from(g)
-    act = torch.from_numpy(g["action"]).clone().requires_grad_(True)
-    full, actual, refl = f.render(torch.from_numpy(g["sun"]), act, None, monitor=True)
-    (gfull,) = torch.autograd.grad((full * torch.from_numpy(g["G"])).sum(), act)
-    outs = [torch.load(os.path.join(tmp_path, f"rank{r}.pt")) for r in range(2)]
-    assert [o["rows"] for o in outs] == [(0, 4), (4, 7)]
+    act = torch.from_numpy(g["action"])[:nsuns].clone().requires_grad_(True)
+    full, actual, refl = f.render(torch.from_numpy(g["sun"])[:nsuns], act, None, monitor=True)
+    (gfull,) = torch.autograd.grad((full * torch.from_numpy(g["G"])[:nsuns]).sum(), act)
+    outs = [torch.load(os.path.join(tmp_path, f"rank{r}.pt")) for r in range(world)]
+    assert [o["rows"] for o in outs] == rows
+    total = torch.zeros_like(gfull)
     for o in outs:
         assert o["same"]
         assert torch.equal(o["images"], full.detach())             # every rank holds the full batch
         assert torch.equal(o["actual"], actual.detach()) and torch.equal(o["refl"], refl.detach())
         b0, b1 = o["rows"]
-        assert torch.equal(o["grad"][b0:b1], gfull[b0:b1])         # own rows: full gradient
+        assert torch.equal(o["grad"][b0:b1], gfull[b0:b1])         # own rows: full gradient (per rank)
         other = torch.cat([o["grad"][:b0], o["grad"][b1:]])
-        assert float(other.abs().max()) == 0.0                     # foreign rows: none (no collective)
+        assert other.numel() == 0 or float(other.abs().max()) == 0.0   # foreign rows: none (no collective)
+        total += o["grad"]
+    assert torch.equal(total, gfull)                               # the ranks' gradients tile the batch exactly
