@@ -21,6 +21,7 @@ void launch_init_actions(long, const float*, const float*, float, float*, hipStr
 int launch_splat_fwd(int, int, int, const float*, const float*, const float*, float*, int, void*, long, hipStream_t);
 int launch_splat_bwd(int, int, int, const float*, const float*, const float*, const float*, float*, int, void*, long, hipStream_t);
 long splat_fwd_scratch_bytes(int, int, int, int);
+long splat_fwd_scratch_required(int, int, int, int);
 long splat_bwd_scratch_bytes(int, int, int, int);
 int splat_bwd_blocks(int);
 bool render_is_fused(int, int, int);
@@ -123,9 +124,11 @@ int helio_splat_fwd(int B, int N, int R, const float* rays_d, const float* xs_d,
     if (!rays_d || !xs_d || !ys_d || !image_d) return fail(HELIO_E_INVALID, "splat_fwd: null pointer");
     if (!aligned16(rays_d) || !aligned16(image_d)) return fail(HELIO_E_INVALID, "splat_fwd: rays/image must be 16-byte aligned");
     if (!scratch_ok(scratch_d, scratch_bytes)) return fail(HELIO_E_INVALID, "splat_fwd: scratch must be 256-byte aligned");
-    if (helio::launch_splat_fwd(B, N, R, rays_d, xs_d, ys_d, image_d, variant, scratch_d, scratch_bytes,
-                                static_cast<hipStream_t>(stream)) != HELIO_OK)
-        return fail(HELIO_E_INVALID, "splat_fwd: unknown variant %d", variant);
+    if (const int rc = helio::launch_splat_fwd(B, N, R, rays_d, xs_d, ys_d, image_d, variant, scratch_d, scratch_bytes,
+                                               static_cast<hipStream_t>(stream)); rc != HELIO_OK)
+        return rc == HELIO_E_SCRATCH ? fail(rc, "splat_fwd: variant %d at B=%d N=%d R=%d needs %ld bytes of scratch", variant, B, N, R,
+                                            helio::splat_fwd_scratch_required(B, N, R, variant))
+                                     : fail(HELIO_E_INVALID, "splat_fwd: unknown variant %d", variant);
     return after_launch("splat_fwd");
 }
 
@@ -149,9 +152,14 @@ int helio_render_fwd(int B, int N, int R, const float* helios_d, const float* su
         return after_launch("render_fwd(fused)");
     }
     if (!rays_d) return fail(HELIO_E_INVALID, "render_fwd: this problem size needs the rays work buffer");
+    if (const long need = helio::splat_fwd_scratch_required(B, N, R, variant); need > 0 && (!scratch_d || scratch_bytes < need))
+        return fail(HELIO_E_SCRATCH, "render_fwd: variant %d at B=%d N=%d R=%d needs %ld bytes of scratch", variant, B, N, R, need);
     helio::launch_geometry_fwd(B, N, helios_d, sun_d, action_d, trig_d, trig_b_stride, plane, actual_d, refl_d, rays_d, st);
-    if (helio::launch_splat_fwd(B, N, R, rays_d, xs_d, ys_d, image_d, variant, scratch_d, scratch_bytes, st) != HELIO_OK)
-        return fail(HELIO_E_INVALID, "render_fwd: unknown variant %d", variant);
+    if (const int rc = helio::launch_splat_fwd(B, N, R, rays_d, xs_d, ys_d, image_d, variant, scratch_d, scratch_bytes, st);
+        rc != HELIO_OK)
+        return rc == HELIO_E_SCRATCH ? fail(rc, "render_fwd: variant %d at B=%d N=%d R=%d needs %ld bytes of scratch", variant, B, N, R,
+                                            helio::splat_fwd_scratch_required(B, N, R, variant))
+                                     : fail(HELIO_E_INVALID, "render_fwd: unknown variant %d", variant);
     return after_launch("render_fwd");
 }
 
@@ -163,6 +171,12 @@ long helio_fwd_scratch_bytes(int B, int N, int R, int variant) {
     if (!sizes_ok(B, N) || R < 1 || R > 16384) return 0;
     if (((variant == 0 || variant == 2) && helio::render_is_fused(B, N, R)) || fused_form(variant)) return 0;
     return helio::splat_fwd_scratch_bytes(B, N, R, variant);
+}
+
+long helio_fwd_scratch_required(int B, int N, int R, int variant) {
+    if (!sizes_ok(B, N) || R < 1 || R > 16384) return 0;
+    if (((variant == 0 || variant == 2) && helio::render_is_fused(B, N, R)) || fused_form(variant)) return 0;
+    return helio::splat_fwd_scratch_required(B, N, R, variant);
 }
 
 long helio_bwd_scratch_bytes(int B, int N, int R, int variant) {

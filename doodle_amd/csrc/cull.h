@@ -78,13 +78,15 @@ __device__ __forceinline__ bool cull_dead_strict(const float4 ray, const CullBox
 // Which workgroup computes a tile does not enter any result.
 //
 // ---- scratch layouts (device memory handed in by the caller; helio_*_scratch_bytes) ----------------
-// forward:  int counts[T] | int order[T] | float4 lists[T][N]          T = B·tiles², tile = TE×TE pixels
+// forward:  int counts[T] | int order[T] | float4 lists[T][P]          T = B·tiles²·S, tile = TE×TE pixels;
+//           S = 1, P = N normally; with the heliostat sum split across workgroups (splat_fwd.hip, "split"),
+//           S parts of P consecutive rays each and one list per (image, tile, part)
 // backward: int counts[B] | int idx[B][N] | int total (+pad) | int2 map[B·⌈N/256⌉]
 // (every section padded to 256 bytes)
 __host__ __device__ inline long cull_pad256(long bytes) { return (bytes + 255) & ~255l; }
-inline long cull_fwd_bytes(int B, int N, int R, int TE) {
-    const long t = (R + TE - 1) / TE, T = (long)B * t * t;
-    return 2 * cull_pad256(4 * T) + 16 * T * N;
+inline long cull_fwd_bytes(int B, int N, int R, int TE, int S = 1, int P = 0) {
+    const long t = (R + TE - 1) / TE, T = (long)B * t * t * S;
+    return 2 * cull_pad256(4 * T) + 16 * T * (S > 1 ? P : N);
 }
 constexpr int CULL_BWD_TILE = 256;           // rays per tile of splat_bwd_mfma
 inline long cull_bwd_bytes(int B, int N) {
@@ -96,7 +98,7 @@ struct CullFwd { const int* counts; const int* order; const float4* lists; };   
 struct CullBwd { const int* counts; const int* idx; const int* total; const int2* map; };
 
 // launchers (cull.hip)
-CullFwd launch_cull_fwd(int B, int N, int R, int TE, const float* rays, const float* xs, const float* ys,
+CullFwd launch_cull_fwd(int B, int N, int R, int TE, int S, int P, const float* rays, const float* xs, const float* ys,
                         void* scratch, hipStream_t st);
 CullBwd launch_cull_bwd(int B, int N, int R, int JB, const float* rays, const float* xs, const float* ys,
                         float* moments, void* scratch, hipStream_t st);

@@ -50,21 +50,24 @@ __device__ __forceinline__ int block_rank(bool flag, int* sw, int& total) {
     return before + rank;
 }
 
-// grid (tiles², B): the rays of image b that are not exactly zero on tile (ti, tj) — blockIdx.x = ti·tiles + tj,
-// the tile numbering of the footprint kernels
+// grid (tiles²·S, B): the rays [part·P, part·P + P) of image b that are not exactly zero on tile (ti, tj) —
+// blockIdx.x = (ti·tiles + tj)·S + part, the tile (and part) numbering of the footprint kernels; S = 1, P = N:
+// the whole image's rays
 __global__ void __launch_bounds__(CULL_THREADS)
-cull_fwd_kernel(int N, int R, int TE, const float4* __restrict__ rays, const float* __restrict__ xs,
+cull_fwd_kernel(int Nall, int R, int TE, int S, int P, const float4* __restrict__ rays, const float* __restrict__ xs,
                 const float* __restrict__ ys, int* __restrict__ counts, float4* __restrict__ lists) {
     __shared__ float sm[3 * CULL_WAVES];
     __shared__ int sw[CULL_WAVES];
     const int tiles = (R + TE - 1) / TE;
-    const int b = blockIdx.y, ti = blockIdx.x / tiles, tj = blockIdx.x % tiles;
+    const int tile = blockIdx.x / S, part = blockIdx.x % S;
+    const int b = blockIdx.y, ti = tile / tiles, tj = tile % tiles;
     CullBox bx;
     block_minmax(xs, ti * TE, min(R, ti * TE + TE), sm, bx.xlo, bx.xhi);
     block_minmax(ys, tj * TE, min(R, tj * TE + TE), sm, bx.ylo, bx.yhi);
     const long list = (long)b * gridDim.x + blockIdx.x;
-    const float4* __restrict__ rb = rays + (long)b * N;
-    float4* __restrict__ out = lists + list * N;
+    const int first = part * P, N = max(0, min(Nall - first, P));
+    const float4* __restrict__ rb = rays + (long)b * Nall + first;
+    float4* __restrict__ out = lists + list * P;
     int base = 0;
     for (int n0 = 0; n0 < N; n0 += CULL_THREADS) {
         const int n = n0 + (int)threadIdx.x;
@@ -178,17 +181,18 @@ bool cull_enabled() {
     return on;
 }
 
-CullFwd launch_cull_fwd(int B, int N, int R, int TE, const float* rays, const float* xs, const float* ys,
+CullFwd launch_cull_fwd(int B, int N, int R, int TE, int S, int P, const float* rays, const float* xs, const float* ys,
                         void* scratch, hipStream_t st) {
     const int t = (R + TE - 1) / TE;
-    const long T = (long)B * t * t;
+    const long T = (long)B * t * t * S;
+    if (S == 1) P = N;
     char* base = static_cast<char*>(scratch);
     int* counts = reinterpret_cast<int*>(base);
     int* order = reinterpret_cast<int*>(base + cull_pad256(4 * T));
     float4* lists = reinterpret_cast<float4*>(base + 2 * cull_pad256(4 * T));
-    hipLaunchKernelGGL(cull_fwd_kernel, dim3(t * t, B), dim3(CULL_THREADS), 0, st, N, R, TE,
+    hipLaunchKernelGGL(cull_fwd_kernel, dim3(t * t * S, B), dim3(CULL_THREADS), 0, st, N, R, TE, S, P,
                        reinterpret_cast<const float4*>(rays), xs, ys, counts, lists);
-    hipLaunchKernelGGL(cull_order_fwd_kernel, dim3(1), dim3(ORDER_THREADS), 0, st, (int)T, N, counts, order);
+    hipLaunchKernelGGL(cull_order_fwd_kernel, dim3(1), dim3(ORDER_THREADS), 0, st, (int)T, P, counts, order);
     return CullFwd{counts, order, lists};
 }
 

@@ -41,14 +41,16 @@ void* cur_stream(const at::Tensor& t) { return (void*)c10::hip::getCurrentHIPStr
 // torch's caching allocator when the kernels the call will run can use one (large problems: the lists of rays
 // that are not exactly zero on a tile), nothing otherwise — the query is a few integer operations.  The block
 // is free again when the call returns: the allocator's stream ordering covers its reuse.
-// set_use_scratch(false) makes every call run dense (A/B runs, the dense roofline measurement).
+// set_use_scratch(false) makes every call run dense (A/B runs, the dense roofline measurement): only what a
+// kernel cannot do without (helio_fwd_scratch_required: the partial images of a split heliostat sum) is handed over.
 std::atomic<bool> g_use_scratch{true};
 struct Scratch {
     at::Tensor t;
     void* p = nullptr;
     long bytes = 0;
-    Scratch(long n, const at::Tensor& like) {
-        if (n > 0 && g_use_scratch.load(std::memory_order_relaxed)) {
+    Scratch(long n, const at::Tensor& like, long required = 0) {
+        if (!g_use_scratch.load(std::memory_order_relaxed)) n = required;
+        if (n > 0) {
             t = at::empty({(int64_t)n}, like.options().dtype(at::kByte));
             p = t.data_ptr();
             bytes = n;
@@ -56,7 +58,8 @@ struct Scratch {
     }
 };
 Scratch fwd_scratch(int64_t B, int64_t N, int64_t R, int64_t variant, const at::Tensor& like) {
-    return Scratch(helio_fwd_scratch_bytes((int)B, (int)N, (int)R, (int)variant), like);
+    return Scratch(helio_fwd_scratch_bytes((int)B, (int)N, (int)R, (int)variant), like,
+                   helio_fwd_scratch_required((int)B, (int)N, (int)R, (int)variant));
 }
 Scratch bwd_scratch(int64_t B, int64_t N, int64_t R, int64_t variant, const at::Tensor& like) {
     return Scratch(helio_bwd_scratch_bytes((int)B, (int)N, (int)R, (int)variant), like);

@@ -455,7 +455,8 @@ template <int W, bool TWO_LEVEL>
 __global__ void __launch_bounds__(64 * W * W)
 splat_fwd_mfma_tile(int B, int Nall, int R, const float* __restrict__ rays, const float* __restrict__ xs,
                     const float* __restrict__ ys, float* __restrict__ image, const int* __restrict__ live_counts,
-                    const int* __restrict__ live_order, const float4* __restrict__ live_lists) {
+                    const int* __restrict__ live_order, const float4* __restrict__ live_lists, int S, int P,
+                    float* __restrict__ partials) {
     // row pitch: odd for the 4-wave form (ds_write_b32 per factor), T+2 for the 16-wave form, whose
     // producer stores factor PAIRS with ds_write_b64 (8-byte aligned rows; 16 lanes × 2 dwords
     // at pitch 258 cover the 32 banks exactly once)
@@ -468,6 +469,8 @@ splat_fwd_mfma_tile(int B, int Nall, int R, const float* __restrict__ rays, cons
     const int tiles_j = (R + T - 1) / T;
     // the workgroup's (image, tile): its place in the grid, or — with lists (cull.h) — the entry of the work
     // order at its linear id (longest list first)
+    // With S > 1 the heliostat sum is SPLIT: blockIdx.x = tile·S + part, part p sums the rays [p·P, p·P + P) into
+    // partials[b][p] (an R×R image of its own), which splat_reduce_parts adds in part order (launch_splat_fwd).
     int b = blockIdx.y, tile = blockIdx.x;
     long list = 0;
     if (live_counts) {
@@ -475,6 +478,8 @@ splat_fwd_mfma_tile(int B, int Nall, int R, const float* __restrict__ rays, cons
         b = (int)(list / gridDim.x);
         tile = (int)(list % gridDim.x);
     }
+    int part = 0;
+    if (S > 1) { part = tile % S; tile /= S; }
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int lr = lane & 31, lh = lane >> 5;
     const int ti0 = (tile / tiles_j) * T, tj0 = (tile % tiles_j) * T;
@@ -493,9 +498,10 @@ splat_fwd_mfma_tile(int B, int Nall, int R, const float* __restrict__ rays, cons
     // the tile's rays: all of the image's, or (cull.h) the ordered list of those that are not exactly zero here
     const float4* __restrict__ rb = reinterpret_cast<const float4*>(rays) + (long)b * Nall;
     int N = Nall;
+    if (S > 1) { rb += part * P; N = max(0, min(Nall - part * P, P)); }
     if (live_counts) {
         N = live_counts[list];
-        rb = live_lists + list * Nall;
+        rb = live_lists + list * (S > 1 ? P : Nall);
     }
     float4 g = (lane < N) ? rb[lane] : pad;
 
@@ -590,10 +596,24 @@ splat_fwd_mfma_tile(int B, int Nall, int R, const float* __restrict__ rays, cons
         }
     }
 
-    float* __restrict__ img = image + (long)b * R * R;
+    float* __restrict__ img = S > 1 ? partials + ((long)b * S + part) * R * R : image + (long)b * R * R;
 #pragma unroll
     for (int m = 0; m < 4; ++m)
         store_block(img, R, ti0 + wi + 32 * (m >> 1), tj0 + wj + 32 * (m & 1), lr, lh, TWO_LEVEL ? tot[m] : acc[m]);
+}
+
+// image[b] = ((partials[b][0] + partials[b][1]) + partials[b][2]) + … — the parts of a split heliostat sum, added
+// in part order (round to nearest each): the bits depend on N, R and S, not on which workgroup ran when
+__global__ void __launch_bounds__(256)
+splat_reduce_parts(long pixels_per_image, int S, const float* __restrict__ partials, float* __restrict__ image) {
+    const int b = blockIdx.y;
+    const float* __restrict__ src = partials + (long)b * S * pixels_per_image;
+    float* __restrict__ dst = image + (long)b * pixels_per_image;
+    for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < pixels_per_image; p += (long)gridDim.x * blockDim.x) {
+        float v = src[p];
+        for (int k = 1; k < S; ++k) v += src[(long)k * pixels_per_image + p];
+        dst[p] = v;
+    }
 }
 
 // Small problems are launch-latency bound (config 2 is 41 MFLOP ≈ 0.3 µs at peak): ONE launch for
@@ -1196,7 +1216,8 @@ static void launch_regs(int B, int N, int R, const float* rays, const float* xs,
 
 template <int W, bool TWO_LEVEL>
 static void launch_tile(int B, int N, int R, const float* rays, const float* xs, const float* ys,
-                        float* image, hipStream_t st, CullFwd cull = CullFwd{nullptr, nullptr, nullptr}) {
+                        float* image, hipStream_t st, CullFwd cull = CullFwd{nullptr, nullptr, nullptr}, int S = 1, int P = 0,
+                        float* partials = nullptr) {
     constexpr int T = 64 * W;
     const int t = (R + T - 1) / T;
     const size_t lds = (2 * 64 * (T + (W == 4 ? 2 : 1)) + 2 * T) * sizeof(float);
@@ -1206,8 +1227,8 @@ static void launch_tile(int B, int N, int R, const float* rays, const float* xs,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         configured = true;
     }
-    hipLaunchKernelGGL((splat_fwd_mfma_tile<W, TWO_LEVEL>), dim3(t * t, B), dim3(64 * W * W), lds, st,
-                       B, N, R, rays, xs, ys, image, cull.counts, cull.order, cull.lists);
+    hipLaunchKernelGGL((splat_fwd_mfma_tile<W, TWO_LEVEL>), dim3(t * t * S, B), dim3(64 * W * W), lds, st,
+                       B, N, R, rays, xs, ys, image, cull.counts, cull.order, cull.lists, S, P, partials);
 }
 
 
@@ -1465,12 +1486,22 @@ static int splat_fwd_choice(int B, int N, int R) {
     // register-operand kernel once ITS tiles fill the chip; below that, 32² blocks with the heliostat sum
     // split over the waves of a workgroup where it is long, else 64² tiles.
     if (N >= 200 && R > 128 && t256 >= 192) return 5;
+    // between 24 and 192 such tiles — tens of images of a large field — the 256² kernel with the heliostat sum
+    // split across workgroups (variants 14..16, below): as many parts as fill the chip, while a part keeps at
+    // least 7 of the kernel's 64-ray chunks.  tools/sweep_split.py (profiles/r03_c_sweep_split.txt): B = 32,
+    // N = 5000, R = 256: 256 → 215 µs (k-split blocks before); B = 64: 464 → 371 µs (128² register tiles
+    // before); B = 16, N = 5000, R = 512: 458 → 357 µs.  HELIO_SPLIT=0 switches the choice off.
+    static const bool no_split = [] { const char* e = getenv("HELIO_SPLIT"); return e && e[0] == '0'; }();
+    if (!no_split && R > 128 && t256 >= 24) {
+        const int S = t256 >= 96 ? 2 : t256 >= 48 ? 4 : 8;
+        if (N / S >= 448) return S == 2 ? 14 : S == 4 ? 15 : 16;
+    }
     if (t128 >= 192 && R > 64) return 3;
     return ksplit_parts(B, N, R) ? 9 : 6;
 }
 
 // What helio_render_fwd's variant 0 resolves to for (B, N, R): 10..13 (a form of the single-launch kernel)
-// or 3, 5, 6, 9 (geometry + that splat kernel).  A caller that renders a batch in pieces — one shard per
+// or 3, 5, 6, 9, 14..16 (geometry + that splat kernel).  A caller that renders a batch in pieces — one shard per
 // GPU — passes the choice of the WHOLE batch with every piece and gets the rows of the unsharded render
 // bit for bit.  (The few-ray form assumes 16-byte aligned images, as torch's allocations are.)
 int render_fwd_choice(int B, int N, int R) {
@@ -1481,6 +1512,16 @@ int render_fwd_choice(int B, int N, int R) {
     return splat_fwd_choice(B, N, R);
 }
 
+// Variants 14..17: the 256² LDS-table kernel with the heliostat sum SPLIT into S = 2, 4, 8, 16 parts of P
+// consecutive rays (P a multiple of the kernel's 64-ray chunk): few images of many heliostats do not give the
+// chip 256 tiles, but tiles × parts do.  A part is summed from zero by a workgroup of its own into a partial
+// image in the caller's scratch, and splat_reduce_parts adds the S partial images in part order — the bits are
+// a function of N, R and S only, so a shard of a batch forced to the whole batch's variant reproduces its rows.
+// These variants NEED the scratch (HELIO_E_SCRATCH without it): the partial images live there.
+static int split_parts(int variant) { return variant >= 14 && variant <= 17 ? 2 << (variant - 14) : 1; }
+static int split_part_rays(int N, int S) { return (((N + S - 1) / S) + 63) & ~63; }
+static long split_partial_bytes(int B, int R, int S) { return S > 1 ? cull_pad256(4l * B * S * R * R) : 0; }
+
 // Skipping exactly-zero rays (cull.h): the one-level LDS-table / register-operand kernels take a per-tile list of
 // the rays that are not exactly zero on their tile.  (The two-level and part-wise kernels — 64² tiles, k-split —
 // round at chunk boundaries, which a compacted list would move; the split-bf16 kernels align products against
@@ -1489,21 +1530,39 @@ int render_fwd_choice(int B, int N, int R) {
 static int cull_fwd_tile(int variant, int B, int N, int R) {
     if (variant == 0 || variant == 2) variant = splat_fwd_choice(B, N, R);
     if (!cull_enabled() || N < 192) return 0;
-    return variant == 5 ? 256 : (variant == 3 || variant == 4) ? 128 : 0;
+    return (variant == 5 || split_parts(variant) > 1) ? 256 : (variant == 3 || variant == 4) ? 128 : 0;
 }
 
+// bytes a call can use (partial images of a split sum + the lists); and the part of it the call cannot do without
 long splat_fwd_scratch_bytes(int B, int N, int R, int variant) {
-    const int te = cull_fwd_tile(variant, B, N, R);
-    return te ? cull_fwd_bytes(B, N, R, te) : 0;
+    if (variant == 0 || variant == 2) variant = splat_fwd_choice(B, N, R);
+    const int S = split_parts(variant), te = cull_fwd_tile(variant, B, N, R);
+    return split_partial_bytes(B, R, S) + (te ? cull_fwd_bytes(B, N, R, te, S, split_part_rays(N, S)) : 0);
+}
+long splat_fwd_scratch_required(int B, int N, int R, int variant) {
+    if (variant == 0 || variant == 2) variant = splat_fwd_choice(B, N, R);
+    return split_partial_bytes(B, R, split_parts(variant));
 }
 
 int launch_splat_fwd(int B, int N, int R, const float* rays, const float* xs, const float* ys,
                      float* image, int variant, void* scratch, long scratch_bytes, hipStream_t st) {
     const long t128 = (long)B * ((R + 127) / 128) * ((R + 127) / 128);
     if (variant == 0 || variant == 2) variant = splat_fwd_choice(B, N, R);
+    const int S = split_parts(variant), P = split_part_rays(N, S);
+    const long part_bytes = split_partial_bytes(B, R, S);
+    if (S > 1 && (!scratch || scratch_bytes < part_bytes)) return HELIO_E_SCRATCH;
     CullFwd cull{nullptr, nullptr, nullptr};
-    if (const int te = scratch ? cull_fwd_tile(variant, B, N, R) : 0; te && scratch_bytes >= cull_fwd_bytes(B, N, R, te))
-        cull = launch_cull_fwd(B, N, R, te, rays, xs, ys, scratch, st);
+    if (const int te = scratch ? cull_fwd_tile(variant, B, N, R) : 0;
+        te && scratch_bytes >= part_bytes + cull_fwd_bytes(B, N, R, te, S, P))
+        cull = launch_cull_fwd(B, N, R, te, S, P, rays, xs, ys, static_cast<char*>(scratch) + part_bytes, st);
+    if (S > 1) {
+        float* partials = static_cast<float*>(scratch);
+        launch_tile<4, false>(B, N, R, rays, xs, ys, image, st, cull, S, P, partials);
+        const long px = (long)R * R;
+        hipLaunchKernelGGL(splat_reduce_parts, dim3((unsigned)min(4096l, (px + 255) / 256), B), dim3(256), 0, st, px, S,
+                           partials, image);
+        return HELIO_OK;
+    }
     switch (variant) {
     case 9: {       // the k-split block kernel; forced: 16 waves where the rule would not choose it
         const int kp = ksplit_parts(B, N, R);

@@ -26,6 +26,7 @@ EXPORTS = (
     "helio_env_step_workspace", "helio_env_step_launches", "helio_render_fwd_choice", "helio_env_step_fwd",
     "helio_notify_create", "helio_notify_destroy", "helio_notify_wait",
     "helio_env_step_bwd_image_ws", "helio_env_step_bwd", "helio_fwd_scratch_bytes", "helio_bwd_scratch_bytes",
+    "helio_fwd_scratch_required",
 )
 ABI_VERSION = 2
 
@@ -64,6 +65,7 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
         "helio_render_bwd": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _l, pp] + [_vp] * 8 + [_i, _vp, _l, _vp]),
         "helio_fwd_scratch_bytes": (_l, [_i, _i, _i, _i]),
         "helio_bwd_scratch_bytes": (_l, [_i, _i, _i, _i]),
+        "helio_fwd_scratch_required": (_l, [_i, _i, _i, _i]),
         "helio_render_fwd_launches": (_i, [_i, _i, _i]),
         "helio_splat_bwd_blocks": (_i, [_i]),
         "helio_splat_bwd": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _l, _vp]),
@@ -196,7 +198,10 @@ class HipOps:
 
     def _scratch(self, query, B, N, R, variant, like, cull=None):
         """→ (tensor keeping it alive | None, pointer | None, bytes) of the optional device scratch."""
-        n = query(int(B), int(N), int(R), int(variant)) if (self.cull if cull is None else cull) else 0
+        if self.cull if cull is None else cull:
+            n = query(int(B), int(N), int(R), int(variant))
+        else:       # dense: only what the kernel cannot do without (the partial images of a split heliostat sum)
+            n = self.lib.helio_fwd_scratch_required(int(B), int(N), int(R), int(variant)) if query is self.lib.helio_fwd_scratch_bytes else 0
         if n <= 0:
             return None, None, 0
         t = torch.empty(n, dtype=torch.uint8, device=like.device)

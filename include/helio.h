@@ -39,6 +39,7 @@ extern "C" {
 #define HELIO_E_NODEVICE   -3   /* no HIP device / wrong architecture            */
 #define HELIO_E_TIMEOUT    -4   /* helio_notify_wait: the record was not written in time */
 #define HELIO_E_STALE      -5   /* helio_notify_wait: the slot was reused by a later ticket */
+#define HELIO_E_SCRATCH    -6   /* the kernel this call runs NEEDS device scratch (helio_fwd_scratch_required) */
 
 /* Receiver plane, HOST memory (passed by value to the kernels).
  * origin = target_position, normal = unit target normal (ctor :184-192),
@@ -78,6 +79,13 @@ typedef struct helio_plane {
  */
 long helio_fwd_scratch_bytes(int B, int N, int R, int variant);
 long helio_bwd_scratch_bytes(int B, int N, int R, int variant);
+/*
+ * The part of helio_fwd_scratch_bytes a forward call cannot do without (0 for most sizes): forward variants
+ * 14..17 — the 256x256 LDS-table kernel with the heliostat sum split into 2, 4, 8, 16 parts across workgroups,
+ * for few images of many heliostats — keep their partial images in the scratch and return HELIO_E_SCRATCH when
+ * handed less.  A caller that always passes helio_fwd_scratch_bytes() never sees that code.
+ */
+long helio_fwd_scratch_required(int B, int N, int R, int variant);
 
 int         helio_abi_version(void);
 const char *helio_last_error_string(void);
@@ -130,6 +138,11 @@ int helio_geometry_fwd(int B, int N,
  * levels (16 rays on the pipe, then a round-to-nearest vector add): against fp64 at N = 2000 its
  * worst per-pixel relative error is 8.6e-7, tighter than the exact-f32 MFMA kernel's one-level
  * chain (1.2e-6), at 1.77x its speed; 8 sums in one level: 2.5e-6, 2.03x.
+ * 14, 15, 16, 17 = the 256x256 LDS-table kernel with the heliostat sum split into 2, 4, 8, 16 parts of consecutive
+ * rays across workgroups (each part summed from zero into a partial image in the caller's scratch, the partial
+ * images added in part order: bits a function of N, R and the variant): what 0 chooses for tens of images of a
+ * large field (24 <= B*ceil(R/256)^2 < 192 tiles and >= 448 rays per part; HELIO_SPLIT=0 switches the choice
+ * off).  These need helio_fwd_scratch_required() bytes of scratch: HELIO_E_SCRATCH otherwise.
  * helio_render_fwd / helio_env_step_fwd also take 10, 11, 12 (the single-launch block kernel with 1, 2, 4
  * waves per 32x32 block; needs N <= 64, 128, 256) and 13 (the few-ray streaming kernel; needs N <= 8,
  * R % 4 == 0 and 16-byte aligned ys / images): forced forms of what 0 chooses by size, for parity
@@ -158,7 +171,7 @@ int helio_render_fwd_launches(int B, int N, int R);
 
 /*
  * The variant that helio_render_fwd's variant 0 resolves to at (B, N, R): 10..13 (a form of the
- * single-launch kernel) or 3, 5, 6, 9 (geometry + that splat kernel); 0 for invalid sizes.  Every
+ * single-launch kernel) or 3, 5, 6, 9, 14..16 (geometry + that splat kernel); 0 for invalid sizes.  Every
  * kernel sums an image's heliostats in an order that depends on N and R only, so a caller that
  * renders a batch in pieces (one shard of the sun batch per GPU) passes the choice
  * of the WHOLE batch with every piece and gets the rows of the unsharded render bit for bit.

@@ -131,6 +131,18 @@ int main() {
     EXPECT_INVALID(helio_render_fwd(512, 2000, 512, P, P, P, P, 8000, &plane, P, P, P, P, P, P, 0, P1, 1 << 20, nullptr));
     EXPECT_INVALID(helio_render_fwd(512, 2000, 512, P, P, P, P, 8000, &plane, P, P, P, P, P, P, 0, SCR, -5, nullptr));
     EXPECT_LAUNCH(helio_render_fwd(512, 2000, 512, P, P, P, P, 8000, &plane, P, P, P, P, P, P, 0, SCR, 1l << 30, nullptr));
+    // the split variants keep partial images in the scratch: without it, HELIO_E_SCRATCH and no launch
+    {
+        const int before = g_launches;
+        const int rc = helio_render_fwd(32, 2000, 512, P, P, P, P, 8000, &plane, P, P, P, P, P, P, 16, nullptr, 0, nullptr);
+        const int rc2 = helio_render_fwd(32, 2000, 512, P, P, P, P, 8000, &plane, P, P, P, P, P, P, 16, SCR, 100, nullptr);
+        if (rc != HELIO_E_SCRATCH || rc2 != HELIO_E_SCRATCH || g_launches != before || !helio_last_error_string()[0]) {
+            printf("FAIL split variant without scratch: rc=%d rc2=%d launches %d->%d\n", rc, rc2, before, g_launches);
+            ++failures;
+        }
+        if (helio_fwd_scratch_required(32, 2000, 512, 16) <= 0 || helio_fwd_scratch_required(32, 2000, 512, 5) != 0) { printf("FAIL scratch required\n"); ++failures; }
+    }
+    EXPECT_LAUNCH(helio_render_fwd(32, 2000, 512, P, P, P, P, 8000, &plane, P, P, P, P, P, P, 16, SCR, 1l << 30, nullptr));
     if (helio_render_fwd_launches(B, N, R) != 1 || helio_render_fwd_launches(512, 2000, 512) != 2) { printf("FAIL launches\n"); ++failures; }
     if (helio_render_fwd_choice(B, N, R) != 12 || helio_render_fwd_choice(512, 2000, 512) != 6 || helio_render_fwd_choice(0, N, R) != 0 ||
         helio_render_fwd_choice(B, N, 0) != 0) { printf("FAIL choice\n"); ++failures; }

@@ -288,3 +288,49 @@ def test_scratch_that_is_missing_or_too_small_runs_the_dense_kernels():
     rc = ops.lib.helio_splat_fwd(B, N, R, rays.data_ptr(), f._xs.data_ptr(), f._ys.data_ptr(), dense.data_ptr(), 5,
                                  ctypes.c_void_p(misaligned.data_ptr() + 16), need, native._stream())
     assert rc == -1 and b"256-byte" in ops.lib.helio_last_error_string()
+
+
+@pytest.mark.parametrize("N,B,R", [(700, 3, 512), (1000, 5, 260), (5000, 2, 256), (257, 2, 300)])
+@pytest.mark.parametrize("sigma,err", [(0.01, 90.0), (0.02, 40.0)])
+def test_split_heliostat_sum_variants(N, B, R, sigma, err):
+    """Variants 14..17: the 256² LDS-table kernel with the heliostat sum split into 2..16 parts across workgroups,
+    partial images in the scratch, added in part order.  (a) culled == dense-with-scratch bit for bit; (b) within
+    the summation-order noise of the unsplit kernel's one-level chain (≤ 8e-6·peak at N = 5000) and inside the oracle's tolerance; (c) the bits
+    do not depend on the number of images (a shard forced to the variant reproduces the batch's rows); (d) without
+    scratch: HELIO_E_SCRATCH, nothing launched."""
+    from doodle_amd import native
+    from test_gpu_more import make_case
+    ops = native.get_ops()
+    # what the size rule hands them: tens of images of a large field
+    assert [ops.render_choice(b, 5000, 256) for b in (16, 32, 64, 128, 256)] == [9, 16, 15, 14, 5]
+    assert ops.render_choice(16, 2000, 512) == 15 and ops.render_choice(32, 2000, 256) == 9
+    f, sc, suns, errs, act = make_case(N, B, R, sigma=sigma, err=err, seed=N + R + 3, span=30.0)
+    s_dev = suns.to(DEV)
+    normals = act.to(DEV).reshape(B, N, 3).contiguous()
+    trig, stride = f._select_trig(B)
+    args = (f.heliostat_positions, s_dev, normals, trig, stride, f._plane, f._xs, f._ys)
+    with torch.no_grad():
+        unsplit = ops.render_fwd(*args, variant=5)[0]
+        img_o, _ = to.render_chunked(sc, suns[:1], act[:1], (errs if B > 1 else errs[:1])[:1], b_chunk=1, n_chunk=50)
+        peak = unsplit.max().item()
+        for variant in (14, 15, 16, 17):
+            assert ops.lib.helio_fwd_scratch_required(B, N, R, variant) == ((4 * B * (2 << (variant - 14)) * R * R + 255) // 256) * 256
+            culled = ops.render_fwd(*args, variant=variant)[0]
+            ops.cull = False
+            try:
+                dense = ops.render_fwd(*args, variant=variant)[0]                  # scratch for the partial images only
+            finally:
+                ops.cull = True
+            assert same_bits(culled, dense), variant
+            assert (culled - unsplit).abs().max().item() <= 8e-6 * peak, variant     # two summation orders of N terms
+            np.testing.assert_allclose(culled[:1].cpu().numpy(), img_o.numpy(), rtol=1e-5, atol=1e-8)
+            if B > 1:
+                part = ops.render_fwd(f.heliostat_positions, s_dev[1:], normals[1:], trig[1:], stride, f._plane, f._xs, f._ys,
+                                      variant=variant)[0]
+                assert same_bits(part, culled[1:])
+    rays = ops.geometry_fwd(f.heliostat_positions, s_dev, normals, trig, stride, f._plane)[2]
+    image = torch.full((B, R, R), 7.0, device=DEV)
+    rc = ops.lib.helio_splat_fwd(B, N, R, rays.data_ptr(), f._xs.data_ptr(), f._ys.data_ptr(), image.data_ptr(), 15, None, 0,
+                                 native._stream())
+    torch.cuda.synchronize()
+    assert rc == -6 and b"scratch" in ops.lib.helio_last_error_string() and float(image.min()) == 7.0

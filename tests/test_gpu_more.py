@@ -1519,7 +1519,8 @@ def test_ksplit_block_kernel_is_what_few_images_of_many_heliostats_get(N, B, R):
 
 
 @pytest.mark.parametrize("N,B,R,rows", [(300, 40, 128, (7, 12)), (300, 256, 128, (100, 116)), (50, 300, 128, (5, 15)),
-                                          (1000, 6, 64, (2, 3)), (600, 64, 256, (30, 34)), (4, 40, 64, (0, 9))])
+                                          (1000, 6, 64, (2, 3)), (600, 64, 256, (30, 34)), (4, 40, 64, (0, 9)),
+                                          (2000, 64, 256, (30, 37)), (1000, 100, 260, (0, 3))])   # split heliostat sums (variants 15, 14)
 def test_shards_reproduce_the_whole_batch_across_kernel_regimes(N, B, R, rows):
     """a shard must equal the unsharded render bit for bit.  The size rules look at B, so a shard
     on its own could get another kernel (another summation order) than the whole batch: render_rows forces the
