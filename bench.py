@@ -409,7 +409,7 @@ def main():
     from doodle_amd import affinity
     cpu_mask0 = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None
     torch.empty(1, device=dev)                     # the runtime's helper threads exist from here on
-    numa = affinity.bind_to_gpu_ccd(local, slot=local)
+    numa = affinity.bind_to_gpu_ccd(local)         # slot = the card's index among the cards of its NUMA node
     dist = None
     if world > 1 or args.force_dist:
         import torch.distributed as dist
@@ -504,6 +504,9 @@ def main():
     # rank): at config 2 the gathered loop is bound by delivering (N-1) x 1.64 MB to every rank per
     # step, DESIGN.md §5 — always reported beside `value`, never instead of it
     el_other = None
+    if gather is not None and numa is not None:
+        # the gathered legs are not launch-bound and run RCCL's proxy threads: the whole NUMA node for them
+        affinity.widen_to_node(local)
     if gather is not None:
         gather_now[0] = not gather_now[0]
         for _ in range(min(args.warmup, 50)):

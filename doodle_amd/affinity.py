@@ -88,7 +88,26 @@ def _set_all_threads(cpus: set) -> None:
             pass                                   # a thread that ended meanwhile
 
 
-def bind_to_gpu_ccd(device_index: int = 0, slot: int = 0) -> Optional[dict]:
+def gpu_slot_on_node(device_index: int) -> tuple:
+    """→ (index of the device among the visible devices of its NUMA node, how many there are)."""
+    import torch
+    node = gpu_numa_node(device_index)
+    same = [d for d in range(torch.cuda.device_count()) if gpu_numa_node(d) == node]
+    return (same.index(device_index) if device_index in same else 0), max(len(same), 1)
+
+
+def widen_to_node(device_index: int = 0) -> None:
+    """Every thread of the process back on ALL CPUs of the device's NUMA node (within the process's mask when it
+    was bound): for phases that are not launch-bound and run helper threads of their own (RCCL's proxies)."""
+    if os.environ.get("HELIO_NUMA_BIND", "1") == "0" or not hasattr(os, "sched_setaffinity"):
+        return
+    node = gpu_numa_node(device_index)
+    cpus = node_cpus(node) if node is not None else set()
+    if cpus:
+        _set_all_threads(cpus)
+
+
+def bind_to_gpu_ccd(device_index: int = 0, slot: Optional[int] = None) -> Optional[dict]:
     """Restrict EVERY thread of this process to ONE last-level-cache group (CCD) of the device's NUMA node.
 
     Measured (tools/core_sweep.py, config-2 loop, K = 20 renders + fence, main thread pinned core by core):
@@ -97,8 +116,10 @@ def bind_to_gpu_ccd(device_index: int = 0, slot: int = 0) -> Optional[dict]:
     launch hands cache lines — queue pointers, completion signals — between them and the launching thread;
     inside one L3 that is cheap).  So the binding has to cover the runtime's threads too, not just the caller:
     call this AFTER the device is initialised (the threads exist) and once; threads created later inherit it.
-    ``slot`` spreads several processes of one node over its CCDs (pass the local rank).
-    → {"numa_node", "cpus", "l3_group"} or None when nothing was changed."""
+    ``slot`` spreads several processes of one node over its CCDs; by default the device's index among the
+    devices of ITS NUMA node (local ranks 0 and 4 of an 8-GPU, 2-node host both take the first CCD of their own
+    node).  With more GPUs than CCDs on a node two ranks share one: reported as ``shared_ccd``, with a warning.
+    → {"numa_node", "cpus", "l3_group", "shared_ccd"} or None when nothing was changed."""
     if os.environ.get("HELIO_NUMA_BIND", "1") == "0" or not hasattr(os, "sched_setaffinity"):
         return None
     node = gpu_numa_node(device_index)
@@ -109,9 +130,17 @@ def bind_to_gpu_ccd(device_index: int = 0, slot: int = 0) -> Optional[dict]:
     groups = _l3_groups(cpus)
     if not groups:
         return None
+    gpus_here = 1
+    if slot is None:
+        slot, gpus_here = gpu_slot_on_node(device_index)
+    shared = gpus_here > len(groups)
+    if shared:
+        import warnings
+        warnings.warn(f"doodle_amd.affinity: {gpus_here} GPUs on NUMA node {node} but {len(groups)} last-level-cache groups: "
+                      "some ranks share one", stacklevel=2)
     grp = groups[slot % len(groups)]
     _set_all_threads(grp)
-    return {"numa_node": node, "cpus": len(grp), "l3_group": f"{min(grp)}-{max(grp)}"}
+    return {"numa_node": node, "cpus": len(grp), "l3_group": f"{min(grp)}-{max(grp)}", "shared_ccd": shared}
 
 
 def restore(mask: set) -> None:

@@ -87,6 +87,18 @@ def build_hostbind(force: bool = False, verbose: bool = False):
     return hostbind_path()
 
 
+def audit() -> None:
+    """Static audit of the compiled kernels the build depends on the compiler for (tools/audit_fused_late.py: the
+    hand-issued kernel-argument loads of the fused small-problem kernel).  Raises on a violation."""
+    tool = os.path.join(ROOT, "tools", "audit_fused_late.py")
+    out = subprocess.run([sys.executable, tool], capture_output=True, text=True)
+    if out.returncode != 0:
+        raise RuntimeError("kernel audit failed — this hipcc does not produce a safe libhelio.so:\n" + out.stdout + out.stderr)
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
     print(build_hostbind(force="--force" in sys.argv, verbose=True))
+    if "--audit" in sys.argv:
+        audit()
+        print("kernel audit clean")

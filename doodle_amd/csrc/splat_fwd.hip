@@ -667,7 +667,7 @@ struct LateRegs { i32x16 a; i32x8 b; i32x4 c; };       // floats 0..15 of P | P[
 __device__ __forceinline__ void late_issue(LateRegs& r) {
     auto kp = __builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("s_load_dwordx16 %0, %3, 0x38\n\ts_load_dwordx8 %1, %3, 0x78\n\ts_load_dwordx4 %2, %3, 0x98"
-                 : "=s"(r.a), "=s"(r.b), "=s"(r.c) : "s"(kp));
+                 : "=&s"(r.a), "=&s"(r.b), "=&s"(r.c) : "s"(kp));      // early-clobber: no destination on top of the base pair
 }
 __device__ __forceinline__ void late_wait(LateRegs& r) {
     asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(r.a), "+s"(r.b), "+s"(r.c) :: "memory");

@@ -8,8 +8,10 @@ three s_load instructions and the statement that waits for them
     load's destination as written when the statement ends and may copy or reuse it);
   * hipcc issues no scalar-memory or LDS instruction and no lgkmcnt wait of its own (its counted
     waits do not know about the loads in flight);
+  * no destination of the three loads overlaps the base register pair they share;
 
-and that the kernel spills nothing.  Exit status 0 = clean.  Run by tests/test_host_logic.py."""
+and that the kernel spills nothing.  Exit status 0 = clean.  Run by the test suite AND by the product build (__graft_entry__.build,
+`python -m doodle_amd.build --audit`): another hipcc must not silently produce a bad library."""
 import os, re, subprocess, sys, tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -40,9 +42,16 @@ def audit(asm: str):
             problems.append(f"{name}: the late-argument loads were not found")
             continue
         end_issue = next(i for i in range(issue, len(lines)) if "ASMEND" in lines[i])
-        dest = set()
+        dest, base = set(), set()
         for l in lines[issue:end_issue]:
-            dest |= regs(l.split(",")[0])
+            ops = l.split(";")[0].split(",")
+            dest |= regs(ops[0])
+            if len(ops) > 1:
+                base |= regs(ops[1])
+        if dest & base:
+            # the three loads share one base pair: a destination on top of it would be overwritten by the first
+            # load's data before the later loads issue ("=&s" in late_issue keeps the allocator from doing that)
+            problems.append(f"{name}: a late-argument destination overlaps the kernarg base pair s{sorted(base)}")
         wait = next((i for i in range(end_issue, len(lines)) if "s_waitcnt lgkmcnt(0)" in lines[i] and "ASMSTART" in lines[i - 1]), None)
         if wait is None:
             problems.append(f"{name}: the wait statement was not found")
