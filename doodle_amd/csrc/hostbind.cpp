@@ -7,6 +7,7 @@
 // instead of ≈7 µs.  No arithmetic happens here.  Optional: if it is not built, native.py's
 // ctypes path is used.
 #include <torch/extension.h>
+#include <hip/hip_runtime.h>
 #include <c10/hip/HIPFunctions.h>
 #include <c10/hip/HIPGuard.h>
 #include <c10/hip/HIPStream.h>
@@ -139,13 +140,20 @@ py::tuple render_any(int64_t plane, const at::Tensor& helios, const at::Tensor& 
 // Outputs of a launch-bound call come from torch's caching allocator through bare TensorImpls over blocks the
 // binding asks the allocator for directly: an at::empty costs 0.72 µs (dispatcher, device guard, allocator,
 // TensorImpl) next to a 3.3 µs launch and a 3.7 µs kernel, a direct allocator call and a TensorImpl about a
-// third of that.  A block goes back to the allocator when the last tensor over it dies, so tensors share a
-// block ONLY when callers keep or drop them together and no member is much smaller than the block: what a
-// rollout buffer retains step after step — the image, the `aux` row, the 0-dim metrics — always has a block
-// of its own (holding `metrics['mse']` for 10 000 steps must cost 10 000 x 256 bytes, not 10 000 images);
-// `actual | refl` and the per-image / per-ray monitor vectors (+ the call's scratch) share one each.
-// record_stream() on any tensor covers its block, as with at::empty.
+// third of that — and a SECOND allocator call per render was measured at 0.29 µs (6.59 → 6.13 M frames/s at
+// config 2).  A block goes back to the allocator when the last tensor over it dies, so what shares a block
+// decides what a kept tensor pins:
+//   * the image always has a block of its own (it is what a rollout keeps; nothing small may pin it);
+//   * everything small — actual | refl, the five 0-dim metrics, the per-image / per-ray monitor vectors with the
+//     call's workspace, the `aux` row — is a SLOT of a slab: one allocator block serves the next up to 16 calls
+//     (at most kSlabBytes), so the allocator is called once per 16 calls for them, and a tensor somebody keeps
+//     pins at most its slab (≤ 256 KB) — `metrics['mse']` of 10 000 steps costs 10 000 x 256 bytes when all are
+//     kept, never 10 000 images (tests/test_round3_gpu.py).
+// A slab is used on the stream it was allocated under (a call on another stream starts a new one), so the caching
+// allocator's stream bookkeeping — and record_stream() on any tensor of it — stays exact, as with at::empty.
 constexpr int64_t kCarveMaxBytes = 8 << 20;
+constexpr int64_t kSlabBytes = 256 << 10;
+constexpr int64_t kSlabMaxSlots = 16;
 
 struct Carver {
     c10::DispatchKeySet keys, keys_inference;   // of what at::empty returns outside / inside torch.inference_mode()
@@ -182,6 +190,39 @@ struct Carver {
         return t;
     }
 };
+
+// 0 when `stream` is not being captured into a HIP graph, else the capture's id + 1: memory handed out during a
+// capture must come from that graph's private pool (allocated during it) and must not be used after it
+uint64_t capture_key(void* stream) {
+    hipStreamCaptureStatus status = hipStreamCaptureStatusNone;
+    unsigned long long id = 0;
+    if (hipStreamGetCaptureInfo((hipStream_t)stream, &status, &id) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return status == hipStreamCaptureStatusNone ? 0 : (uint64_t)id + 1;
+}
+
+// One slab in use per purpose and thread (never destroyed: no allocator call at thread or process exit).
+struct Slab {
+    c10::Storage st;
+    int64_t slot_floats = 0, slots = 0, used = 0;
+    void* stream = nullptr;
+    uint64_t capture = 0;
+    int device = -1;
+    // storage and offset (in floats) of a fresh slot of `floats` floats for a call on `stream_` (capture key `cap`)
+    std::pair<c10::Storage, int64_t> take(const Carver& cv, int64_t floats, void* stream_, uint64_t cap) {
+        floats = Carver::pad(floats);
+        if (!st || slot_floats != floats || used == slots || stream != stream_ || capture != cap || device != cv.device.index()) {
+            slots = std::max<int64_t>(1, std::min<int64_t>(kSlabMaxSlots, kSlabBytes / (floats * (int64_t)sizeof(float))));
+            st = cv.block(floats * slots);
+            slot_floats = floats; used = 0; stream = stream_; capture = cap; device = cv.device.index();
+        }
+        return {st, (used++) * floats};
+    }
+};
+enum SlabPurpose { kSlabRays = 0, kSlabScalars, kSlabVectors, kSlabAux, kSlabPurposes };
+Slab& slab_for(SlabPurpose p) {
+    thread_local Slab* slabs = new Slab[kSlabPurposes];
+    return slabs[p];
+}
 
 // bumped whenever something a bound context was built from is reassigned on the Python side (the forced
 // kernel variant, the binding itself); a context of an older generation declines its fast entry
@@ -220,6 +261,12 @@ struct RenderCtx {
     int64_t generation;
     at::Tensor errs;               // the error tensor the trig table was made from (bind_errors), for render_checked
     int64_t errs_version = -1;
+    int64_t scratch_B = -1, scratch_need = 0;      // helio_fwd_scratch_bytes of the last batch size asked for
+    Scratch scratch_for(int64_t B, int64_t N, int64_t R) {
+        if (B != scratch_B) { scratch_B = B; scratch_need = helio_fwd_scratch_bytes((int)B, (int)N, (int)R, (int)variant); }
+        if (scratch_need <= 0) return Scratch(0, helios);
+        return fwd_scratch(B, N, R, variant, helios);
+    }
     RenderCtx(int64_t plane_, at::Tensor helios_, at::Tensor xs_, at::Tensor ys_, at::Tensor trig_, int64_t stride_,
               int64_t variant_)
         : plane(plane_), helios(std::move(helios_)), xs(std::move(xs_)), ys(std::move(ys_)), trig(std::move(trig_)),
@@ -235,13 +282,13 @@ struct RenderCtx {
         const int64_t ni = B * R * R, na = B * N * 3;
         const int64_t rays_total = Carver::pad(na) + (want_refl ? na : 0);
         if ((ni + rays_total) * (int64_t)sizeof(float) <= kCarveMaxBytes) {
-            // the image alone (what a caller keeps as an observation); actual | refl together (same size, both
-            // per-ray monitor outputs)
+            // the image alone (what a caller keeps as an observation); actual | refl a slot of a slab
             const c10::Storage si = carve.block(ni);
             o.image = batched ? carve.tensor(si, 0, {B, R, R}) : carve.tensor(si, 0, {R, R});
-            const c10::Storage sr = carve.block(rays_total);
-            o.actual = carve.tensor(sr, 0, {B, N, 3});
-            if (want_refl) o.refl = carve.tensor(sr, Carver::pad(na), {B * N, 3});
+            void* const stream = cur_stream(helios);
+            const auto slot = slab_for(kSlabRays).take(carve, rays_total, stream, capture_key(stream));
+            o.actual = carve.tensor(slot.first, slot.second, {B, N, 3});
+            if (want_refl) o.refl = carve.tensor(slot.first, slot.second + Carver::pad(na), {B * N, 3});
         } else {
             const auto opt = helios.options();
             o.actual = at::empty({B, N, 3}, opt);
@@ -276,7 +323,7 @@ struct RenderCtx {
             return py::none();
         Outputs o = outputs(B, N, R, want_refl, batched);
         if (!rays_ws.defined() || rays_ws.size(0) != B) rays_ws = at::empty({B, N, HELIO_RAY_STRIDE}, helios.options());
-        const Scratch sc = fwd_scratch(B, N, R, variant, helios);
+        const Scratch sc = scratch_for(B, N, R);
         check(helio_render_fwd((int)B, (int)N, (int)R, helios.data_ptr<float>(), sun.data_ptr<float>(),
                                action.data_ptr<float>(), trig.data_ptr<float>(), (long)trig_b_stride,
                                reinterpret_cast<const helio_plane*>(plane), xs.data_ptr<float>(), ys.data_ptr<float>(),
@@ -298,7 +345,7 @@ struct RenderCtx {
         if (trig_b_stride != 0 && trig.numel() < B * N * 4) return py::none();
         Outputs o = outputs(B, N, R, want_refl, true);
         if (!rays_ws.defined() || rays_ws.size(0) != B) rays_ws = at::empty({B, N, HELIO_RAY_STRIDE}, helios.options());
-        const Scratch sc = fwd_scratch(B, N, R, variant, helios);
+        const Scratch sc = scratch_for(B, N, R);
         check(helio_render_fwd((int)B, (int)N, (int)R, helios.data_ptr<float>(), sun.data_ptr<float>(),
                                action.data_ptr<float>(), trig.data_ptr<float>(), (long)trig_b_stride,
                                reinterpret_cast<const helio_plane*>(plane), xs.data_ptr<float>(), ys.data_ptr<float>(),
@@ -512,19 +559,29 @@ StepOut step_core(int64_t plane, const at::Tensor& helios, const at::Tensor& sun
                   f_small = f_allb + P(B * N);
     const bool carve_all = (f_small + P(ni) + 2 * P(na) + P(naux)) * (int64_t)sizeof(float) <= kCarveMaxBytes;
     const Carver& cv = carver_for(helios);
-    o.out = cv.tensor(cv.block(64), 0, {5});
-    const c10::Storage st = cv.block(f_small);
-    at::Tensor ws = cv.tensor(st, 0, {nws});
-    o.mae = cv.tensor(st, f_mae, {B});
-    o.keep = cv.tensor(st, f_keep, {B});
-    o.align = cv.tensor(st, f_align, {B, N});
-    o.allb = cv.tensor(st, f_allb, {B, N});
+    void* const stream = cur_stream(normals);
+    const uint64_t cap = capture_key(stream);
+    {
+        const auto sl = slab_for(kSlabScalars).take(cv, 64, stream, cap);
+        o.out = cv.tensor(sl.first, sl.second, {5});
+    }
+    const auto sv = slab_for(kSlabVectors).take(cv, f_small, stream, cap);
+    const c10::Storage& st = sv.first;
+    const int64_t v0 = sv.second;
+    at::Tensor ws = cv.tensor(st, v0, {nws});
+    o.mae = cv.tensor(st, v0 + f_mae, {B});
+    o.keep = cv.tensor(st, v0 + f_keep, {B});
+    o.align = cv.tensor(st, v0 + f_align, {B, N});
+    o.allb = cv.tensor(st, v0 + f_allb, {B, N});
     if (carve_all) {
         o.image = cv.tensor(cv.block(ni), 0, {B, R, R});
-        const c10::Storage sr = cv.block(2 * P(na));
-        o.actual = cv.tensor(sr, 0, {B, N, 3});
-        o.refl = cv.tensor(sr, P(na), {B, N, 3});
-        if (want_aux) o.aux = cv.tensor(cv.block(naux), 0, {B, 3 + 3 * N});
+        const auto sr = slab_for(kSlabRays).take(cv, 2 * P(na), stream, cap);
+        o.actual = cv.tensor(sr.first, sr.second, {B, N, 3});
+        o.refl = cv.tensor(sr.first, sr.second + P(na), {B, N, 3});
+        if (want_aux) {
+            const auto sa = slab_for(kSlabAux).take(cv, naux, stream, cap);
+            o.aux = cv.tensor(sa.first, sa.second, {B, 3 + 3 * N});
+        }
     } else {
         o.actual = at::empty_like(normals);
         o.refl = at::empty_like(normals);
@@ -542,7 +599,7 @@ StepOut step_core(int64_t plane, const at::Tensor& helios, const at::Tensor& sun
                              o.out.data_ptr<float>(), o.mae.data_ptr<float>(), o.keep.data_ptr<float>(),
                              o.align.data_ptr<float>(), o.allb.data_ptr<float>(),
                              want_aux ? o.aux.data_ptr<float>() : nullptr, reinterpret_cast<int*>(notify), (int)ticket,
-                             sc.p, sc.bytes, cur_stream(normals)));
+                             sc.p, sc.bytes, stream));
     return o;
 }
 
