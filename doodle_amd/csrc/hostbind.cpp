@@ -644,6 +644,9 @@ py::tuple env_step_fwd(int64_t plane, const at::Tensor& helios, const at::Tensor
 // (fields' geometry, trig table, reference image / peaks / distance maps / ideal normals, loss
 // constants, completion record): per step the binding converts two tensors and a ticket.  The host
 // side of a step is what bounds it at small sizes (two launches, ≈14 µs of GPU).
+struct EnvStepCtx;
+py::object env_step_ctx_grad(EnvStepCtx& c, const at::Tensor& sun, const at::Tensor& action_in, int64_t bwd_variant,
+                             int64_t ticket);
 struct EnvStepCtx {
     int64_t plane, trig_b_stride, variant, notify;
     at::Tensor helios, xs, ys, trig, target, tx, dmaps, ideal, rays_ws;
@@ -778,11 +781,18 @@ class EnvStepFn : public torch::autograd::Function<EnvStepFn> {
                                  at::Tensor trig, int64_t trig_b_stride, at::Tensor xs, at::Tensor ys, int64_t variant,
                                  int64_t bwd_variant, at::Tensor target, at::Tensor tx, at::Tensor dmaps, at::Tensor ideal,
                                  std::vector<double> tp, std::vector<double> tn, double W, double H, bool exp_risk,
-                                 double mask_ratio, int64_t notify, int64_t ticket) {
-        const StepOut r = step_core(plane, helios, sun, normals, trig, trig_b_stride, xs, ys, c10::nullopt, variant, target, tx,
-                                    dmaps, ideal, tp, tn, W, H, exp_risk, mask_ratio, false, notify, ticket);
-        const at::Tensor &image = r.image, &actual = r.actual, &refl = r.refl, &rays = r.rays, &out = r.out, &mae = r.mae,
-                         &align = r.align, &allb = r.allb, &keep = r.keep;
+                                 double mask_ratio, int64_t notify, int64_t ticket, bool want_aux) {
+        // `normals`: the action in ANY contiguous shape of B·N·3 floats ([B,3N] as step() receives it: no view node
+        // between the action and this one in the graph); with want_aux (step()'s own call) the outputs leave in the
+        // shapes step() hands out — refl [B·N,3], mae [B,1], angles [B·N] — so that no view op follows either
+        const int64_t B = sun.size(0), N = helios.size(0);
+        const at::Tensor n3 = normals.dim() == 3 ? normals : bare_view(normals, 0, {B, N, 3});
+        const StepOut r = step_core(plane, helios, sun, n3, trig, trig_b_stride, xs, ys, c10::nullopt, variant, target, tx,
+                                    dmaps, ideal, tp, tn, W, H, exp_risk, mask_ratio, want_aux, notify, ticket);
+        const at::Tensor &image = r.image, &actual = r.actual, &rays = r.rays, &out = r.out, &allb = r.allb, &keep = r.keep;
+        const at::Tensor refl = want_aux ? bare_view(r.refl, 0, {B * N, 3}) : r.refl;
+        const at::Tensor mae = want_aux ? bare_view(r.mae, 0, {B, 1}) : r.mae;
+        const at::Tensor align = want_aux ? bare_view(r.align, 0, {B * N}) : r.align;
         ctx->save_for_backward({normals, sun, trig, rays, image, actual, keep, helios, xs, ys, target, tx, dmaps, ideal});
         ctx->saved_data["plane"] = plane;
         ctx->saved_data["stride"] = trig_b_stride;
@@ -793,28 +803,49 @@ class EnvStepFn : public torch::autograd::Function<EnvStepFn> {
         ctx->saved_data["H"] = H;
         ctx->saved_data["exp_risk"] = exp_risk;
         ctx->set_materialize_grads(false);
-        const std::vector<at::Tensor> o = out.unbind(0);
+        const at::Tensor o[5] = {bare_view(out, 0, {}), bare_view(out, 1, {}), bare_view(out, 2, {}), bare_view(out, 3, {}),
+                                 bare_view(out, 4, {})};
         ctx->mark_non_differentiable({mae, align, allb, o[4]});
+        // with want_aux the observation row cat(sun, action) of test_environment.py:424 is a 12th output, written by
+        // the loss launch; it is differentiable in the reference (d aux / d action = identity on its last 3N columns)
+        if (want_aux) return {image, actual, refl, o[0], o[1], o[2], o[3], mae, align, allb, o[4], r.aux};
         return {image, actual, refl, o[0], o[1], o[2], o[3], mae, align, allb, o[4]};
     }
 
     static variable_list backward(AutogradContext* ctx, variable_list g) {
         const auto sv = ctx->get_saved_variables();
-        const at::Tensor &normals = sv[0], &sun = sv[1], &trig = sv[2], &rays = sv[3], &image = sv[4], &actual = sv[5],
+        const at::Tensor &action = sv[0], &sun = sv[1], &trig = sv[2], &rays = sv[3], &image = sv[4], &actual = sv[5],
                          &keep = sv[6], &helios = sv[7], &xs = sv[8], &ys = sv[9], &target = sv[10], &tx = sv[11],
                          &dmaps = sv[12], &ideal = sv[13];
+        const int64_t Bn = sun.size(0), Nn = helios.size(0);
+        const at::Tensor normals = action.dim() == 3 ? action : bare_view(action, 0, {Bn, Nn, 3});
+        // the cotangents of refl [B·N,3] / actual in whatever shape the forward handed them out
+        auto as3 = [&](const at::Tensor& t) { return t.defined() ? c10::optional<at::Tensor>(t.contiguous().view({Bn, Nn, 3})) : c10::nullopt; };
+        auto shaped = [&](at::Tensor grad) { return grad.sizes() == action.sizes() ? grad : grad.view(action.sizes()); };
         const int64_t plane = ctx->saved_data["plane"].toInt(), stride = ctx->saved_data["stride"].toInt();
         const int64_t bwd_variant = ctx->saved_data["bwd_variant"].toInt();
         const std::vector<double> tp = ctx->saved_data["tp"].toDoubleVector(), tn = ctx->saved_data["tn"].toDoubleVector();
         const double W = ctx->saved_data["W"].toDouble(), H = ctx->saved_data["H"].toDouble();
         const bool exp_risk = ctx->saved_data["exp_risk"].toBool();
-        variable_list res(22);
+        variable_list res(23);
         auto g_mse = opt_contig(g[3]), g_dist = opt_contig(g[4]), g_bound = opt_contig(g[5]), g_align = opt_contig(g[6]);
+        // a cotangent of the `aux` output: its action columns pass straight through
+        auto add_aux = [&](at::Tensor grad) {
+            if (g.size() > 11 && g[11].defined())
+                grad = grad + g[11].narrow(1, 3, g[11].size(1) - 3).reshape(grad.sizes());
+            return grad;
+        };
+        const bool any = g_mse.has_value() || g_dist.has_value() || g_bound.has_value() || g_align.has_value() ||
+                         g[0].defined() || g[1].defined() || g[2].defined();
+        if (!any) {              // only `aux` (or nothing) carries a gradient
+            if (g.size() > 11 && g[11].defined()) res[0] = shaped(add_aux(at::zeros_like(normals)));
+            return res;
+        }
         if (!g[0].defined()) {
             // the whole backward in one C call (helio_env_step_bwd)
-            res[0] = env_step_bwd(plane, helios, sun, normals, trig, stride, rays, xs, ys, image, target, tx, dmaps, ideal,
-                                  tp, tn, W, H, exp_risk, g_mse, g_dist, g_bound, g_align, keep, opt_contig(g[1]),
-                                  opt_contig(g[2]), bwd_variant);
+            res[0] = shaped(add_aux(env_step_bwd(plane, helios, sun, normals, trig, stride, rays, xs, ys, image, target, tx, dmaps,
+                                                 ideal, tp, tn, W, H, exp_risk, g_mse, g_dist, g_bound, g_align, keep, as3(g[1]),
+                                                 as3(g[2]), bwd_variant)));
             return res;
         }
         // an external cotangent of the image as well: loss gradients first, then the render backward
@@ -829,8 +860,8 @@ class EnvStepFn : public torch::autograd::Function<EnvStepFn> {
             gn = l.action;
         }
         at::Tensor gr = render_bwd(plane, helios, sun, normals, trig, stride, rays, xs, ys, opt_contig(g_image),
-                                   opt_contig(g_actual), opt_contig(g[2]), bwd_variant);
-        res[0] = gn.defined() ? gr + gn : gr;
+                                   as3(g_actual), as3(g[2]), bwd_variant);
+        res[0] = shaped(add_aux(gn.defined() ? gr + gn : gr));
         return res;
     }
 };
@@ -843,10 +874,30 @@ py::tuple env_step_autograd(int64_t plane, const at::Tensor& helios, const at::T
                             const std::vector<double>& tn, double W, double H, bool exp_risk, double mask_ratio,
                             int64_t notify, int64_t ticket) {
     variable_list o = EnvStepFn::apply(normals, plane, helios, sun, trig, trig_b_stride, xs, ys, variant, bwd_variant, target,
-                                       tx, dmaps, ideal, tp, tn, W, H, exp_risk, mask_ratio, notify, ticket);
+                                       tx, dmaps, ideal, tp, tn, W, H, exp_risk, mask_ratio, notify, ticket, false);
     py::tuple t(o.size());
     for (size_t k = 0; k < o.size(); ++k) t[k] = o[k];
     return t;
+}
+
+// HelioEnv.step WITH autograd in one binding call: the step context's constants, ONE autograd node (EnvStepFn, with
+// the `aux` observation row as its 12th output), and the shapes step() hands out — what env.py otherwise does in
+// Python around the node (argument shaping, torch.cat for aux, three views): ≈15 µs of the ≈65 µs of
+// `env.step(a); metrics['dist'].backward()` at config 3.  → the tuple of EnvStepCtx::step, or None when the action
+// needs a dtype / device / layout fix-up.
+py::object env_step_ctx_grad(EnvStepCtx& c, const at::Tensor& sun, const at::Tensor& action_in, int64_t bwd_variant,
+                             int64_t ticket) {
+    const int64_t B = sun.size(0), N = c.helios.size(0);
+    if (!(action_in.scalar_type() == at::kFloat && action_in.device() == c.helios.device() && action_in.is_contiguous() &&
+          action_in.numel() == B * N * 3 && sun.scalar_type() == at::kFloat && sun.is_contiguous() &&
+          sun.device() == c.helios.device()))
+        return py::none();
+    variable_list o = EnvStepFn::apply(action_in, c.plane, c.helios, sun, c.trig, c.trig_b_stride, c.xs, c.ys, c.variant, bwd_variant,
+                                       c.target, c.tx, c.dmaps, c.ideal, c.tp, c.tn, c.W, c.H, c.exp_risk, c.mask_ratio,
+                                       ticket != 0 ? c.notify : 0, ticket, true);
+    // monitor['normals'] = action.view(batch_size, -1, 3) (:460): the one view op left, off the path of any loss
+    at::Tensor normals = action_in.dim() == 3 ? action_in : action_in.view({B, N, 3});
+    return py::make_tuple(o[0], o[1], o[2], o[3], o[4], o[5], o[6], o[10], o[7], o[8], o[9], o[11], normals);
 }
 
 at::Tensor ideal_normals(const at::Tensor& helios, const at::Tensor& sun, const std::vector<double>& target) {
@@ -874,7 +925,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         .def(py::init<int64_t, at::Tensor, at::Tensor, at::Tensor, at::Tensor, int64_t, int64_t, at::Tensor, at::Tensor,
                       at::Tensor, at::Tensor, std::vector<double>, std::vector<double>, double, double, bool, double,
                       int64_t>())
-        .def("step", &EnvStepCtx::step);
+        .def("step", &EnvStepCtx::step)
+        .def("step_grad", &env_step_ctx_grad);
     py::class_<RenderCtx>(m, "RenderCtx")
         .def(py::init<int64_t, at::Tensor, at::Tensor, at::Tensor, at::Tensor, int64_t, int64_t>())
         .def("render", &RenderCtx::render)

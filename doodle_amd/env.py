@@ -245,7 +245,7 @@ class HelioEnv(_EnvBase):
             self._consts_cache = (target, self.distance_maps, self.exponential_risk, mask_ratio, consts)
         fast, ticket = None, 0
         differentiate = torch.is_grad_enabled() and action.requires_grad
-        if not differentiate and type(action) is torch.Tensor:
+        if type(action) is torch.Tensor:
             ops = _field._get_ops()
             make_ctx = getattr(ops, "env_step_context", None)
             if make_ctx is not None:     # everything in one call of the compiled binding
@@ -261,8 +261,14 @@ class HelioEnv(_EnvBase):
                 ctx = self._step_ctx
                 if ctx is not None:
                     ticket = ops.next_ticket() if self.check_finite else 0
-                    fast = ctx.step(self.sun_pos, action, ticket)
-                if fast is None:         # (the action needs a dtype / device / layout fix-up)
+                    if differentiate:    # one autograd node (render + loss block + the aux row), shapes made in C++
+                        step_grad = getattr(ctx, "step_grad", None)
+                        fast = step_grad(self.sun_pos, action, ops.bwd_variant, ticket) if step_grad is not None else None
+                    else:
+                        fast = ctx.step(self.sun_pos, action, ticket)
+                if fast is None and differentiate:
+                    ticket = 0           # (the Python path below issues its own)
+                elif fast is None:       # (the action needs a dtype / device / layout fix-up)
                     ticket = 0
                     step_fn = getattr(ops, "env_step_nograd", None)
                     if step_fn is not None:

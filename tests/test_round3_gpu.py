@@ -186,3 +186,54 @@ def test_cpu_trig_round_trip_is_refused_under_graph_capture_with_a_clear_message
     graph.replay()
     torch.cuda.synchronize()
     assert torch.isfinite(img).all() and float(img.max()) > 0
+
+
+def test_differentiating_step_through_the_compiled_context_matches_the_python_path():
+    """HelioEnv.step with a gradient-carrying action goes through ONE call of the compiled binding (EnvStepCtx.step_grad:
+    one autograd node whose 12th output is the `aux` row, shapes made in C++).  Same tensors, bit for bit, as the
+    Python path around the node (ctypes binding: HELIO_HOSTBIND=0 semantics, here: the context switched off), and the
+    same gradients through every output — `aux` included (test_environment.py:424: d aux / d action = identity)."""
+    from doodle_amd import native, synthetic
+    from doodle_amd.env import HelioEnv
+    ops = native.get_ops()
+    if ops.hb is None:
+        pytest.skip("compiled binding not built")
+    w = synthetic.Workload("t", N=50, B=25, R=128)
+    helios, suns, _, noise = synthetic.make_inputs(w, 4)
+    env = HelioEnv(helios.to(DEV), torch.tensor(synthetic.TARGET_POSITION, device=DEV), synthetic.TARGET_AREA,
+                   torch.tensor(synthetic.TARGET_NORMAL, device=DEV), sigma_scale=0.01, error_scale_mrad=90.0,
+                   resolution=w.R, batch_size=w.B, device=DEV, new_errors_every_reset=False)
+    env.set_sun_pos(suns.to(DEV))
+    env.reset()
+    base = torch.nn.functional.normalize(env.ideal_normals + noise.to(DEV), dim=2).reshape(w.B, -1)
+    W = torch.randn(w.B, 3 + 3 * w.N, device=DEV, generator=torch.Generator(device=DEV).manual_seed(1))
+
+    def run(compiled):
+        saved = ops.env_step_context
+        if not compiled:
+            object.__setattr__(ops, "env_step_context", lambda *a, **k: None)      # → the Python path around the node
+            env._step_ctx = env._step_ctx_key = None
+        try:
+            a = base.clone().requires_grad_(True)
+            obs, metrics, monitor = env.step(a)
+            loss = metrics["dist"] + 0.5 * metrics["mse"] + 0.1 * metrics["alignment_loss"] + metrics["bound"] \
+                + (obs["aux"] * W).sum() + monitor["reflected_rays"].sum()
+            (g,) = torch.autograd.grad(loss, a)
+            (g_aux,) = torch.autograd.grad(env.step(a)[0]["aux"].sum(), a)
+            return obs, metrics, monitor, g, g_aux
+        finally:
+            if not compiled:
+                object.__delattr__(ops, "env_step_context")
+                env._step_ctx = env._step_ctx_key = None
+            assert ops.env_step_context == saved
+
+    fast, slow = run(True), run(False)
+    for k in ("img", "aux"):
+        assert fast[0][k].requires_grad and torch.equal(fast[0][k], slow[0][k]), k
+    for k in fast[1]:
+        assert torch.equal(fast[1][k], slow[1][k]), k
+    for k in fast[2]:
+        assert fast[2][k].shape == slow[2][k].shape and torch.equal(fast[2][k], slow[2][k]), k
+    assert torch.equal(fast[3], slow[3])
+    want = torch.zeros(w.B, 3 * w.N, device=DEV) + 1.0
+    assert torch.equal(fast[4], want) and torch.equal(slow[4], want)
