@@ -66,7 +66,8 @@ from doodle_amd import native, synthetic  # noqa: E402
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 F32_MFMA_PEAK_TF = 157.3     # dense f32 MFMA = f32 vector peak (spec)
 TRAFFIC_FILES = ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json")     # newest first
-KERNEL_SOURCE = {"splat_fwd_mfma_tile": "splat_fwd.hip", "render_fwd_fused_small": "splat_fwd.hip"}
+KERNEL_SOURCE = {"splat_fwd_mfma_tile": "splat_fwd.hip", "render_fwd_fused_small": "splat_fwd.hip",
+                 "splat_fwd_mfma_tile(culled)": "splat_fwd.hip"}
 
 
 def build_field(w, helios, errs, device, max_batch=None):
@@ -855,6 +856,8 @@ def large_leg(dev, seed, iters=20):
             "frac_on_live_flops": round(live * r["algorithmic_flops"] / tc / 1e12 / F32_MFMA_PEAK_TF, 4),
             "dense_equivalent_TFLOPs": round(r["algorithmic_flops"] / tc / 1e12, 1),
             "image_bit_identical_with_dense": culled[2]}
+        r["culled"]["traffic"], r["culled"]["traffic_source"] = measured_traffic("splat_fwd_mfma_tile(culled)", w.N, w.B, w.R)
+        r["culled"]["algorithmic_bytes"] = 4.0 * w.B * w.R * w.R + 16.0 * live * w.B * w.N * 4 + 8.0 * w.R
     # backward at the same size: forward + backward kernels for given cotangents (no autograd graph), default
     # (culled) and dense, interleaved
     try:

@@ -18,7 +18,7 @@ COMM_LIB = os.path.join(HERE, "libhelio_comm.so")      # RCCL wrapper, separate 
 COMM_SOURCES = ["comm.hip"]                             # kernels library has no RCCL dependency
 SOURCES = ["abi.hip", "geometry.hip", "splat_fwd.hip", "splat_bwd.hip", "step_losses.hip", "edt.hip", "cull.hip"]
 HEADERS = [os.path.join(CSRC, "helio_math.h"), os.path.join(CSRC, "ray_trace.h"), os.path.join(CSRC, "step_loss_math.h"),
-           os.path.join(CSRC, "cull.h"), os.path.join(CSRC, "geometry_bwd_ray.h"),
+           os.path.join(CSRC, "cull.h"), os.path.join(CSRC, "cull_math.h"), os.path.join(CSRC, "geometry_bwd_ray.h"),
            os.path.join(ROOT, "include", "helio.h"), os.path.join(ROOT, "include", "helio_comm.h")]
 # -ffp-contract=off: the geometry stage is bit-faithful to the reference's fp32 CPU
 # arithmetic; FMAs appear only where written (helio_math.h).  Division and sqrt stay

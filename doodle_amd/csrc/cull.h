@@ -12,7 +12,9 @@
 // Each is a composition of correctly rounded — hence monotone — operations of |q| or |t|, so the smallest
 // exponent over a tile's coordinates [lo, hi] (the true min and max of the tile's xs / ys: no ordering of
 // the coordinate arrays is assumed) is the same expression evaluated at the end nearer to -s, or 0 when
-// the interval straddles it.  exponent_floor() is the least of the three; a NaN anywhere keeps the ray.
+// the interval straddles it.  exponent_floor() is the least of the three; a NaN anywhere — in a ray's parameters
+// or in the tile's coordinates, on EITHER axis — keeps the ray (the dense kernels turn 0·NaN into NaN).
+// tests/c/cull_floor.cpp checks all of this on the CPU, bit for bit, by brute force (cull_math.h).
 //   * forward: a ray is dropped from a tile when floor_x + floor_y > CULL_EXP2: every product A_i·E_j is
 //     then below 2^-152 (the margin of 2 covers v_exp_f32's error and its handling of denormal results, if
 //     it flushes them the product is 0 outright), less than half an ulp of ANY f32 accumulator, and
@@ -25,45 +27,16 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#define HELIO_HD __device__ __forceinline__
+#include "cull_math.h"
+#undef HELIO_HD
 namespace helio {
 
-constexpr float CULL_EXP2 = 152.0f;
-
-__device__ __forceinline__ float cull_nanmin(float a, float b) {
-    return (a != a || b != b) ? __builtin_nanf("") : fminf(a, b);
-}
-
-// the point of [lo, hi] nearest to zero, as a magnitude
-__device__ __forceinline__ float cull_nearest(float lo, float hi) { return lo > 0.0f ? lo : (hi < 0.0f ? -hi : 0.0f); }
-
-// smallest exponent (base 2) any of the kernels' factor forms computes for a coordinate in [lo, hi]
-__device__ __forceinline__ float exponent_floor(float lo, float hi, float shift, float k2, float sk, float cc) {
-    const float ssk = shift * sk;
-    const float qm = cull_nearest(__builtin_fmaf(lo, sk, ssk), __builtin_fmaf(hi, sk, ssk));
-    const float eq = __builtin_fmaf(qm, qm, cc * k2);
-    const float tm = cull_nearest(lo + shift, hi + shift);
-    const float ef = __builtin_fmaf(tm, tm, cc) * k2;
-    const float eu = ((tm * tm) + cc) * k2;
-    return cull_nanmin(eq, cull_nanmin(ef, eu));
-}
-
-struct CullBox { float xlo, xhi, ylo, yhi; };
-
-// ray = (a, b, k2, c2)
-__device__ __forceinline__ void cull_floors(const float4 ray, const CullBox& bx, float& fx, float& fy) {
-    const float sk = __builtin_sqrtf(ray.z);
-    fx = exponent_floor(bx.xlo, bx.xhi, ray.x, ray.z, sk, ray.w);
-    fy = exponent_floor(bx.ylo, bx.yhi, ray.y, ray.z, sk, 0.0f);
-}
 __device__ __forceinline__ bool cull_dead_product(const float4 ray, const CullBox& bx) {
-    float fx, fy;
-    cull_floors(ray, bx, fx, fy);
-    return fx + fy > CULL_EXP2;                       // false for NaN: kept
+    return cull_dead_product(ray.x, ray.y, ray.z, ray.w, bx);
 }
 __device__ __forceinline__ bool cull_dead_strict(const float4 ray, const CullBox& bx) {
-    float fx, fy;
-    cull_floors(ray, bx, fx, fy);
-    return fx > CULL_EXP2 || fy > CULL_EXP2;
+    return cull_dead_strict(ray.x, ray.y, ray.z, ray.w, bx);
 }
 
 // ---- work order ---------------------------------------------------------------------------------------

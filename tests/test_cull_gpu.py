@@ -103,8 +103,14 @@ def threshold_rays(N, B, R, seed):
     rays[kind == 0] = torch.tensor([0.3, -1.2, 0.8, 0.01])                  # a spot on the receiver
     rays[kind == 1] = torch.tensor([1.0e4, -2.0e4, 0.0, 3.0])               # plane-parallel: adds exactly 1.0 per pixel
     rays[kind == 2] = torch.tensor([3.0e18, 1.0, 1.0e6, 0.0])               # q² overflows: factor exactly 0
-    rays[0, 5] = torch.tensor([float("nan"), 0.0, 1.0, 0.0])                # (image 0 only: a NaN ray makes its image NaN)
-    rays[0, 7] = torch.tensor([0.0, 0.0, float("nan"), 0.0])
+    nan = float("nan")
+    rays[0, 5] = torch.tensor([nan, 0.0, 1.0, 0.0])                         # (image 0 only: a NaN ray makes its image NaN)
+    rays[0, 7] = torch.tensor([0.0, 0.0, nan, 0.0])
+    # NaN on ONE axis while the other is far off the receiver: the dense kernels' 0·NaN products are NaN, so these
+    # must be kept too (tests/c/cull_floor.cpp found a criterion that dropped them)
+    rays[0, 9] = torch.tensor([nan, 1.0e9, 1.0, 0.0])
+    rays[0, 11] = torch.tensor([1.0e9, nan, 1.0, 0.0])
+    rays[0, 13] = torch.tensor([1.0e9, 1.0e9, 1.0, nan])
     return rays.contiguous()
 
 
@@ -122,13 +128,14 @@ def test_rays_on_the_threshold_of_the_criterion(N, B, R, seed):
         assert torch.equal(bits(culled)[~both_nan], bits(dense)[~both_nan]), variant
         assert torch.equal(torch.isnan(dense), torch.isnan(culled))
         assert 0 < int(counts.sum()) < counts.numel() * N              # some are dropped, some are kept
-    # … and the backward's criterion (a factor table that is all zero) on the same rays; NaN rays aside
-    finite = rays.clone()
-    finite[torch.isnan(finite).any(dim=2)] = torch.tensor([0.1, 0.2, 0.5, 0.0], device=DEV)
+    # … and the backward's criterion (a factor table that is all zero) on the same rays: the same numbers where the
+    # dense kernel has numbers, NaN exactly where it has NaN (the moments of the NaN rays)
     G = torch.randn(B, R, R, device=DEV, generator=torch.Generator(device=DEV).manual_seed(seed)) * 1e6
-    dense_m = ops.splat_bwd(finite, xs, ys, G, variant=2, cull=False)
-    culled_m = ops.splat_bwd(finite, xs, ys, G, variant=2, cull=True)
-    assert same_bits(culled_m, dense_m)
+    dense_m = ops.splat_bwd(rays, xs, ys, G, variant=2, cull=False)
+    culled_m = ops.splat_bwd(rays, xs, ys, G, variant=2, cull=True)
+    assert torch.equal(torch.isnan(dense_m), torch.isnan(culled_m)) and torch.isnan(dense_m).any()
+    ok = ~torch.isnan(dense_m)
+    assert torch.equal(bits(culled_m)[ok], bits(dense_m)[ok])
 
 
 @pytest.mark.parametrize("N,B,R", [(257, 3, 260), (700, 2, 512), (1000, 2, 128), (300, 4, 200)])
