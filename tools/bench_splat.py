@@ -25,8 +25,9 @@ def main():
     ops = native.get_ops()
     trig, stride = f._select_trig(B)
     _, _, rays = ops.geometry_fwd(f.heliostat_positions, suns_d, act.reshape(B, w.N, 3).contiguous(), trig, stride, f._plane)
-    ref = ops.splat_fwd(rays, f._xs, f._ys, variant=2, cull=False)
-    image = torch.empty_like(ref)
+    # (PMC passes average over every launch of a kernel: HELIO_NOREF=1 leaves out this dense reference launch)
+    ref = None if os.environ.get("HELIO_NOREF") == "1" else ops.splat_fwd(rays, f._xs, f._ys, variant=2, cull=False)
+    image = torch.empty((B, w.R, w.R), device=dev)
     st = torch.cuda.current_stream().cuda_stream
     flops = 2.0 * B * w.N * w.R * w.R
     iters = max(3, min(200, int(2e12 / flops)))
@@ -41,7 +42,7 @@ def main():
             rc = ops.lib.helio_splat_fwd(*args)
             assert rc == 0, ops.lib.helio_last_error_string()
             torch.cuda.synchronize()
-            if rnd == 0:
+            if rnd == 0 and ref is not None:
                 err = (image - ref).abs().max().item() / ref.max().item()
                 print(f"variant {v}: max|d|/peak vs variant 2 = {err:.2e}" + (f"  bit-identical: {torch.equal(image, ref)}" if vi == 5 else ""))
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
