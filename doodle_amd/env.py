@@ -21,7 +21,7 @@ import torch.nn.functional as F
 
 from . import field as _field
 from .field import HelioField
-from .losses import StepConstants, env_step_fused, step_losses
+from .losses import StepConstants, env_step_fused
 
 try:  # pragma: no cover - depends on the image
     import gymnasium as _gym
@@ -287,9 +287,17 @@ class HelioEnv(_EnvBase):
                  flag, ticket) = env_step_fused(self.noisy_field, self.sun_pos, normals.contiguous(), consts,
                                                 notify=self.check_finite)
             else:
-                img, actual, reflected = self.noisy_field.render(self.sun_pos, action, ideal, monitor=True)
-                mse, dist_l, bound, alignment_loss, mae, angles, all_bounds, flag = step_losses(img, actual, normals,
-                                                                                             consts)
+                # no compiled binding (or an action that needed a fix-up): the same ONE C call — helio_env_step_fwd,
+                # render + loss block — through the ctypes binding, so that this path and the differentiating one
+                # give the same bits whatever the binding
+                nf = self.noisy_field
+                n3 = torch.as_tensor(action, dtype=torch.float32, device=self.device).detach().reshape(
+                    self.batch_size, -1, 3).contiguous()
+                trig, stride = nf._select_trig(self.batch_size)
+                (img, actual, reflected, _rays, out5, mae, angles, all_bounds, _keep, _aux, ticket) = _field._get_ops().env_step_fwd(
+                    nf.heliostat_positions, self.sun_pos, n3, trig, stride, nf._plane, nf._xs, nf._ys, consts,
+                    notify=bool(self.check_finite))
+                mse, dist_l, bound, alignment_loss, flag = out5[0], out5[1], out5[2], out5[3], out5[4]
             aux = torch.cat([self.sun_pos.detach(), action.flatten(1)], dim=1)
             reflected, mae, angles = reflected.view([-1, 3]), mae.view([-1, 1]), angles.view([-1])
         metrics = {"mse": mse, "dist": dist_l, "bound": bound, "alignment_loss": alignment_loss}

@@ -276,6 +276,7 @@ class HelioField:
             out = memo.render_checked(sun_position, action, monitor)
             if out is not None:
                 return out
+        picked = None        # the error table once selected for this call: the fresh-error branch draws from the RNG
         if (type(sun_position) is torch.Tensor and type(action) is torch.Tensor
                 and not (action.requires_grad and torch.is_grad_enabled())):
             # launch-bound fast path (config 2 is ≈3.7 µs of GPU per call: every host microsecond shows):
@@ -295,6 +296,7 @@ class HelioField:
                 else:
                     trig, stride = self._select_trig(B)
                     cached = B == 1 or (batch is not None and B <= batch.shape[0])   # else: errors drawn per call
+                picked = (trig, stride)
                 ops = self._ops
                 key = self._ctx_key
                 if (key is None or key[0] is not trig or key[1] != stride or key[2] != ops.splat_variant
@@ -318,7 +320,9 @@ class HelioField:
         batched = sun.dim() > 1
         if not batched:
             sun = sun.unsqueeze(0)
-        img, actual, refl = self.render_rows(sun, action, 0, sun.shape[0], monitor)
+        # (a call that got as far as selecting its errors above and then needs the general path — ctypes binding,
+        # an action that needs a dtype fix-up — keeps that selection: ONE draw per render, as in the reference :349-353)
+        img, actual, refl = self.render_rows(sun, action, 0, sun.shape[0], monitor, _picked=picked)
         if not batched:
             img = img[0]
         return (img, actual, refl) if monitor else (img, actual)
@@ -372,7 +376,7 @@ class HelioField:
         image, actual, grad = out
         return (image if batched else image[0]), actual, grad.view(B, -1)
 
-    def render_rows(self, sun_rows, action_rows, row_offset: int, global_batch: int, monitor: bool = False):
+    def render_rows(self, sun_rows, action_rows, row_offset: int, global_batch: int, monitor: bool = False, _picked=None):
         """Render rows ``row_offset : row_offset+len(sun_rows)`` of a batch of
         ``global_batch`` suns (the whole batch when called by :meth:`render`; one shard of
         it when called by :class:`doodle_amd.sharded.ShardedRenderer`).  The error rows are
@@ -383,7 +387,7 @@ class HelioField:
 
         act = torch.as_tensor(action_rows, dtype=torch.float32, device=self.device)
         normals = act.reshape(B, N, 3).contiguous()
-        trig, stride = self._select_trig(global_batch, row_offset, B)
+        trig, stride = _picked if _picked is not None else self._select_trig(global_batch, row_offset, B)
 
         # a piece of a larger batch is rendered by the kernel the WHOLE batch would get (the size rules look at
         # B; every kernel's summation order depends on N and R only): the rows of the unsharded render, bit
