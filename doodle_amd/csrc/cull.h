@@ -71,9 +71,9 @@ struct CullFwd { const int* counts; const int* order; const float4* lists; };   
 struct CullBwd { const int* counts; const int* idx; const int* total; const int2* map; };
 
 // launchers (cull.hip)
-CullFwd launch_cull_fwd(int B, int N, int R, int TE, int S, int P, const float* rays, const float* xs, const float* ys,
-                        void* scratch, hipStream_t st);
-CullBwd launch_cull_bwd(int B, int N, int R, int JB, const float* rays, const float* xs, const float* ys,
+CullFwd launch_cull_fwd(int B, int N, int R, int TE, int S, int P, bool with_order, const float* rays, const float* xs,
+                        const float* ys, void* scratch, hipStream_t st);
+CullBwd launch_cull_bwd(int B, int N, int R, int JB, bool with_map, const float* rays, const float* xs, const float* ys,
                         float* moments, void* scratch, hipStream_t st);
 bool cull_enabled();
 

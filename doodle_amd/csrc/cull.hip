@@ -9,13 +9,16 @@
 
 namespace helio {
 
-constexpr int CULL_THREADS = 256, CULL_WAVES = CULL_THREADS / 64;
+constexpr int CULL_THREADS = 256;
+constexpr int CULL_BWD_THREADS = 1024;       // one workgroup per image compacts its list: few images must not take long
 
 // min and max of v[i0 .. i1) over the workgroup (every thread gets both); i1 > i0
+template <int THREADS = CULL_THREADS>
 __device__ __forceinline__ void block_minmax(const float* __restrict__ v, int i0, int i1, float* sm, float& lo, float& hi) {
+    constexpr int CULL_WAVES = THREADS / 64;
     float a = __builtin_inff(), b = -__builtin_inff();
     bool bad = false;
-    for (int i = i0 + (int)threadIdx.x; i < i1; i += CULL_THREADS) {
+    for (int i = i0 + (int)threadIdx.x; i < i1; i += THREADS) {
         const float x = v[i];
         bad |= x != x;
         a = fminf(a, x);
@@ -36,7 +39,9 @@ __device__ __forceinline__ void block_minmax(const float* __restrict__ v, int i0
 }
 
 // the calling thread's place among the flagged threads of the workgroup, and how many there are
+template <int THREADS = CULL_THREADS>
 __device__ __forceinline__ int block_rank(bool flag, int* sw, int& total) {
+    constexpr int CULL_WAVES = THREADS / 64;
     const unsigned long long m = __ballot(flag);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int rank = __popcll(m & ((1ull << lane) - 1ull));
@@ -56,8 +61,8 @@ __device__ __forceinline__ int block_rank(bool flag, int* sw, int& total) {
 __global__ void __launch_bounds__(CULL_THREADS)
 cull_fwd_kernel(int Nall, int R, int TE, int S, int P, const float4* __restrict__ rays, const float* __restrict__ xs,
                 const float* __restrict__ ys, int* __restrict__ counts, float4* __restrict__ lists) {
-    __shared__ float sm[3 * CULL_WAVES];
-    __shared__ int sw[CULL_WAVES];
+    __shared__ float sm[3 * CULL_THREADS / 64];
+    __shared__ int sw[CULL_THREADS / 64];
     const int tiles = (R + TE - 1) / TE;
     const int tile = blockIdx.x / S, part = blockIdx.x % S;
     const int b = blockIdx.y, ti = tile / tiles, tj = tile % tiles;
@@ -82,39 +87,48 @@ cull_fwd_kernel(int Nall, int R, int TE, int S, int P, const float4* __restrict_
     if (threadIdx.x == 0) counts[list] = base;
 }
 
-// grid (B): the rays of image b with a footprint that is not identically zero on the image, as indices; the
-// moments of the others (all column blocks) are zeroed here — what the dense kernels compute for them
-__global__ void __launch_bounds__(CULL_THREADS)
-cull_bwd_kernel(int N, int R, int JB, const float4* __restrict__ rays, const float* __restrict__ xs,
-                const float* __restrict__ ys, int* __restrict__ counts, int* __restrict__ idx,
-                float* __restrict__ moments) {
-    __shared__ float sm[3 * CULL_WAVES];
-    __shared__ int sw[CULL_WAVES];
+// grid (B): the rays of image b with a footprint that is not identically zero on the image, as indices, in order
+__global__ void __launch_bounds__(CULL_BWD_THREADS)
+cull_bwd_kernel(int N, int R, const float4* __restrict__ rays, const float* __restrict__ xs,
+                const float* __restrict__ ys, int* __restrict__ counts, int* __restrict__ idx) {
+    __shared__ float sm[3 * CULL_BWD_THREADS / 64];
+    __shared__ int sw[CULL_BWD_THREADS / 64];
     const int b = blockIdx.x;
     CullBox bx;
-    block_minmax(xs, 0, R, sm, bx.xlo, bx.xhi);
-    block_minmax(ys, 0, R, sm, bx.ylo, bx.yhi);
+    block_minmax<CULL_BWD_THREADS>(xs, 0, R, sm, bx.xlo, bx.xhi);
+    block_minmax<CULL_BWD_THREADS>(ys, 0, R, sm, bx.ylo, bx.yhi);
     const float4* __restrict__ rb = rays + (long)b * N;
     int* __restrict__ out = idx + (long)b * N;
     int base = 0;
-    for (int n0 = 0; n0 < N; n0 += CULL_THREADS) {
+    for (int n0 = 0; n0 < N; n0 += CULL_BWD_THREADS) {
         const int n = n0 + (int)threadIdx.x;
-        bool live = false;
-        if (n < N) {
-            live = !cull_dead_strict(rb[n], bx);
-            if (!live)
-                for (int jb = 0; jb < JB; ++jb) {
-                    float* o = moments + (((long)b * JB + jb) * N + n) * HELIO_MOMENT_STRIDE;
-#pragma unroll
-                    for (int k = 0; k < HELIO_MOMENT_STRIDE; ++k) o[k] = 0.0f;
-                }
-        }
+        const bool live = n < N && !cull_dead_strict(rb[n], bx);
         int total;
-        const int at = block_rank(live, sw, total);
+        const int at = block_rank<CULL_BWD_THREADS>(live, sw, total);
         if (live) out[base + at] = n;
         base += total;
     }
     if (threadIdx.x == 0) counts[b] = base;
+}
+
+// grid (⌈N/256⌉, B): the moments of the rays NOT listed (all column blocks) are zeroed — what the dense kernels
+// compute for them.  The same test on the same numbers as cull_bwd_kernel, one thread per ray: with few images
+// the list's one workgroup per image must not also write N·JB·20 bytes.
+__global__ void __launch_bounds__(CULL_THREADS)
+cull_bwd_fill_kernel(int N, int R, int JB, const float4* __restrict__ rays, const float* __restrict__ xs,
+                     const float* __restrict__ ys, float* __restrict__ moments) {
+    __shared__ float sm[3 * CULL_THREADS / 64];
+    const int b = blockIdx.y;
+    CullBox bx;
+    block_minmax(xs, 0, R, sm, bx.xlo, bx.xhi);
+    block_minmax(ys, 0, R, sm, bx.ylo, bx.yhi);
+    const int n = blockIdx.x * CULL_THREADS + (int)threadIdx.x;
+    if (n >= N || !cull_dead_strict(rays[(long)b * N + n], bx)) return;
+    for (int jb = 0; jb < JB; ++jb) {
+        float* o = moments + (((long)b * JB + jb) * N + n) * HELIO_MOMENT_STRIDE;
+#pragma unroll
+        for (int k = 0; k < HELIO_MOMENT_STRIDE; ++k) o[k] = 0.0f;
+    }
 }
 
 // ---- work order (cull.h): one workgroup each -----------------------------------------------------------
@@ -181,8 +195,8 @@ bool cull_enabled() {
     return on;
 }
 
-CullFwd launch_cull_fwd(int B, int N, int R, int TE, int S, int P, const float* rays, const float* xs, const float* ys,
-                        void* scratch, hipStream_t st) {
+CullFwd launch_cull_fwd(int B, int N, int R, int TE, int S, int P, bool with_order, const float* rays, const float* xs,
+                        const float* ys, void* scratch, hipStream_t st) {
     const int t = (R + TE - 1) / TE;
     const long T = (long)B * t * t * S;
     if (S == 1) P = N;
@@ -192,20 +206,23 @@ CullFwd launch_cull_fwd(int B, int N, int R, int TE, int S, int P, const float* 
     float4* lists = reinterpret_cast<float4*>(base + 2 * cull_pad256(4 * T));
     hipLaunchKernelGGL(cull_fwd_kernel, dim3(t * t * S, B), dim3(CULL_THREADS), 0, st, N, R, TE, S, P,
                        reinterpret_cast<const float4*>(rays), xs, ys, counts, lists);
-    hipLaunchKernelGGL(cull_order_fwd_kernel, dim3(1), dim3(ORDER_THREADS), 0, st, (int)T, P, counts, order);
+    if (with_order)
+        hipLaunchKernelGGL(cull_order_fwd_kernel, dim3(1), dim3(ORDER_THREADS), 0, st, (int)T, P, counts, order);
     return CullFwd{counts, order, lists};
 }
 
-CullBwd launch_cull_bwd(int B, int N, int R, int JB, const float* rays, const float* xs, const float* ys,
+CullBwd launch_cull_bwd(int B, int N, int R, int JB, bool with_map, const float* rays, const float* xs, const float* ys,
                         float* moments, void* scratch, hipStream_t st) {
     char* base = static_cast<char*>(scratch);
     int* counts = reinterpret_cast<int*>(base);
     int* idx = reinterpret_cast<int*>(base + cull_pad256(4l * B));
     int* total = reinterpret_cast<int*>(base + cull_pad256(4l * B) + cull_pad256(4l * B * N));
     int2* map = reinterpret_cast<int2*>(reinterpret_cast<char*>(total) + 256);
-    hipLaunchKernelGGL(cull_bwd_kernel, dim3(B), dim3(CULL_THREADS), 0, st, N, R, JB,
-                       reinterpret_cast<const float4*>(rays), xs, ys, counts, idx, moments);
-    hipLaunchKernelGGL(cull_map_bwd_kernel, dim3(1), dim3(ORDER_THREADS), 0, st, B, counts, total, map);
+    hipLaunchKernelGGL(cull_bwd_kernel, dim3(B), dim3(CULL_BWD_THREADS), 0, st, N, R,
+                       reinterpret_cast<const float4*>(rays), xs, ys, counts, idx);
+    hipLaunchKernelGGL(cull_bwd_fill_kernel, dim3((N + CULL_THREADS - 1) / CULL_THREADS, B), dim3(CULL_THREADS), 0, st, N, R, JB,
+                       reinterpret_cast<const float4*>(rays), xs, ys, moments);
+    if (with_map) hipLaunchKernelGGL(cull_map_bwd_kernel, dim3(1), dim3(ORDER_THREADS), 0, st, B, counts, total, map);
     return CullBwd{counts, idx, total, map};
 }
 

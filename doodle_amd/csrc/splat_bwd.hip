@@ -401,7 +401,11 @@ template <int PASS, int NRB>
 __device__ __forceinline__ void small_wave_partial_n(int N, int R, const float* __restrict__ rays_b,
                                                      const float* __restrict__ xs, const float* __restrict__ ys,
                                                      const float* __restrict__ G, int c0, int n0, int k_begin, int k_end,
-                                                     float* __restrict__ sCc_wave, float (&m)[NRB][3]) {
+                                                     float* __restrict__ sCc_wave, float (&m)[NRB][3],
+                                                     const int* __restrict__ lidx = nullptr, int L = -1, int* nn = nullptr) {
+    // (cull.h) with `lidx`: the ray axis runs over the image's list of rays whose footprint is not identically zero —
+    // position p < L is ray lidx[p] — and nn[rb] returns the ray this lane's results belong to (-1: none)
+    if (L < 0) L = N;
     const int lane = threadIdx.x & 63;
     const int lr = lane & 31, lh = lane >> 5;
     const float* __restrict__ ccoord = PASS == 0 ? ys : xs;   // coordinates along c (the axis that survives)
@@ -410,8 +414,15 @@ __device__ __forceinline__ void small_wave_partial_n(int N, int R, const float* 
     // first group of grad-image loads has been issued — every first touch of memory in a freshly launched
     // kernel costs ≈900 cycles, so none of them may wait for another
     float4 qraw[NRB];
+    int nray[NRB];
 #pragma unroll
-    for (int rb = 0; rb < NRB; ++rb) qraw[rb] = reinterpret_cast<const float4*>(rays_b)[min(n0 + 32 * rb + lr, N - 1)];
+    for (int rb = 0; rb < NRB; ++rb) {
+        const int p = n0 + 32 * rb + lr;
+        nray[rb] = lidx ? lidx[min(p, max(L - 1, 0))] : min(p, N - 1);
+        qraw[rb] = reinterpret_cast<const float4*>(rays_b)[nray[rb]];
+        if (p >= L) nray[rb] = -1;
+        if (nn) nn[rb] = nray[rb];
+    }
     const float ccv = ccoord[min(c0 + lane, R - 1)];
 
     f32x16 acc0[NRB], acc1[NRB];
@@ -479,7 +490,7 @@ __device__ __forceinline__ void small_wave_partial_n(int N, int R, const float* 
         for (int rb = 0; rb < NRB; ++rb) {
             float4 q = qraw[rb];
             asm volatile("" : "+v"(q.x), "+v"(q.y), "+v"(q.z), "+v"(q.w));
-            if (n0 + 32 * rb + lr >= N) q = make_float4(0.f, 0.f, 1.f, 1e30f);      // padding ray: factor = exp2(-1e30) = 0
+            if (nray[rb] < 0) q = make_float4(0.f, 0.f, 1.f, 1e30f);      // padding ray: factor = exp2(-1e30) = 0
             const float sk = __builtin_sqrtf(q.z);
             const float fshift = (PASS == 0 ? q.x : q.y) * sk;
             const float fcc = PASS == 0 ? q.w * q.z : 0.0f;
@@ -514,7 +525,7 @@ __device__ __forceinline__ void small_wave_partial_n(int N, int R, const float* 
     for (int rb = 0; rb < NRB; ++rb) {
         const float hshift = PASS == 0 ? qraw[rb].y : qraw[rb].x;
         const float hcc = PASS == 0 ? 0.0f : qraw[rb].w;
-        const float hk = n0 + 32 * rb + lr < N ? qraw[rb].z : 0.0f;
+        const float hk = nray[rb] >= 0 ? qraw[rb].z : 0.0f;
         float m0 = 0.f, m1 = 0.f, m2 = 0.f;
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk)
@@ -551,7 +562,8 @@ template <int PASS, int KS, int NRB, int RBW>
 __device__ __forceinline__ void splat_bwd_small_body(int N, int R, const float* __restrict__ rays,
                                                      const float* __restrict__ xs, const float* __restrict__ ys,
                                                      const float* __restrict__ gimg, float* __restrict__ moments,
-                                                     float* smem) {
+                                                     float* smem, const int* __restrict__ live_counts,
+                                                     const int* __restrict__ live_idx) {
     constexpr int NW = KS * RBW, RPG = 32 * NRB;      // waves per workgroup; rays per k-split group
     float* __restrict__ sCc = smem;                // [NW][64] c coordinates, one private copy per wave
     float* __restrict__ sRed = smem + NW * 64;     // [RBW][KS][RPG rays][3]
@@ -564,6 +576,10 @@ __device__ __forceinline__ void splat_bwd_small_body(int N, int R, const float* 
     const int lr = lane & 31, lh = lane >> 5;
     const int c0 = (blockIdx.x % JB) * 64, n0 = ((blockIdx.x / JB) * RBW + grp) * RPG;
     const float* __restrict__ G = gimg + (long)b * R * R;
+    // (cull.h) per-image list of the rays that are not identically zero: workgroups past its end leave at once
+    const int L = live_counts ? live_counts[b] : N;
+    const int* __restrict__ lidx = live_counts ? live_idx + (long)b * N : nullptr;
+    if ((int)(blockIdx.x / JB) * RBW * RPG >= L) return;
 
     // this wave's part of the contracted axis: k-pairs dealt evenly, in multiples of 2 (so that a wave
     // starts at a multiple of 4: 16-byte row segments in pass 1)
@@ -572,13 +588,14 @@ __device__ __forceinline__ void splat_bwd_small_body(int N, int R, const float* 
     const int k_begin = min(R, 2 * per * kpart), k_end = min(R, 2 * per * (kpart + 1));
 
     float m[NRB][3];
-    small_wave_partial_n<PASS, NRB>(N, R, rays + 4l * b * N, xs, ys, G, c0, n0, k_begin, k_end, sCc + wave * 64, m);
+    int nn[NRB];
+    small_wave_partial_n<PASS, NRB>(N, R, rays + 4l * b * N, xs, ys, G, c0, n0, k_begin, k_end, sCc + wave * 64, m, lidx, L, nn);
     if constexpr (KS == 1) {
         if (lh == 0) {
 #pragma unroll
             for (int rb = 0; rb < NRB; ++rb) {
-                const int n = n0 + 32 * rb + lr;
-                if (n < N) {
+                const int n = nn[rb];
+                if (n >= 0) {
                     float* o = moments + (((long)b * JB + c0 / 64) * N + n) * HELIO_MOMENT_STRIDE;
                     if (PASS == 0) { o[0] = m[rb][0]; o[2] = m[rb][1]; o[4] = m[rb][2]; }
                     else { o[1] = m[rb][1]; o[3] = m[rb][2]; }
@@ -597,7 +614,8 @@ __device__ __forceinline__ void splat_bwd_small_body(int N, int R, const float* 
     __syncthreads();
     if (tid < RBW * RPG) {                                          // fixed order over the KS k-parts
         const int g = tid / RPG, rl = tid % RPG;
-        const int n = ((blockIdx.x / JB) * RBW + g) * RPG + rl;
+        const int p = ((blockIdx.x / JB) * RBW + g) * RPG + rl;
+        const int n = p < L ? (lidx ? lidx[p] : p) : N;
         if (n < N) {
             float t0 = 0.f, t1 = 0.f, t2 = 0.f;
 #pragma unroll
@@ -615,10 +633,11 @@ __device__ __forceinline__ void splat_bwd_small_body(int N, int R, const float* 
 template <int KS, int NRB = 1, int RBW = 1>
 __global__ void __launch_bounds__(64 * KS * RBW)
 splat_bwd_mfma_small(int N, int R, const float* __restrict__ rays, const float* __restrict__ xs,
-                     const float* __restrict__ ys, const float* __restrict__ gimg, float* __restrict__ moments) {
+                     const float* __restrict__ ys, const float* __restrict__ gimg, float* __restrict__ moments,
+                     const int* __restrict__ live_counts, const int* __restrict__ live_idx) {
     __shared__ float smem[KS * RBW * 64 + KS * RBW * 32 * NRB * 3];
-    if (blockIdx.z == 0) splat_bwd_small_body<0, KS, NRB, RBW>(N, R, rays, xs, ys, gimg, moments, smem);
-    else splat_bwd_small_body<1, KS, NRB, RBW>(N, R, rays, xs, ys, gimg, moments, smem);
+    if (blockIdx.z == 0) splat_bwd_small_body<0, KS, NRB, RBW>(N, R, rays, xs, ys, gimg, moments, smem, live_counts, live_idx);
+    else splat_bwd_small_body<1, KS, NRB, RBW>(N, R, rays, xs, ys, gimg, moments, smem, live_counts, live_idx);
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -1228,11 +1247,34 @@ static int splat_bwd_choice(int B, int N, int R) {
     return splat_bwd_is_few(B, N) ? 4 : (R > 64 && N >= 96 && wgs >= 128) ? 2 : 3;
 }
 
+// the small-tile kernel's form without a split of the contracted axis (4 independent waves of 64 rays each): from
+// N = 600 with workgroups enough (tools/sweep_bwd_nrb.py)
+static bool small_whole_k(int B, int N, int R) {
+    static const int ks_exp = [] { const char* e = getenv("HELIO_BWD_KSX"); return e ? atoi(e) : 0; }();     // tuning runs
+    return ks_exp == 0 && N >= 600 && 2l * ((R + 63) / 64) * ((N + 255) / 256) * B >= 256;
+}
+
 // Skipping rays whose footprint is identically zero on the image (cull.h): the LDS-tile kernels walk 256-ray
-// tiles of a per-image list; worth a compaction launch once an image has more than one such tile.
+// tiles of a per-image list, the small-tile kernel in its whole-k form (few images of many heliostats) 256-ray
+// groups of it.  In the backward a list means FEWER workgroups, not shorter ones (a ray's moments are a sum over
+// the whole image), so it pays only where the dense grid is more than one round of the chip: measured at B = 4,
+// N = 5000, R = 512 — 160 tiles, one round — the two passes take 134 µs each with or without the list and the
+// three small launches in front of them cost 21 µs; at B = 16, R = 256 (320 tiles): 291 → 177 µs
+// (tools/bench_few_images.py).
+// → the kernel this call runs CAN walk a list (what a launch with enough scratch does) …
+static bool cull_bwd_possible(int variant, int B, int N, int R) {
+    if (variant == 0) variant = splat_bwd_choice(B, N, R);
+    if (!cull_enabled() || N <= 256) return false;
+    return variant == 2 || (variant == 3 && small_whole_k(B, N, R));
+}
+// … and it PAYS (what the size query answers: a caller that sizes its scratch by the query hands none otherwise)
 static bool cull_bwd_wanted(int variant, int B, int N, int R) {
     if (variant == 0) variant = splat_bwd_choice(B, N, R);
-    return variant == 2 && N > 256 && cull_enabled();
+    if (!cull_bwd_possible(variant, B, N, R)) return false;
+    const long ray_tiles = (N + 255) / 256;
+    if (variant == 2) return (long)B * ((R + (R <= 128 ? 127 : 255)) / (R <= 128 ? 128 : 256)) * ray_tiles > 256;   // 1 tile per CU
+    // (both passes in one launch; two 4-wave workgroups fit a CU)
+    return N >= 1024 && 2l * B * ((R + 63) / 64) * ray_tiles > 512;
 }
 
 long splat_bwd_scratch_bytes(int B, int N, int R, int variant) {
@@ -1257,34 +1299,37 @@ int launch_splat_bwd(int B, int N, int R, const float* rays, const float* xs, co
         const int ct = (R + 63) / 64, nt = (N + 31) / 32;
         const int nrb = variant == 3 ? bwd_small_nrb(B, N, R) : 1;
         static const int ks_exp = [] { const char* e = getenv("HELIO_BWD_KSX"); return e ? atoi(e) : 0; }();     // tuning runs
+        CullBwd cull{nullptr, nullptr, nullptr, nullptr};
+        if (scratch && cull_bwd_possible(variant, B, N, R) && scratch_bytes >= cull_bwd_bytes(B, N))
+            cull = launch_cull_bwd(B, N, R, splat_bwd_blocks(R), /*with_map=*/false, rays, xs, ys, moments, scratch, st);
         // tools/sweep_bwd_nrb.py: from N = 600 — with workgroups enough — no split of the contracted axis at all
         // (4 independent waves of 64 rays each: one epilogue per 2·R MFMAs): B = 25: N = 1000, R = 128: 37 → 30 µs,
         // R = 256: 112 → 98 µs; B = 256, N = 1000, R = 64: 96 → 62 µs; at N = 300 it is 1.5× slower.  (Held to 128
         // registers — four waves per SIMD instead of two — it is no faster: 35.6 µs; the two passes alone take
         // 16.5 and 21.0 µs of the 31 µs they take together.)
-        const bool whole_k = variant == 3 && ks_exp == 0 && N >= 600 && 2l * ct * ((N + 255) / 256) * B >= 256;
+        const bool whole_k = variant == 3 && small_whole_k(B, N, R);
         if (whole_k || (variant == 3 && ks_exp == 1 && nrb == 2))
-            hipLaunchKernelGGL((splat_bwd_mfma_small<1, 2, 4>), dim3(ct * ((N + 255) / 256), B, 2), dim3(256), 0, st, N, R, rays, xs, ys, gimg, moments);
+            hipLaunchKernelGGL((splat_bwd_mfma_small<1, 2, 4>), dim3(ct * ((N + 255) / 256), B, 2), dim3(256), 0, st, N, R, rays, xs, ys, gimg, moments, cull.counts, cull.idx);
         else if (variant == 3 && ks_exp == 1 && nrb == 1)
-            hipLaunchKernelGGL((splat_bwd_mfma_small<1, 1, 4>), dim3(ct * ((N + 127) / 128), B, 2), dim3(256), 0, st, N, R, rays, xs, ys, gimg, moments);
+            hipLaunchKernelGGL((splat_bwd_mfma_small<1, 1, 4>), dim3(ct * ((N + 127) / 128), B, 2), dim3(256), 0, st, N, R, rays, xs, ys, gimg, moments, nullptr, nullptr);
         else if (variant == 3 && ks_exp == 2 && nrb == 1)
-            hipLaunchKernelGGL((splat_bwd_mfma_small<2, 1, 2>), dim3(ct * ((N + 63) / 64), B, 2), dim3(256), 0, st, N, R, rays, xs, ys, gimg, moments);
+            hipLaunchKernelGGL((splat_bwd_mfma_small<2, 1, 2>), dim3(ct * ((N + 63) / 64), B, 2), dim3(256), 0, st, N, R, rays, xs, ys, gimg, moments, nullptr, nullptr);
         else if (variant == 3 && ks_exp == 2 && nrb == 2)
-            hipLaunchKernelGGL((splat_bwd_mfma_small<2, 2, 2>), dim3(ct * ((N + 127) / 128), B, 2), dim3(256), 0, st, N, R, rays, xs, ys, gimg, moments);
+            hipLaunchKernelGGL((splat_bwd_mfma_small<2, 2, 2>), dim3(ct * ((N + 127) / 128), B, 2), dim3(256), 0, st, N, R, rays, xs, ys, gimg, moments, nullptr, nullptr);
         else if (nrb == 4)
-            hipLaunchKernelGGL((splat_bwd_mfma_small<4, 4>), dim3(ct * ((N + 127) / 128), B, 2), dim3(256), 0, st, N, R, rays, xs, ys, gimg, moments);
+            hipLaunchKernelGGL((splat_bwd_mfma_small<4, 4>), dim3(ct * ((N + 127) / 128), B, 2), dim3(256), 0, st, N, R, rays, xs, ys, gimg, moments, nullptr, nullptr);
         else if (nrb == 2)
-            hipLaunchKernelGGL((splat_bwd_mfma_small<4, 2>), dim3(ct * ((N + 63) / 64), B, 2), dim3(256), 0, st, N, R, rays, xs, ys, gimg, moments);
+            hipLaunchKernelGGL((splat_bwd_mfma_small<4, 2>), dim3(ct * ((N + 63) / 64), B, 2), dim3(256), 0, st, N, R, rays, xs, ys, gimg, moments, nullptr, nullptr);
         else if (variant == 7 || (variant == 3 && bwd_small_ks(B, N, R) == 8))
-            hipLaunchKernelGGL(splat_bwd_mfma_small<8>, dim3(ct * nt, B, 2), dim3(512), 0, st, N, R, rays, xs, ys, gimg, moments);
+            hipLaunchKernelGGL(splat_bwd_mfma_small<8>, dim3(ct * nt, B, 2), dim3(512), 0, st, N, R, rays, xs, ys, gimg, moments, nullptr, nullptr);
         else
-            hipLaunchKernelGGL(splat_bwd_mfma_small<4>, dim3(ct * nt, B, 2), dim3(256), 0, st, N, R, rays, xs, ys, gimg, moments);
+            hipLaunchKernelGGL(splat_bwd_mfma_small<4>, dim3(ct * nt, B, 2), dim3(256), 0, st, N, R, rays, xs, ys, gimg, moments, nullptr, nullptr);
         return HELIO_OK;
     }
     if (variant == 2) {
         CullBwd cull{nullptr, nullptr, nullptr, nullptr};
-        if (scratch && cull_bwd_wanted(2, B, N, R) && scratch_bytes >= cull_bwd_bytes(B, N))
-            cull = launch_cull_bwd(B, N, R, splat_bwd_blocks(R), rays, xs, ys, moments, scratch, st);
+        if (scratch && cull_bwd_possible(2, B, N, R) && scratch_bytes >= cull_bwd_bytes(B, N))
+            cull = launch_cull_bwd(B, N, R, splat_bwd_blocks(R), /*with_map=*/true, rays, xs, ys, moments, scratch, st);
         launch_bwd_mfma<0>(B, N, R, rays, xs, ys, gimg, moments, st, cull);
         launch_bwd_mfma<1>(B, N, R, rays, xs, ys, gimg, moments, st, cull);
         return HELIO_OK;

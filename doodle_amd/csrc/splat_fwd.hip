@@ -335,7 +335,8 @@ constexpr int KSPLIT_PARTS = 16;
 template <int KP>
 __global__ void __launch_bounds__(64 * KP)
 splat_fwd_block_ksplit(int N, int R, const float* __restrict__ rays, const float* __restrict__ xs,
-                       const float* __restrict__ ys, float* __restrict__ image) {
+                       const float* __restrict__ ys, float* __restrict__ image, const int* __restrict__ live_counts,
+                       const float4* __restrict__ live_lists) {
     constexpr int PW = KSPLIT_PARTS / KP;              // parts per wave
     // ray buffers [KP][2][64 + 4] float4 during the sum; afterwards the same space holds the partial blocks,
     // 8 of the 16 accumulator registers at a time: [16 parts][8][64] floats (35 KB at KP = 16)
@@ -349,8 +350,6 @@ splat_fwd_block_ksplit(int N, int R, const float* __restrict__ rays, const float
 
     const int per = (((N + KSPLIT_PARTS - 1) / KSPLIT_PARTS) + 3) & ~3;
     const float4* __restrict__ rb = reinterpret_cast<const float4*>(rays) + (long)b * N;
-    // (clamped, unconditional loads: "in range ? load : pad" becomes a branch around the load)
-    auto fetch = [&](int base) { return rb[min(base + lane, N - 1)]; };
 
     f32x16 acc[PW];
     int buf = 0;
@@ -359,7 +358,19 @@ splat_fwd_block_ksplit(int N, int R, const float* __restrict__ rays, const float
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[pw][e] = 0.0f;
         const int part = wave * PW + pw;
-        const int n_begin = min(N, per * part), n_end = min(N, n_begin + per);
+        // the part's rays: `per` consecutive ones of the image, or (cull.h) the ordered list of those of them whose
+        // footprint is not exactly zero on the image — each part is a chain from zero either way: the same bits
+        int n_begin = min(N, per * part), n_end = min(N, n_begin + per), last = N - 1;
+        const float4* __restrict__ src = rb;
+        if (live_counts) {
+            const long list = (long)b * KSPLIT_PARTS + part;
+            n_begin = 0;
+            n_end = live_counts[list];
+            src = live_lists + list * per;
+            last = max(n_end - 1, 0);
+        }
+        // (clamped, unconditional loads: "in range ? load : pad" becomes a branch around the load)
+        auto fetch = [&](int base) { return src[min(base + lane, last)]; };
         float4 nxt = fetch(n_begin);
         for (int base = n_begin; base < n_end; base += 64, buf ^= 1) {
             float4* __restrict__ tab = reinterpret_cast<float4*>(smem) + (wave * 2 + buf) * 68;
@@ -429,13 +440,13 @@ static int ksplit_parts(int B, int N, int R) {
 }
 
 static bool launch_ksplit(int B, int N, int R, const float* rays, const float* xs, const float* ys, float* image,
-                          int kp, hipStream_t st) {
+                          int kp, hipStream_t st, CullFwd cull = CullFwd{nullptr, nullptr, nullptr}) {
     const int t = (R + 31) / 32;
     if (t > 65535 || B > 65535) return false;
     const dim3 grid(t, t, B);
-    if (kp == 16) hipLaunchKernelGGL(splat_fwd_block_ksplit<16>, grid, dim3(1024), 0, st, N, R, rays, xs, ys, image);
-    else if (kp == 8) hipLaunchKernelGGL(splat_fwd_block_ksplit<8>, grid, dim3(512), 0, st, N, R, rays, xs, ys, image);
-    else if (kp == 4) hipLaunchKernelGGL(splat_fwd_block_ksplit<4>, grid, dim3(256), 0, st, N, R, rays, xs, ys, image);
+    if (kp == 16) hipLaunchKernelGGL(splat_fwd_block_ksplit<16>, grid, dim3(1024), 0, st, N, R, rays, xs, ys, image, cull.counts, cull.lists);
+    else if (kp == 8) hipLaunchKernelGGL(splat_fwd_block_ksplit<8>, grid, dim3(512), 0, st, N, R, rays, xs, ys, image, cull.counts, cull.lists);
+    else if (kp == 4) hipLaunchKernelGGL(splat_fwd_block_ksplit<4>, grid, dim3(256), 0, st, N, R, rays, xs, ys, image, cull.counts, cull.lists);
     else return false;
     return true;
 }
@@ -1522,22 +1533,35 @@ static int split_parts(int variant) { return variant >= 14 && variant <= 17 ? 2 
 static int split_part_rays(int N, int S) { return (((N + S - 1) / S) + 63) & ~63; }
 static long split_partial_bytes(int B, int R, int S) { return S > 1 ? cull_pad256(4l * B * S * R * R) : 0; }
 
-// Skipping exactly-zero rays (cull.h): the one-level LDS-table / register-operand kernels take a per-tile list of
-// the rays that are not exactly zero on their tile.  (The two-level and part-wise kernels — 64² tiles, k-split —
-// round at chunk boundaries, which a compacted list would move; the split-bf16 kernels align products against
-// the accumulator inside the pipe.  They stay dense.)  → the tile edge of the lists, 0: this call runs dense.
-// From N = 192: below that the compaction launch costs what it saves.
-static int cull_fwd_tile(int variant, int B, int N, int R) {
+// Skipping exactly-zero rays (cull.h): which lists a variant's kernel takes.  The one-level LDS-table /
+// register-operand kernels: one list per (image, tile[, part of a split sum]) — removing terms that leave the
+// accumulator unchanged from ONE fmaf chain leaves its result.  The k-split block kernel: one list per (image, part)
+// for the whole image (its 16 parts are chains from zero over fixed ray ranges, culled inside each range; every
+// 32×32 block of the image walks the same lists) — from N = 1024 and 2^31 (ray, pixel) pairs: it serves few images,
+// where the compaction launch must be paid by one short kernel.  (The 64² two-level kernel rounds at 128-ray chunk boundaries — one list per
+// chunk would be more lists than rays saved —, the split-bf16 kernels align products against the accumulator inside
+// the pipe, the VALU kernels are reference forms: they stay dense.)  From N = 192: below that the compaction launch
+// costs what it saves.
+struct CullPlan { int te, S, P; bool order; };       // te = 0: this call runs dense
+constexpr int CULL_WHOLE_IMAGE = 16384;              // a tile edge no image exceeds (R <= 16384)
+static CullPlan cull_fwd_plan(int variant, int B, int N, int R) {
     if (variant == 0 || variant == 2) variant = splat_fwd_choice(B, N, R);
-    if (!cull_enabled() || N < 192) return 0;
-    return (variant == 5 || split_parts(variant) > 1) ? 256 : (variant == 3 || variant == 4) ? 128 : 0;
+    if (!cull_enabled() || N < 192) return {0, 1, 0, false};
+    const int S = split_parts(variant);
+    if (variant == 5 || S > 1) return {256, S, split_part_rays(N, S), true};
+    if (variant == 3 || variant == 4) return {128, 1, 0, true};
+    // (tools/sweep_split.py at err 90 / sigma 0.01, k-split with and without lists: B=4, N=5000, R=512: 130 → 86 µs; B=2:
+    // 69 → 46; B=8, N=2000, R=512: 102 → 70; nothing at N = 1000; with every ray live the extra launch costs ≈5 µs)
+    if (variant == 9 && N >= 1024 && (long)B * N * R * R >= (1l << 31))
+        return {CULL_WHOLE_IMAGE, KSPLIT_PARTS, (((N + KSPLIT_PARTS - 1) / KSPLIT_PARTS) + 3) & ~3, false};
+    return {0, 1, 0, false};
 }
 
 // bytes a call can use (partial images of a split sum + the lists); and the part of it the call cannot do without
 long splat_fwd_scratch_bytes(int B, int N, int R, int variant) {
     if (variant == 0 || variant == 2) variant = splat_fwd_choice(B, N, R);
-    const int S = split_parts(variant), te = cull_fwd_tile(variant, B, N, R);
-    return split_partial_bytes(B, R, S) + (te ? cull_fwd_bytes(B, N, R, te, S, split_part_rays(N, S)) : 0);
+    const CullPlan c = cull_fwd_plan(variant, B, N, R);
+    return split_partial_bytes(B, R, split_parts(variant)) + (c.te ? cull_fwd_bytes(B, N, R, c.te, c.S, c.P) : 0);
 }
 long splat_fwd_scratch_required(int B, int N, int R, int variant) {
     if (variant == 0 || variant == 2) variant = splat_fwd_choice(B, N, R);
@@ -1552,9 +1576,9 @@ int launch_splat_fwd(int B, int N, int R, const float* rays, const float* xs, co
     const long part_bytes = split_partial_bytes(B, R, S);
     if (S > 1 && (!scratch || scratch_bytes < part_bytes)) return HELIO_E_SCRATCH;
     CullFwd cull{nullptr, nullptr, nullptr};
-    if (const int te = scratch ? cull_fwd_tile(variant, B, N, R) : 0;
-        te && scratch_bytes >= part_bytes + cull_fwd_bytes(B, N, R, te, S, P))
-        cull = launch_cull_fwd(B, N, R, te, S, P, rays, xs, ys, static_cast<char*>(scratch) + part_bytes, st);
+    if (const CullPlan c = scratch ? cull_fwd_plan(variant, B, N, R) : CullPlan{0, 1, 0, false};
+        c.te && scratch_bytes >= part_bytes + cull_fwd_bytes(B, N, R, c.te, c.S, c.P))
+        cull = launch_cull_fwd(B, N, R, c.te, c.S, c.P, c.order, rays, xs, ys, static_cast<char*>(scratch) + part_bytes, st);
     if (S > 1) {
         float* partials = static_cast<float*>(scratch);
         launch_tile<4, false>(B, N, R, rays, xs, ys, image, st, cull, S, P, partials);
@@ -1566,7 +1590,7 @@ int launch_splat_fwd(int B, int N, int R, const float* rays, const float* xs, co
     switch (variant) {
     case 9: {       // the k-split block kernel; forced: 16 waves where the rule would not choose it
         const int kp = ksplit_parts(B, N, R);
-        return launch_ksplit(B, N, R, rays, xs, ys, image, kp ? kp : (N >= 512 ? 16 : 4), st) ? HELIO_OK : HELIO_E_INVALID;
+        return launch_ksplit(B, N, R, rays, xs, ys, image, kp ? kp : (N >= 512 ? 16 : 4), st, cull) ? HELIO_OK : HELIO_E_INVALID;
     }
     case 1:
         if (t128 < 512) {

@@ -75,7 +75,9 @@ typedef struct helio_plane {
  * any f32 accumulator — leaving them out changes no bit of any output (doodle_amd/csrc/cull.h states the
  * criterion, which is evaluated on what the kernels compute, with a margin).  Results are IDENTICAL with and
  * without scratch, with a buffer that is too small (the dense kernels run) and with HELIO_CULL=0; a query
- * returns 0 when the kernel the call would run takes no scratch.
+ * returns 0 when the kernel the call would run takes no scratch OR would not gain from it (in the backward a list
+ * means fewer workgroups, which pays only where the dense grid is more than one round of the chip) — a call that
+ * is handed enough scratch anyway uses it.
  */
 long helio_fwd_scratch_bytes(int B, int N, int R, int variant);
 long helio_bwd_scratch_bytes(int B, int N, int R, int variant);

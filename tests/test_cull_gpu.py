@@ -42,6 +42,21 @@ def field_and_rays(N, B, R, sigma, err, seed=0, normal=(0.0, 1.0, 0.0), span=10.
     return f, suns.to(DEV), act, rays
 
 
+def splat_bwd_with_list(rays, xs, ys, G, variant):
+    """helio_splat_bwd handed enough scratch for the per-image list whatever the size rule says → (moments, counts)."""
+    from doodle_amd import native
+    ops = native.get_ops()
+    B, N, R = rays.shape[0], rays.shape[1], xs.shape[0]
+    pad = lambda n: (n + 255) // 256 * 256      # noqa: E731  counts | idx | total | map (csrc/cull.h)
+    need = pad(4 * B) + pad(4 * B * N) + 256 + 8 * B * ((N + 255) // 256)
+    scratch = torch.full((need,), 0x7F, dtype=torch.uint8, device=rays.device)
+    moments = torch.full((B, ops.lib.helio_splat_bwd_blocks(R), N, 5), float("nan"), device=rays.device)
+    rc = ops.lib.helio_splat_bwd(B, N, R, rays.data_ptr(), xs.data_ptr(), ys.data_ptr(), G.data_ptr(), moments.data_ptr(), variant,
+                                 scratch.data_ptr(), need, native._stream())
+    assert rc == 0, ops.lib.helio_last_error_string()
+    return moments, scratch[:4 * B].view(torch.int32).clone(), need
+
+
 def splat_with_counts(rays, xs, ys, variant):
     """helio_splat_fwd with a scratch buffer of the test's own → (image, live counts per (image, tile) | None)."""
     from doodle_amd import native
@@ -132,7 +147,8 @@ def test_rays_on_the_threshold_of_the_criterion(N, B, R, seed):
     # dense kernel has numbers, NaN exactly where it has NaN (the moments of the NaN rays)
     G = torch.randn(B, R, R, device=DEV, generator=torch.Generator(device=DEV).manual_seed(seed)) * 1e6
     dense_m = ops.splat_bwd(rays, xs, ys, G, variant=2, cull=False)
-    culled_m = ops.splat_bwd(rays, xs, ys, G, variant=2, cull=True)
+    culled_m, bcounts, _ = splat_bwd_with_list(rays, xs, ys, G, 2)
+    assert N <= 256 or 0 < int(bcounts.sum()) < B * N       # (up to 256 rays: one ray tile per image, no list)
     assert torch.equal(torch.isnan(dense_m), torch.isnan(culled_m)) and torch.isnan(dense_m).any()
     ok = ~torch.isnan(dense_m)
     assert torch.equal(bits(culled_m)[ok], bits(dense_m)[ok])
@@ -145,15 +161,20 @@ def test_culled_backward_moments_equal_the_dense_ones_bit_for_bit(N, B, R, sigma
     ops = native.get_ops()
     f, suns, act, rays = field_and_rays(N, B, R, sigma, err, seed=N + R + 1, span=30.0)
     G = torch.randn(B, R, R, device=DEV, generator=torch.Generator(device=DEV).manual_seed(3))
-    pad = lambda n: (n + 255) // 256 * 256      # noqa: E731  counts | idx | total | map (csrc/cull.h)
-    assert ops.lib.helio_bwd_scratch_bytes(B, N, R, 2) == pad(4 * B) + pad(4 * B * N) + 256 + 8 * B * ((N + 255) // 256)
     dense = ops.splat_bwd(rays, f._xs, f._ys, G, variant=2, cull=False)
-    culled = ops.splat_bwd(rays, f._xs, f._ys, G, variant=2, cull=True)
+    # (the size rule hands over a list only where the dense grid is more than one round of the chip; these small
+    # cases pass the scratch themselves to exercise the kernels)
+    culled, counts, need = splat_bwd_with_list(rays, f._xs, f._ys, G, 2)
+    assert ops.lib.helio_bwd_scratch_bytes(B, N, R, 2) in (0, need) and ops.lib.helio_bwd_scratch_bytes(512, 2000, 512, 2) > 0
     assert same_bits(culled, dense), (culled - dense).abs().max().item()
+    assert int(counts.min()) >= 0 and int(counts.max()) <= N
     if sigma == 0.01:                                    # some rays ARE dropped: their moments read exactly +0
+        assert int(counts.sum()) < B * N
         dead = (culled.abs().sum(dim=(1, 3)) == 0)
         assert dead.any()
         assert not (bits(culled)[dead[:, None, :, None].expand_as(culled)] != 0).any()
+    else:
+        assert int(counts.sum()) == B * N
     for variant in (1, 3, 4, 5, 6, 7):
         assert ops.lib.helio_bwd_scratch_bytes(B, N, R, variant) == 0
 
@@ -164,7 +185,7 @@ def test_render_autograd_and_env_step_are_unchanged_by_the_culling():
     from doodle_amd import native
     from doodle_amd.env import HelioEnv
     ops = native.get_ops()
-    N, B, R = 600, 48, 256
+    N, B, R = 600, 96, 256
     f, suns, act, _ = field_and_rays(N, B, R, 0.01, 90.0, seed=11, span=40.0)
     assert ops.lib.helio_fwd_scratch_bytes(B, N, R, 0) > 0 and ops.lib.helio_bwd_scratch_bytes(B, N, R, 0) > 0
     G = torch.randn(B, R, R, device=DEV, generator=torch.Generator(device=DEV).manual_seed(1))
@@ -341,3 +362,64 @@ def test_split_heliostat_sum_variants(N, B, R, sigma, err):
                                  native._stream())
     torch.cuda.synchronize()
     assert rc == -6 and b"scratch" in ops.lib.helio_last_error_string() and float(image.min()) == 7.0
+
+
+@pytest.mark.parametrize("N,B,R", [(1500, 6, 512), (5000, 2, 512), (1200, 7, 513), (3000, 12, 256)])
+@pytest.mark.parametrize("sigma,err", [(0.01, 90.0), (0.01, 180.0), (0.1, 90.0)])
+def test_ksplit_block_kernel_with_lists_equals_the_dense_one_bit_for_bit(N, B, R, sigma, err):
+    """One sun over a whole plant (few images, N >= 1024, >= 2^31 (ray, pixel) pairs): the k-split block kernel takes
+    one list per (image, part) — its 16 parts are chains from zero over fixed ray ranges, culled inside each range."""
+    from doodle_amd import native
+    ops = native.get_ops()
+    assert ops.render_choice(B, N, R) == 9 and ops.lib.helio_fwd_scratch_bytes(B, N, R, 0) > 0
+    assert ops.lib.helio_fwd_scratch_bytes(B, 1000, R, 9) == 0            # below 1024 rays: dense
+    assert ops.lib.helio_fwd_scratch_bytes(1, 5000, 256, 9) == 0          # a short kernel: the compaction launch would not pay
+    f, suns, act, rays = field_and_rays(N, B, R, sigma, err, seed=N + R + B, span=40.0)
+    dense = ops.splat_fwd(rays, f._xs, f._ys, variant=9, cull=False)
+    n = ops.lib.helio_fwd_scratch_bytes(B, N, R, 9)
+    image = torch.empty_like(dense)
+    scratch = torch.full((n,), 0x7F, dtype=torch.uint8, device=DEV)
+    rc = ops.lib.helio_splat_fwd(B, N, R, rays.data_ptr(), f._xs.data_ptr(), f._ys.data_ptr(), image.data_ptr(), 9,
+                                 scratch.data_ptr(), n, native._stream())
+    assert rc == 0 and same_bits(image, dense)
+    counts = scratch[:4 * B * 16].view(torch.int32).view(B, 16)
+    per = (((N + 15) // 16) + 3) & ~3
+    assert int(counts.min()) >= 0 and int(counts.max()) <= per
+    if sigma == 0.1:
+        assert int(counts.sum()) == B * N
+    else:
+        assert int(counts.sum()) < 0.8 * B * N
+    # the render through the Python surface takes the same path by default
+    with torch.no_grad():
+        img, _ = f.render(suns, act.reshape(B, -1), None)
+    assert same_bits(img if B > 1 else img, dense)
+
+
+@pytest.mark.parametrize("N,B,R", [(5000, 2, 512), (1500, 6, 512), (3000, 12, 256), (1200, 7, 513)])
+@pytest.mark.parametrize("sigma,err", [(0.01, 90.0), (0.01, 180.0), (0.1, 90.0)])
+def test_small_tile_backward_with_lists_equals_the_dense_one_bit_for_bit(N, B, R, sigma, err):
+    """The backward of few images of many heliostats: the small-tile kernel in its whole-k form walks 256-ray groups
+    of the per-image list (where its dense grid is more than one round of the chip); moments bit-identical with the
+    dense launch — forced (variant 3) and as the size rule chooses —, the gradient through render_bwd too."""
+    from doodle_amd import native
+    ops = native.get_ops()
+    assert ops.lib.helio_bwd_scratch_bytes(2, 5000, 512, 0) > 0          # 640 workgroups of the small-tile kernel: a list
+    assert ops.lib.helio_bwd_scratch_bytes(1, 5000, 256, 0) == 0 and ops.lib.helio_bwd_scratch_bytes(B, N, R, 6) == 0
+    assert ops.lib.helio_bwd_scratch_bytes(4, 5000, 512, 0) == 0       # 160 tiles of the LDS-tile kernel: one round, no list
+    f, suns, act, rays = field_and_rays(N, B, R, sigma, err, seed=N + R + B + 5, span=40.0)
+    G = torch.randn(B, R, R, device=DEV, generator=torch.Generator(device=DEV).manual_seed(9))
+    dense = ops.splat_bwd(rays, f._xs, f._ys, G, variant=3, cull=False)
+    culled, counts, _ = splat_bwd_with_list(rays, f._xs, f._ys, G, 3)
+    assert same_bits(culled, dense) and (int(counts.sum()) < B * N) == (sigma == 0.01)
+    assert same_bits(ops.splat_bwd(rays, f._xs, f._ys, G, variant=3, cull=True), dense)
+    assert same_bits(ops.splat_bwd(rays, f._xs, f._ys, G, variant=0, cull=True), ops.splat_bwd(rays, f._xs, f._ys, G, variant=0, cull=False))
+    if sigma == 0.01:
+        assert (culled.abs().sum(dim=(1, 3)) == 0).any()
+    out = {}
+    for cull in (True, False):
+        ops.cull = cull
+        try:
+            out[cull] = f.render_value_and_grad(suns, act.reshape(B, -1), grad_image=G)[2]
+        finally:
+            ops.cull = True
+    assert same_bits(out[True], out[False])
