@@ -423,3 +423,17 @@ def test_small_tile_backward_with_lists_equals_the_dense_one_bit_for_bit(N, B, R
         finally:
             ops.cull = True
     assert same_bits(out[True], out[False])
+
+
+def test_fuzz_of_every_list_taking_kernel_against_its_dense_self():
+    """tools/fuzz_cull.py: random shapes (odd sizes included), fields (sigma 0.002…0.1, err 0…400 mrad, tilted
+    receivers, spans 10…100 m) and cotangent scales; forward variants 3, 4, 5, 9, 14–17 and backward variants 2, 3
+    with their lists against themselves without — any differing bit fails.  (300 cases were run once by hand:
+    profiles/r03_e_fuzz_cull.txt; 30 here.)"""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_cull.py"), "30", "11"], capture_output=True, text=True,
+                         timeout=600)
+    assert run.returncode == 0 and "30 cases, 0 differences" in run.stdout, run.stdout[-3000:] + run.stderr[-2000:]
