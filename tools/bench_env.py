@@ -42,7 +42,8 @@ def fb(key):
     _, m, _ = env.step(a)
     m[key].backward()
     a.grad = None
-t_align = timeit(lambda: fb("alignment_loss"))
+timeit(lambda: fb("dist"), n=100, repeats=3)     # the FIRST differentiating loop of a process runs 1.5-2x slow for ~0.5 s
+t_align = timeit(lambda: fb("alignment_loss"))    # (autograd's device thread, allocator pools) whichever metric it uses: untimed
 t_dist = timeit(lambda: fb("dist"))
 if "--ab" in sys.argv:      # A/B, interleaved: helio_env_step_bwd vs the composed backward (step_losses_bwd + render_bwd + add)
     from doodle_amd import field as _field
