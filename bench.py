@@ -660,6 +660,7 @@ def extras_leg(field, suns_d, action, w, dev):
     #   render_fwd_bwd_graph_us     the autograd iteration captured once and replayed as a HIP graph
     ones = torch.ones((w.B, w.N, 3), device=dev)
     t_vg = wall(lambda: field.render_value_and_grad(suns_d, action, G, ones), 300)
+    preheat(fwdbwd, 0.7)        # the first differentiating loop of a process runs 1.5-2x slow for ~0.5 s (tools/bench_env.py)
     t_fb = wall(fwdbwd, 300)
     out = {"render_fwd_bwd_frames_per_s": round(w.B / t_vg, 1), "render_fwd_bwd_us": round(t_vg * 1e6, 1),
            "render_fwd_bwd_autograd_us": round(t_fb * 1e6, 1)}

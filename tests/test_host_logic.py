@@ -365,3 +365,26 @@ def test_env_surface_the_training_loop_uses(monkeypatch):
     env.reset()
     o, l, m = env.step(env.ideal_normals.reshape(B, -1).numpy())
     assert float(l["alignment_loss"]) >= 0.0 and o["img"].shape == (B, R, R)
+
+
+def test_library_switches_change_the_size_rules_they_name():
+    """HELIO_CULL=0 / HELIO_SPLIT=0 are read once by the library (README "Switches"): with them the scratch queries
+    return 0 and the size rule never answers a split-sum variant — host code, checked without a device, each in a
+    process of its own."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); from doodle_amd import native; lib = native.load_library(); "
+            "print(lib.helio_fwd_scratch_bytes(512, 2000, 512, 0), lib.helio_bwd_scratch_bytes(512, 2000, 512, 0), "
+            "lib.helio_render_fwd_choice(32, 5000, 256), lib.helio_fwd_scratch_required(32, 5000, 256, 0), "
+            "lib.helio_fwd_scratch_bytes(2, 5000, 512, 0), lib.helio_bwd_scratch_bytes(16, 5000, 256, 0))" % ROOT)
+
+    def run(**env):
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, **env))
+        assert out.returncode == 0, out.stderr[-2000:]
+        return [int(x) for x in out.stdout.split()]
+
+    fwd, bwd, choice, required, ksplit, bwd_mid = run()
+    assert fwd > 0 and bwd > 0 and choice == 16 and required == 4 * 32 * 8 * 256 * 256 and ksplit > 0 and bwd_mid > 0
+    assert run(HELIO_CULL="0") == [0, 0, 16, required, 0, 0]           # dense everywhere; the split sum keeps its partial images
+    fwd2, bwd2, choice2, required2, _, _ = run(HELIO_SPLIT="0")
+    assert choice2 == 9 and required2 == 0 and fwd2 == fwd and bwd2 == bwd
