@@ -21,7 +21,11 @@
 //     fma(A_i, E_j, acc) == acc.
 //   * backward: a ray is dropped from an image when floor_x > CULL_EXP2 or floor_y > CULL_EXP2 over the WHOLE
 //     image: one factor table is then all +0, both contractions and all five moments of the dense kernels
-//     are exactly +0, and zeros are what the compaction kernel writes for it.
+//     are exactly +0, and zeros are what the compaction kernel writes for it.  Where an image is several c tiles
+//     of the LDS-tile kernels wide (R > 256) the same holds per (pass, c tile): pass 0's moments of a tile of
+//     COLUMNS are Σ_j E_j·w_j·(Σ_i G_ij A_i) over that tile's columns and all rows — exactly +0 when the tile's
+//     E_j are all +0 or the image's A_i are (finite cotangent), so the ray leaves that tile's list when
+//     floor_y(tile) > CULL_EXP2 or floor_x(image) > CULL_EXP2; pass 1 likewise with rows and columns exchanged.
 // A plane-parallel ray (k2 = 0) has exponent 0 everywhere and is always kept: it adds 1.0 to every pixel
 // (:141-148).
 #pragma once
@@ -54,7 +58,9 @@ __device__ __forceinline__ bool cull_dead_strict(const float4 ray, const CullBox
 // forward:  int counts[T] | int order[T] | float4 lists[T][P]          T = B·tiles²·S, tile = TE×TE pixels;
 //           S = 1, P = N normally; with the heliostat sum split across workgroups (splat_fwd.hip, "split"),
 //           S parts of P consecutive rays each and one list per (image, tile, part)
-// backward: int counts[B] | int idx[B][N] | int total (+pad) | int2 map[B·⌈N/256⌉]
+// backward: int counts[T] | int idx[T][N] | int total[sets] (+pad) | int2 map[T·⌈N/256⌉]     T = sets·B·CT lists:
+//           CT = 1: one list per image, shared by the two passes (sets = 1); CT > 1: one list per (pass, image,
+//           c tile) of the LDS-tile kernels (sets = 2), list = (pass·B + b)·CT + tile
 // (every section padded to 256 bytes)
 __host__ __device__ inline long cull_pad256(long bytes) { return (bytes + 255) & ~255l; }
 inline long cull_fwd_bytes(int B, int N, int R, int TE, int S = 1, int P = 0) {
@@ -62,19 +68,29 @@ inline long cull_fwd_bytes(int B, int N, int R, int TE, int S = 1, int P = 0) {
     return 2 * cull_pad256(4 * T) + 16 * T * (S > 1 ? P : N);
 }
 constexpr int CULL_BWD_TILE = 256;           // rays per tile of splat_bwd_mfma
-inline long cull_bwd_bytes(int B, int N) {
-    const long nt = (N + CULL_BWD_TILE - 1) / CULL_BWD_TILE;
-    return cull_pad256(4l * B) + cull_pad256(4l * B * N) + 256 + 8l * B * nt;
+constexpr int CULL_BWD_MAX_CT = 8;           // c tiles per image that get lists of their own (R ≤ 2048)
+inline long cull_bwd_lists(int B, int CT) { return (long)B * CT * (CT > 1 ? 2 : 1); }
+inline long cull_bwd_bytes(int B, int N, int CT = 1) {
+    const long nt = (N + CULL_BWD_TILE - 1) / CULL_BWD_TILE, T = cull_bwd_lists(B, CT);
+    return cull_pad256(4 * T) + cull_pad256(4 * T * N) + 256 + 8 * T * nt;
 }
 
 struct CullFwd { const int* counts; const int* order; const float4* lists; };      // counts == nullptr: dense
-struct CullBwd { const int* counts; const int* idx; const int* total; const int2* map; };
+// ct: lists per image and pass (1 = one per image for both passes); for_pass(): the set a pass walks
+struct CullBwd {
+    const int* counts; const int* idx; const int* total; const int2* map; int ct; long set_lists, set_items; int N;
+    CullBwd for_pass(int pass) const {
+        if (!counts || ct <= 1 || pass == 0) return *this;
+        return CullBwd{counts + set_lists, idx + set_lists * N, total + 1, map + set_items, ct, set_lists, set_items, N};
+    }
+};
 
 // launchers (cull.hip)
 CullFwd launch_cull_fwd(int B, int N, int R, int TE, int S, int P, bool with_order, const float* rays, const float* xs,
                         const float* ys, void* scratch, hipStream_t st);
-CullBwd launch_cull_bwd(int B, int N, int R, int JB, bool with_map, const float* rays, const float* xs, const float* ys,
-                        float* moments, void* scratch, hipStream_t st);
+// TC: width of a c tile in pixels, CT = ⌈R/TC⌉ or 1
+CullBwd launch_cull_bwd(int B, int N, int R, int JB, int TC, int CT, bool with_map, const float* rays, const float* xs,
+                        const float* ys, float* moments, void* scratch, hipStream_t st);
 bool cull_enabled();
 
 }  // namespace helio

@@ -87,18 +87,30 @@ cull_fwd_kernel(int Nall, int R, int TE, int S, int P, const float4* __restrict_
     if (threadIdx.x == 0) counts[list] = base;
 }
 
-// grid (B): the rays of image b with a footprint that is not identically zero on the image, as indices, in order
+// The box a (pass, c tile) list is decided on: the c axis (columns in pass 0, rows in pass 1) restricted to the
+// tile's TC pixels, the contracted axis whole.  CT = 1: the whole image on both axes (one list for both passes).
+template <int THREADS>
+__device__ __forceinline__ CullBox bwd_box(int R, int TC, int CT, int pass, int tile, const float* __restrict__ xs,
+                                           const float* __restrict__ ys, float* sm) {
+    const int c0 = CT > 1 ? tile * TC : 0, c1 = CT > 1 ? min(R, c0 + TC) : R;
+    CullBox bx;
+    block_minmax<THREADS>(xs, pass == 1 ? c0 : 0, pass == 1 ? c1 : R, sm, bx.xlo, bx.xhi);
+    block_minmax<THREADS>(ys, pass == 0 ? c0 : 0, pass == 0 ? c1 : R, sm, bx.ylo, bx.yhi);
+    return bx;
+}
+
+// grid (CT, B, sets): the rays of image b whose moments of this (pass, c tile) are not identically zero, as
+// indices, in order; list = (pass·B + b)·CT + tile
 __global__ void __launch_bounds__(CULL_BWD_THREADS)
-cull_bwd_kernel(int N, int R, const float4* __restrict__ rays, const float* __restrict__ xs,
+cull_bwd_kernel(int N, int R, int TC, int CT, const float4* __restrict__ rays, const float* __restrict__ xs,
                 const float* __restrict__ ys, int* __restrict__ counts, int* __restrict__ idx) {
     __shared__ float sm[3 * CULL_BWD_THREADS / 64];
     __shared__ int sw[CULL_BWD_THREADS / 64];
-    const int b = blockIdx.x;
-    CullBox bx;
-    block_minmax<CULL_BWD_THREADS>(xs, 0, R, sm, bx.xlo, bx.xhi);
-    block_minmax<CULL_BWD_THREADS>(ys, 0, R, sm, bx.ylo, bx.yhi);
+    const int tile = blockIdx.x, b = blockIdx.y, pass = blockIdx.z;
+    const long list = ((long)pass * gridDim.y + b) * CT + tile;
+    const CullBox bx = bwd_box<CULL_BWD_THREADS>(R, TC, CT, pass, tile, xs, ys, sm);
     const float4* __restrict__ rb = rays + (long)b * N;
-    int* __restrict__ out = idx + (long)b * N;
+    int* __restrict__ out = idx + list * N;
     int base = 0;
     for (int n0 = 0; n0 < N; n0 += CULL_BWD_THREADS) {
         const int n = n0 + (int)threadIdx.x;
@@ -108,27 +120,39 @@ cull_bwd_kernel(int N, int R, const float4* __restrict__ rays, const float* __re
         if (live) out[base + at] = n;
         base += total;
     }
-    if (threadIdx.x == 0) counts[b] = base;
+    if (threadIdx.x == 0) counts[list] = base;
 }
 
-// grid (⌈N/256⌉, B): the moments of the rays NOT listed (all column blocks) are zeroed — what the dense kernels
-// compute for them.  The same test on the same numbers as cull_bwd_kernel, one thread per ray: with few images
-// the list's one workgroup per image must not also write N·JB·20 bytes.
+// grid (⌈N/256⌉, B): the moments a ray is NOT listed for are zeroed — what the dense kernels compute for them:
+// pass 0 owns components (0, 2, 4) of the tile's 64-wide column blocks, pass 1 components (1, 3) of its row blocks.
+// The same test on the same numbers as cull_bwd_kernel, one thread per ray: with few images the list's one
+// workgroup must not also write N·JB·20 bytes.
 __global__ void __launch_bounds__(CULL_THREADS)
-cull_bwd_fill_kernel(int N, int R, int JB, const float4* __restrict__ rays, const float* __restrict__ xs,
+cull_bwd_fill_kernel(int N, int R, int JB, int TC, int CT, const float4* __restrict__ rays, const float* __restrict__ xs,
                      const float* __restrict__ ys, float* __restrict__ moments) {
     __shared__ float sm[3 * CULL_THREADS / 64];
     const int b = blockIdx.y;
-    CullBox bx;
-    block_minmax(xs, 0, R, sm, bx.xlo, bx.xhi);
-    block_minmax(ys, 0, R, sm, bx.ylo, bx.yhi);
     const int n = blockIdx.x * CULL_THREADS + (int)threadIdx.x;
-    if (n >= N || !cull_dead_strict(rays[(long)b * N + n], bx)) return;
-    for (int jb = 0; jb < JB; ++jb) {
-        float* o = moments + (((long)b * JB + jb) * N + n) * HELIO_MOMENT_STRIDE;
+    float4 ray = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (n < N) ray = rays[(long)b * N + n];
+    const int per = TC / 64;                               // moment blocks per c tile
+    for (int pass = 0; pass < (CT > 1 ? 2 : 1); ++pass)
+        for (int tile = 0; tile < CT; ++tile) {
+            const CullBox bx = bwd_box<CULL_THREADS>(R, TC, CT, pass, tile, xs, ys, sm);     // (barriers: every thread)
+            if (n >= N || !cull_dead_strict(ray, bx)) continue;
+            const int j0 = CT > 1 ? tile * per : 0, j1 = CT > 1 ? min(JB, j0 + per) : JB;
+            for (int jb = j0; jb < j1; ++jb) {
+                float* o = moments + (((long)b * JB + jb) * N + n) * HELIO_MOMENT_STRIDE;
+                if (CT == 1) {
 #pragma unroll
-        for (int k = 0; k < HELIO_MOMENT_STRIDE; ++k) o[k] = 0.0f;
-    }
+                    for (int k = 0; k < HELIO_MOMENT_STRIDE; ++k) o[k] = 0.0f;
+                } else if (pass == 0) {
+                    o[0] = 0.0f; o[2] = 0.0f; o[4] = 0.0f;
+                } else {
+                    o[1] = 0.0f; o[3] = 0.0f;
+                }
+            }
+        }
 }
 
 // ---- work order (cull.h): one workgroup each -----------------------------------------------------------
@@ -173,20 +197,23 @@ cull_order_fwd_kernel(int T, int N, const int* __restrict__ counts, int* __restr
     for (int i = tid; i < T; i += ORDER_THREADS) order[atomicAdd(&cls[klass(counts[i])], 1)] = i;
 }
 
-// map[] = (image, ray tile) of every tile of the per-image lists that holds a ray, image-major; *total = how many
+// map[] = (list, ray tile) of every tile of the lists that holds a ray, list-major (= image-major); *total = how
+// many.  grid (sets): one workgroup per set of `lists` lists.
 __global__ void __launch_bounds__(ORDER_THREADS)
-cull_map_bwd_kernel(int B, const int* __restrict__ counts, int* __restrict__ total_out, int2* __restrict__ map) {
+cull_map_bwd_kernel(int lists, int nt, const int* __restrict__ counts, int* __restrict__ total_out, int2* __restrict__ map) {
     __shared__ int sw[ORDER_WAVES];
+    counts += (long)blockIdx.x * lists;
+    map += (long)blockIdx.x * lists * nt;
     int running = 0;
-    for (int b0 = 0; b0 < B; b0 += ORDER_THREADS) {
-        const int b = b0 + (int)threadIdx.x;
-        const int t = b < B ? (counts[b] + CULL_BWD_TILE - 1) / CULL_BWD_TILE : 0;
+    for (int l0 = 0; l0 < lists; l0 += ORDER_THREADS) {
+        const int l = l0 + (int)threadIdx.x;
+        const int t = l < lists ? (counts[l] + CULL_BWD_TILE - 1) / CULL_BWD_TILE : 0;
         int total;
         const int start = running + block_scan_incl(t, sw, total) - t;
-        for (int k = 0; k < t; ++k) map[start + k] = make_int2(b, k);
+        for (int k = 0; k < t; ++k) map[start + k] = make_int2(l, k);
         running += total;
     }
-    if (threadIdx.x == 0) *total_out = running;
+    if (threadIdx.x == 0) total_out[blockIdx.x] = running;
 }
 
 // HELIO_CULL=0 switches the stage off (A/B runs): the dense kernels then run whatever scratch is passed
@@ -211,19 +238,22 @@ CullFwd launch_cull_fwd(int B, int N, int R, int TE, int S, int P, bool with_ord
     return CullFwd{counts, order, lists};
 }
 
-CullBwd launch_cull_bwd(int B, int N, int R, int JB, bool with_map, const float* rays, const float* xs, const float* ys,
-                        float* moments, void* scratch, hipStream_t st) {
+CullBwd launch_cull_bwd(int B, int N, int R, int JB, int TC, int CT, bool with_map, const float* rays, const float* xs,
+                        const float* ys, float* moments, void* scratch, hipStream_t st) {
+    const int sets = CT > 1 ? 2 : 1;
+    const long T = cull_bwd_lists(B, CT), nt = (N + CULL_BWD_TILE - 1) / CULL_BWD_TILE;
     char* base = static_cast<char*>(scratch);
     int* counts = reinterpret_cast<int*>(base);
-    int* idx = reinterpret_cast<int*>(base + cull_pad256(4l * B));
-    int* total = reinterpret_cast<int*>(base + cull_pad256(4l * B) + cull_pad256(4l * B * N));
+    int* idx = reinterpret_cast<int*>(base + cull_pad256(4 * T));
+    int* total = reinterpret_cast<int*>(base + cull_pad256(4 * T) + cull_pad256(4 * T * N));
     int2* map = reinterpret_cast<int2*>(reinterpret_cast<char*>(total) + 256);
-    hipLaunchKernelGGL(cull_bwd_kernel, dim3(B), dim3(CULL_BWD_THREADS), 0, st, N, R,
+    hipLaunchKernelGGL(cull_bwd_kernel, dim3(CT, B, sets), dim3(CULL_BWD_THREADS), 0, st, N, R, TC, CT,
                        reinterpret_cast<const float4*>(rays), xs, ys, counts, idx);
     hipLaunchKernelGGL(cull_bwd_fill_kernel, dim3((N + CULL_THREADS - 1) / CULL_THREADS, B), dim3(CULL_THREADS), 0, st, N, R, JB,
-                       reinterpret_cast<const float4*>(rays), xs, ys, moments);
-    if (with_map) hipLaunchKernelGGL(cull_map_bwd_kernel, dim3(1), dim3(ORDER_THREADS), 0, st, B, counts, total, map);
-    return CullBwd{counts, idx, total, map};
+                       TC, CT, reinterpret_cast<const float4*>(rays), xs, ys, moments);
+    if (with_map)
+        hipLaunchKernelGGL(cull_map_bwd_kernel, dim3(sets), dim3(ORDER_THREADS), 0, st, (int)(T / sets), (int)nt, counts, total, map);
+    return CullBwd{counts, idx, total, map, CT, T / sets, T / sets * nt, N};
 }
 
 }  // namespace helio

@@ -162,7 +162,7 @@ __global__ void __launch_bounds__(256 * WC)
 splat_bwd_mfma(int B, int N, int R, const float* __restrict__ rays, const float* __restrict__ xs,
                const float* __restrict__ ys, const float* __restrict__ gimg, float* __restrict__ moments,
                const int* __restrict__ live_counts, const int* __restrict__ live_idx, const int* __restrict__ live_total,
-               const int2* __restrict__ live_map) {
+               const int2* __restrict__ live_map, int live_ct) {
     static_assert(!(VEC && PASS == 1), "16-byte staging is pass 0's");
     // Row pitch of the two LDS tables.  Pass 1 writes the slab transposed (lanes ↔ k at stride LD):
     // an odd pitch keeps that conflict-free.  Pass 0 writes it along c and stages it 16 bytes at a time
@@ -182,23 +182,26 @@ splat_bwd_mfma(int B, int N, int R, const float* __restrict__ rays, const float*
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // scalar: nothing of it is kept in (or spilled from) VGPRs
     const int lr = lane & 31, lh = lane >> 5;
-    // (cull.h) with a list of the image's rays whose footprint is not identically zero, the ray axis of the
-    // tiles runs over the list: L entries, entry p is ray live_idx[b·N + p] (the moments of the rays not
-    // listed were zeroed with the list).  A ray's moments involve no other ray, so which tile computes them
-    // changes nothing.  The workgroup's (image, ray tile) then comes from the table of non-empty tiles, in id
-    // order, and the ids past the table leave at once — all at the end of the grid (cull.h, "work order").
-    int b = blockIdx.y, bx = blockIdx.x;
+    // (cull.h) with lists of the rays whose moments are not identically zero, the ray axis of the tiles runs over
+    // a list: L entries, entry p is ray lidx[p] (the moments of the rays not listed were zeroed with the list).
+    // A ray's moments involve no other ray, so which tile computes them changes nothing.  One list per image
+    // serving all its c tiles (live_ct = 1), or one per (image, c tile) of THIS pass (live_ct = c_tiles).  The
+    // workgroup's (list, ray tile) comes from the table of non-empty tiles, in id order, and the ids past the
+    // table leave at once — all at the end of the grid (cull.h, "work order").
+    int b = blockIdx.y, bx = blockIdx.x, lst = 0;
     if (live_counts) {
         const unsigned w = blockIdx.x + gridDim.x * blockIdx.y;
-        const unsigned item = w / (unsigned)c_tiles;
+        const unsigned per = live_ct > 1 ? 1u : (unsigned)c_tiles;
+        const unsigned item = w / per;
         if (item >= (unsigned)*live_total) return;
         const int2 e = live_map[item];
-        b = e.x;
-        bx = e.y * c_tiles + (int)(w % (unsigned)c_tiles);
+        lst = e.x;
+        b = live_ct > 1 ? e.x / c_tiles : e.x;
+        bx = e.y * c_tiles + (live_ct > 1 ? e.x % c_tiles : (int)(w % per));
     }
     const int c0 = (bx % c_tiles) * TC, n0 = (bx / c_tiles) * T;
-    const int L = live_counts ? live_counts[b] : N;
-    const int* __restrict__ lidx = live_counts ? live_idx + (long)b * N : nullptr;
+    const int L = live_counts ? live_counts[lst] : N;
+    const int* __restrict__ lidx = live_counts ? live_idx + (long)lst * N : nullptr;
     const int wc = (wave >> 2) * 64, wn = (wave & 3) * 64;
     const float* __restrict__ ccoord = PASS == 0 ? ys : xs;   // coordinates along c
     const float* __restrict__ kcoord = PASS == 0 ? xs : ys;   // coordinates along k
@@ -774,8 +777,9 @@ static void launch_bwd_mfma_v(int B, int N, int R, const float* rays, const floa
         configured = true;
     }
     const int ct = (R + TC - 1) / TC, nt = (N + 255) / 256;
+    const CullBwd c = cull.for_pass(PASS);
     hipLaunchKernelGGL((splat_bwd_mfma<PASS, VEC, WC>), dim3(ct * nt, B), dim3(256 * WC), lds, st, B, N, R, rays, xs, ys, gimg, moments,
-                       cull.counts, cull.idx, cull.total, cull.map);
+                       c.counts, c.idx, c.total, c.map, c.ct);
 }
 
 template <int PASS>
@@ -1277,8 +1281,15 @@ static bool cull_bwd_wanted(int variant, int B, int N, int R) {
     return N >= 1024 && 2l * B * ((R + 63) / 64) * ray_tiles > 512;
 }
 
+// lists per image and pass: the LDS-tile kernels' c tiles where an image is 2..8 of them wide (cull.h), else 1
+static int cull_bwd_ct(int variant, int B, int N, int R) {
+    if (variant == 0) variant = splat_bwd_choice(B, N, R);
+    const int c_tiles = (R + 255) / 256;
+    return variant == 2 && R > 128 && c_tiles > 1 && c_tiles <= CULL_BWD_MAX_CT ? c_tiles : 1;
+}
+
 long splat_bwd_scratch_bytes(int B, int N, int R, int variant) {
-    return cull_bwd_wanted(variant, B, N, R) ? cull_bwd_bytes(B, N) : 0;
+    return cull_bwd_wanted(variant, B, N, R) ? cull_bwd_bytes(B, N, cull_bwd_ct(variant, B, N, R)) : 0;
 }
 
 int launch_splat_bwd(int B, int N, int R, const float* rays, const float* xs, const float* ys,
@@ -1299,9 +1310,9 @@ int launch_splat_bwd(int B, int N, int R, const float* rays, const float* xs, co
         const int ct = (R + 63) / 64, nt = (N + 31) / 32;
         const int nrb = variant == 3 ? bwd_small_nrb(B, N, R) : 1;
         static const int ks_exp = [] { const char* e = getenv("HELIO_BWD_KSX"); return e ? atoi(e) : 0; }();     // tuning runs
-        CullBwd cull{nullptr, nullptr, nullptr, nullptr};
+        CullBwd cull{};
         if (scratch && cull_bwd_possible(variant, B, N, R) && scratch_bytes >= cull_bwd_bytes(B, N))
-            cull = launch_cull_bwd(B, N, R, splat_bwd_blocks(R), /*with_map=*/false, rays, xs, ys, moments, scratch, st);
+            cull = launch_cull_bwd(B, N, R, splat_bwd_blocks(R), R, 1, /*with_map=*/false, rays, xs, ys, moments, scratch, st);
         // tools/sweep_bwd_nrb.py: from N = 600 — with workgroups enough — no split of the contracted axis at all
         // (4 independent waves of 64 rays each: one epilogue per 2·R MFMAs): B = 25: N = 1000, R = 128: 37 → 30 µs,
         // R = 256: 112 → 98 µs; B = 256, N = 1000, R = 64: 96 → 62 µs; at N = 300 it is 1.5× slower.  (Held to 128
@@ -1327,9 +1338,16 @@ int launch_splat_bwd(int B, int N, int R, const float* rays, const float* xs, co
         return HELIO_OK;
     }
     if (variant == 2) {
-        CullBwd cull{nullptr, nullptr, nullptr, nullptr};
-        if (scratch && cull_bwd_possible(2, B, N, R) && scratch_bytes >= cull_bwd_bytes(B, N))
-            cull = launch_cull_bwd(B, N, R, splat_bwd_blocks(R), /*with_map=*/true, rays, xs, ys, moments, scratch, st);
+        CullBwd cull{};
+        if (scratch && cull_bwd_possible(2, B, N, R)) {
+            // a list per (pass, c tile) where the image is several tiles wide and the scratch holds them, else one
+            // per image (what a caller sized by an older query hands over) — the moments are the same bits
+            int ct = cull_bwd_ct(2, B, N, R);
+            if (scratch_bytes < cull_bwd_bytes(B, N, ct)) ct = 1;
+            if (scratch_bytes >= cull_bwd_bytes(B, N, ct))
+                cull = launch_cull_bwd(B, N, R, splat_bwd_blocks(R), R <= 128 ? 128 : 256, ct, /*with_map=*/true, rays, xs, ys,
+                                       moments, scratch, st);
+        }
         launch_bwd_mfma<0>(B, N, R, rays, xs, ys, gimg, moments, st, cull);
         launch_bwd_mfma<1>(B, N, R, rays, xs, ys, gimg, moments, st, cull);
         return HELIO_OK;

@@ -42,19 +42,33 @@ def field_and_rays(N, B, R, sigma, err, seed=0, normal=(0.0, 1.0, 0.0), span=10.
     return f, suns.to(DEV), act, rays
 
 
-def splat_bwd_with_list(rays, xs, ys, G, variant):
-    """helio_splat_bwd handed enough scratch for the per-image list whatever the size rule says → (moments, counts)."""
+def bwd_lists_per_image(R, variant):
+    """Lists per image and pass (csrc/cull.h): the LDS-tile kernels get one per 256-wide c tile where an image is
+    2..8 of them wide, one per image otherwise."""
+    ct = -(-R // 256)
+    return ct if variant == 2 and R > 128 and 2 <= ct <= 8 else 1
+
+
+def bwd_scratch_need(B, N, R, variant, per_image=False):
+    pad = lambda n: (n + 255) // 256 * 256      # noqa: E731  counts | idx | total | map (csrc/cull.h)
+    ct = 1 if per_image else bwd_lists_per_image(R, variant)
+    T = B * ct * (2 if ct > 1 else 1)
+    return pad(4 * T) + pad(4 * T * N) + 256 + 8 * T * ((N + 255) // 256), T
+
+
+def splat_bwd_with_list(rays, xs, ys, G, variant, per_image=False):
+    """helio_splat_bwd handed enough scratch for its lists whatever the size rule says → (moments, counts, bytes);
+    per_image: only enough for one list per image (the LDS-tile kernels then fall back to those)."""
     from doodle_amd import native
     ops = native.get_ops()
     B, N, R = rays.shape[0], rays.shape[1], xs.shape[0]
-    pad = lambda n: (n + 255) // 256 * 256      # noqa: E731  counts | idx | total | map (csrc/cull.h)
-    need = pad(4 * B) + pad(4 * B * N) + 256 + 8 * B * ((N + 255) // 256)
+    need, T = bwd_scratch_need(B, N, R, variant, per_image)
     scratch = torch.full((need,), 0x7F, dtype=torch.uint8, device=rays.device)
     moments = torch.full((B, ops.lib.helio_splat_bwd_blocks(R), N, 5), float("nan"), device=rays.device)
     rc = ops.lib.helio_splat_bwd(B, N, R, rays.data_ptr(), xs.data_ptr(), ys.data_ptr(), G.data_ptr(), moments.data_ptr(), variant,
                                  scratch.data_ptr(), need, native._stream())
     assert rc == 0, ops.lib.helio_last_error_string()
-    return moments, scratch[:4 * B].view(torch.int32).clone(), need
+    return moments, scratch[:4 * T].view(torch.int32).clone(), need
 
 
 def splat_with_counts(rays, xs, ys, variant):
@@ -148,13 +162,13 @@ def test_rays_on_the_threshold_of_the_criterion(N, B, R, seed):
     G = torch.randn(B, R, R, device=DEV, generator=torch.Generator(device=DEV).manual_seed(seed)) * 1e6
     dense_m = ops.splat_bwd(rays, xs, ys, G, variant=2, cull=False)
     culled_m, bcounts, _ = splat_bwd_with_list(rays, xs, ys, G, 2)
-    assert N <= 256 or 0 < int(bcounts.sum()) < B * N       # (up to 256 rays: one ray tile per image, no list)
+    assert N <= 256 or 0 < int(bcounts.sum()) < bcounts.numel() * N       # (up to 256 rays: one ray tile per image, no list)
     assert torch.equal(torch.isnan(dense_m), torch.isnan(culled_m)) and torch.isnan(dense_m).any()
     ok = ~torch.isnan(dense_m)
     assert torch.equal(bits(culled_m)[ok], bits(dense_m)[ok])
 
 
-@pytest.mark.parametrize("N,B,R", [(257, 3, 260), (700, 2, 512), (1000, 2, 128), (300, 4, 200)])
+@pytest.mark.parametrize("N,B,R", [(257, 3, 260), (700, 2, 512), (1000, 2, 128), (300, 4, 200), (520, 2, 600)])
 @pytest.mark.parametrize("sigma,err", [(0.01, 90.0), (0.01, 180.0), (0.1, 90.0)])
 def test_culled_backward_moments_equal_the_dense_ones_bit_for_bit(N, B, R, sigma, err):
     from doodle_amd import native
@@ -168,13 +182,17 @@ def test_culled_backward_moments_equal_the_dense_ones_bit_for_bit(N, B, R, sigma
     assert ops.lib.helio_bwd_scratch_bytes(B, N, R, 2) in (0, need) and ops.lib.helio_bwd_scratch_bytes(512, 2000, 512, 2) > 0
     assert same_bits(culled, dense), (culled - dense).abs().max().item()
     assert int(counts.min()) >= 0 and int(counts.max()) <= N
+    if bwd_lists_per_image(R, 2) > 1:                    # scratch for one list per image only: those are walked, same bits
+        fallback, counts1, need1 = splat_bwd_with_list(rays, f._xs, f._ys, G, 2, per_image=True)
+        assert need1 < need and counts1.numel() == B and same_bits(fallback, dense)
+        assert int(counts.view(2, B, -1).max(dim=2).values.max()) <= int(counts1.max())      # a tile's list ⊆ its image's
     if sigma == 0.01:                                    # some rays ARE dropped: their moments read exactly +0
-        assert int(counts.sum()) < B * N
+        assert int(counts.sum()) < counts.numel() * N
         dead = (culled.abs().sum(dim=(1, 3)) == 0)
         assert dead.any()
         assert not (bits(culled)[dead[:, None, :, None].expand_as(culled)] != 0).any()
     else:
-        assert int(counts.sum()) == B * N
+        assert int(counts.sum()) == counts.numel() * N
     for variant in (1, 3, 4, 5, 6, 7):
         assert ops.lib.helio_bwd_scratch_bytes(B, N, R, variant) == 0
 

@@ -38,6 +38,8 @@ if nb:
     s = torch.zeros(nb, dtype=torch.uint8, device=dev)
     assert lib.helio_splat_bwd(B, N, R, rays.data_ptr(), f._xs.data_ptr(), f._ys.data_ptr(), G.data_ptr(), mom.data_ptr(), 2,
                                s.data_ptr(), nb, native._stream()) == 0
-    c = s[:4 * B].view(torch.int32).float()
-    print(f"backward, per image: live fraction {c.mean().item() / N:.3f} (min {int(c.min())}, max {int(c.max())} of {N}); "
+    ct = -(-R // 256)
+    T = B * ct * 2 if 2 <= ct <= 8 else B             # one list per (pass, image, c tile) where an image is 2..8 tiles wide
+    c = s[:4 * T].view(torch.int32).float()
+    print(f"backward, {T // B} list(s) per image: live fraction {c.mean().item() / N:.3f} (min {int(c.min())}, max {int(c.max())} of {N}); "
           f"in 256-ray tiles {(torch.ceil(c / 256)).mean().item() / (-(-N // 256)):.3f}")
