@@ -87,19 +87,25 @@ def make_action(field, suns, noise):
     return a.reshape(a.shape[0], -1).contiguous()
 
 
-def time_kernel(fn, iters, warm=3):
+def time_kernel(fn, iters, warm=3, repeats=1):
     """Average duration (s) of ``fn`` — one kernel launch — over ``iters`` back-to-back
-    launches, bracketed by HIP events on the current (launch) stream."""
+    launches, bracketed by HIP events on the current (launch) stream.  ``repeats`` > 1 (the size
+    sweeps under tools/, never a figure of the bench line): the least of that many such loops — a
+    shared box now and then stalls one loop for tens of milliseconds (tools/sweep_render.py)."""
     for _ in range(warm):
         fn()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
-    e0.record()
-    for _ in range(iters):
-        fn()
-    e1.record()
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1) * 1e-3 / iters
+    best = None
+    for _ in range(repeats):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        t = e0.elapsed_time(e1) * 1e-3 / iters
+        best = t if best is None else min(best, t)
+    return best
 
 
 def time_interleaved(fns, iters, warm=2):

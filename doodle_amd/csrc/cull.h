@@ -48,7 +48,8 @@ __device__ __forceinline__ bool cull_dead_strict(const float4 ray, const CullBox
 // unequal work the dispatcher waits on the busiest XCD and the others idle (measured: a compacted backward
 // whose empty tiles were interleaved with the full ones took as long as the dense one).  So the kernels do
 // not take their tile from blockIdx directly but from a small table made with the lists:
-//   forward  — order[w]: the (image, tile) lists sorted by length, longest first (neighbouring ids: nearly
+//   forward  — order[w] (made when there are more lists than the chip has CUs — below that every workgroup starts
+//              at once and the table's launch is only latency): the (image, tile) lists sorted by length, longest first (neighbouring ids: nearly
 //              equal work; long ones early: a short tail);
 //   backward — map[w]: the (image, 256-ray tile) items that are not empty, image-major (equal work each), and
 //              their number; ids past it leave at once, all at the END of the grid.

@@ -235,7 +235,7 @@ CullFwd launch_cull_fwd(int B, int N, int R, int TE, int S, int P, bool with_ord
                        reinterpret_cast<const float4*>(rays), xs, ys, counts, lists);
     if (with_order)
         hipLaunchKernelGGL(cull_order_fwd_kernel, dim3(1), dim3(ORDER_THREADS), 0, st, (int)T, P, counts, order);
-    return CullFwd{counts, order, lists};
+    return CullFwd{counts, with_order ? order : nullptr, lists};
 }
 
 CullBwd launch_cull_bwd(int B, int N, int R, int JB, int TC, int CT, bool with_map, const float* rays, const float* xs,

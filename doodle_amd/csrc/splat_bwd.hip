@@ -400,15 +400,16 @@ splat_bwd_mfma(int B, int N, int R, const float* __restrict__ rays, const float*
 // per k-pair): NRB = 1 where latency is everything, 2 or 4 where there are ray blocks enough to keep the
 // chip's workgroup slots full anyway — then the slab is fetched from L2 half / a quarter as often.
 // → m[rb][0..2] for the ray n0 + 32·rb + (lane & 31).
-template <int PASS, int NRB>
+// LISTS (cull.h): the ray axis runs over the image's list of rays whose footprint is not identically zero — position
+// p < L is ray lidx[p] — and nn[rb] returns the ray this lane's results belong to (-1: none).  A template
+// parameter, not a null pointer: with the choice made at run time the DENSE kernel lost 20–26 % where one wave's
+// latency is the whole time (B = 4, N = 1000, R = 512: 68 → 87 µs; the ray request behind a select).
+template <int PASS, int NRB, bool LISTS = false>
 __device__ __forceinline__ void small_wave_partial_n(int N, int R, const float* __restrict__ rays_b,
                                                      const float* __restrict__ xs, const float* __restrict__ ys,
                                                      const float* __restrict__ G, int c0, int n0, int k_begin, int k_end,
                                                      float* __restrict__ sCc_wave, float (&m)[NRB][3],
-                                                     const int* __restrict__ lidx = nullptr, int L = -1, int* nn = nullptr) {
-    // (cull.h) with `lidx`: the ray axis runs over the image's list of rays whose footprint is not identically zero —
-    // position p < L is ray lidx[p] — and nn[rb] returns the ray this lane's results belong to (-1: none)
-    if (L < 0) L = N;
+                                                     const int* __restrict__ lidx = nullptr, int L = 0, int* nn = nullptr) {
     const int lane = threadIdx.x & 63;
     const int lr = lane & 31, lh = lane >> 5;
     const float* __restrict__ ccoord = PASS == 0 ? ys : xs;   // coordinates along c (the axis that survives)
@@ -417,14 +418,17 @@ __device__ __forceinline__ void small_wave_partial_n(int N, int R, const float* 
     // first group of grad-image loads has been issued — every first touch of memory in a freshly launched
     // kernel costs ≈900 cycles, so none of them may wait for another
     float4 qraw[NRB];
-    int nray[NRB];
+    const int lim = LISTS ? L : N;                            // positions from here on are padding: they contribute nothing
 #pragma unroll
     for (int rb = 0; rb < NRB; ++rb) {
-        const int p = n0 + 32 * rb + lr;
-        nray[rb] = lidx ? lidx[min(p, max(L - 1, 0))] : min(p, N - 1);
-        qraw[rb] = reinterpret_cast<const float4*>(rays_b)[nray[rb]];
-        if (p >= L) nray[rb] = -1;
-        if (nn) nn[rb] = nray[rb];
+        if constexpr (LISTS) {
+            const int p = n0 + 32 * rb + lr;
+            const int n = lidx[min(p, max(L - 1, 0))];
+            qraw[rb] = reinterpret_cast<const float4*>(rays_b)[n];
+            nn[rb] = p >= L ? -1 : n;
+        } else {
+            qraw[rb] = reinterpret_cast<const float4*>(rays_b)[min(n0 + 32 * rb + lr, N - 1)];
+        }
     }
     const float ccv = ccoord[min(c0 + lane, R - 1)];
 
@@ -493,7 +497,7 @@ __device__ __forceinline__ void small_wave_partial_n(int N, int R, const float* 
         for (int rb = 0; rb < NRB; ++rb) {
             float4 q = qraw[rb];
             asm volatile("" : "+v"(q.x), "+v"(q.y), "+v"(q.z), "+v"(q.w));
-            if (nray[rb] < 0) q = make_float4(0.f, 0.f, 1.f, 1e30f);      // padding ray: factor = exp2(-1e30) = 0
+            if (n0 + 32 * rb + lr >= lim) q = make_float4(0.f, 0.f, 1.f, 1e30f);      // padding ray: factor = exp2(-1e30) = 0
             const float sk = __builtin_sqrtf(q.z);
             const float fshift = (PASS == 0 ? q.x : q.y) * sk;
             const float fcc = PASS == 0 ? q.w * q.z : 0.0f;
@@ -528,7 +532,7 @@ __device__ __forceinline__ void small_wave_partial_n(int N, int R, const float* 
     for (int rb = 0; rb < NRB; ++rb) {
         const float hshift = PASS == 0 ? qraw[rb].y : qraw[rb].x;
         const float hcc = PASS == 0 ? 0.0f : qraw[rb].w;
-        const float hk = nray[rb] >= 0 ? qraw[rb].z : 0.0f;
+        const float hk = n0 + 32 * rb + lr < lim ? qraw[rb].z : 0.0f;
         float m0 = 0.f, m1 = 0.f, m2 = 0.f;
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk)
@@ -561,7 +565,7 @@ __device__ __forceinline__ void small_wave_partial(int N, int R, const float* __
 // (no split, no LDS reduce: RBW independent waves) is the throughput end: every wave pays the epilogue — 32
 // exps and ≈400 vector instructions per ray block, PMC: more SIMD time than its MFMAs at KS = 4 — once per
 // R MFMAs instead of once per R / 4.
-template <int PASS, int KS, int NRB, int RBW>
+template <int PASS, int KS, int NRB, int RBW, bool LISTS>
 __device__ __forceinline__ void splat_bwd_small_body(int N, int R, const float* __restrict__ rays,
                                                      const float* __restrict__ xs, const float* __restrict__ ys,
                                                      const float* __restrict__ gimg, float* __restrict__ moments,
@@ -580,9 +584,10 @@ __device__ __forceinline__ void splat_bwd_small_body(int N, int R, const float* 
     const int c0 = (blockIdx.x % JB) * 64, n0 = ((blockIdx.x / JB) * RBW + grp) * RPG;
     const float* __restrict__ G = gimg + (long)b * R * R;
     // (cull.h) per-image list of the rays that are not identically zero: workgroups past its end leave at once
-    const int L = live_counts ? live_counts[b] : N;
-    const int* __restrict__ lidx = live_counts ? live_idx + (long)b * N : nullptr;
-    if ((int)(blockIdx.x / JB) * RBW * RPG >= L) return;
+    const int L = LISTS ? live_counts[b] : N;
+    const int* __restrict__ lidx = LISTS ? live_idx + (long)b * N : nullptr;
+    if constexpr (LISTS)
+        if ((int)(blockIdx.x / JB) * RBW * RPG >= L) return;
 
     // this wave's part of the contracted axis: k-pairs dealt evenly, in multiples of 2 (so that a wave
     // starts at a multiple of 4: 16-byte row segments in pass 1)
@@ -592,12 +597,14 @@ __device__ __forceinline__ void splat_bwd_small_body(int N, int R, const float* 
 
     float m[NRB][3];
     int nn[NRB];
-    small_wave_partial_n<PASS, NRB>(N, R, rays + 4l * b * N, xs, ys, G, c0, n0, k_begin, k_end, sCc + wave * 64, m, lidx, L, nn);
+    small_wave_partial_n<PASS, NRB, LISTS>(N, R, rays + 4l * b * N, xs, ys, G, c0, n0, k_begin, k_end, sCc + wave * 64, m, lidx, L, nn);
     if constexpr (KS == 1) {
         if (lh == 0) {
 #pragma unroll
             for (int rb = 0; rb < NRB; ++rb) {
-                const int n = nn[rb];
+                int n = n0 + 32 * rb + lr;
+                if constexpr (LISTS) n = nn[rb];
+                else if (n >= N) n = -1;
                 if (n >= 0) {
                     float* o = moments + (((long)b * JB + c0 / 64) * N + n) * HELIO_MOMENT_STRIDE;
                     if (PASS == 0) { o[0] = m[rb][0]; o[2] = m[rb][1]; o[4] = m[rb][2]; }
@@ -618,7 +625,7 @@ __device__ __forceinline__ void splat_bwd_small_body(int N, int R, const float* 
     if (tid < RBW * RPG) {                                          // fixed order over the KS k-parts
         const int g = tid / RPG, rl = tid % RPG;
         const int p = ((blockIdx.x / JB) * RBW + g) * RPG + rl;
-        const int n = p < L ? (lidx ? lidx[p] : p) : N;
+        const int n = p < L ? (LISTS ? lidx[p] : p) : N;
         if (n < N) {
             float t0 = 0.f, t1 = 0.f, t2 = 0.f;
 #pragma unroll
@@ -633,14 +640,14 @@ __device__ __forceinline__ void splat_bwd_small_body(int N, int R, const float* 
     }
 }
 
-template <int KS, int NRB = 1, int RBW = 1>
+template <int KS, int NRB = 1, int RBW = 1, bool LISTS = false>
 __global__ void __launch_bounds__(64 * KS * RBW)
 splat_bwd_mfma_small(int N, int R, const float* __restrict__ rays, const float* __restrict__ xs,
                      const float* __restrict__ ys, const float* __restrict__ gimg, float* __restrict__ moments,
                      const int* __restrict__ live_counts, const int* __restrict__ live_idx) {
     __shared__ float smem[KS * RBW * 64 + KS * RBW * 32 * NRB * 3];
-    if (blockIdx.z == 0) splat_bwd_small_body<0, KS, NRB, RBW>(N, R, rays, xs, ys, gimg, moments, smem, live_counts, live_idx);
-    else splat_bwd_small_body<1, KS, NRB, RBW>(N, R, rays, xs, ys, gimg, moments, smem, live_counts, live_idx);
+    if (blockIdx.z == 0) splat_bwd_small_body<0, KS, NRB, RBW, LISTS>(N, R, rays, xs, ys, gimg, moments, smem, live_counts, live_idx);
+    else splat_bwd_small_body<1, KS, NRB, RBW, LISTS>(N, R, rays, xs, ys, gimg, moments, smem, live_counts, live_idx);
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -1319,8 +1326,10 @@ int launch_splat_bwd(int B, int N, int R, const float* rays, const float* xs, co
         // registers — four waves per SIMD instead of two — it is no faster: 35.6 µs; the two passes alone take
         // 16.5 and 21.0 µs of the 31 µs they take together.)
         const bool whole_k = variant == 3 && small_whole_k(B, N, R);
-        if (whole_k || (variant == 3 && ks_exp == 1 && nrb == 2))
-            hipLaunchKernelGGL((splat_bwd_mfma_small<1, 2, 4>), dim3(ct * ((N + 255) / 256), B, 2), dim3(256), 0, st, N, R, rays, xs, ys, gimg, moments, cull.counts, cull.idx);
+        if (whole_k && cull.counts)
+            hipLaunchKernelGGL((splat_bwd_mfma_small<1, 2, 4, true>), dim3(ct * ((N + 255) / 256), B, 2), dim3(256), 0, st, N, R, rays, xs, ys, gimg, moments, cull.counts, cull.idx);
+        else if (whole_k || (variant == 3 && ks_exp == 1 && nrb == 2))
+            hipLaunchKernelGGL((splat_bwd_mfma_small<1, 2, 4>), dim3(ct * ((N + 255) / 256), B, 2), dim3(256), 0, st, N, R, rays, xs, ys, gimg, moments, nullptr, nullptr);
         else if (variant == 3 && ks_exp == 1 && nrb == 1)
             hipLaunchKernelGGL((splat_bwd_mfma_small<1, 1, 4>), dim3(ct * ((N + 127) / 128), B, 2), dim3(256), 0, st, N, R, rays, xs, ys, gimg, moments, nullptr, nullptr);
         else if (variant == 3 && ks_exp == 2 && nrb == 1)

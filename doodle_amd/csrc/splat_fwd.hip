@@ -223,7 +223,8 @@ splat_fwd_mfma_regs(int B, int Nall, int R, const float* __restrict__ rays, cons
     int b = blockIdx.y, tile = blockIdx.x;
     long list = 0;
     if (live_counts) {
-        list = live_order[blockIdx.x + gridDim.x * blockIdx.y];
+        list = blockIdx.x + gridDim.x * blockIdx.y;
+        if (live_order) list = live_order[list];             // (no table where every workgroup starts at once)
         b = (int)(list / gridDim.x);
         tile = (int)(list % gridDim.x);
     }
@@ -485,7 +486,8 @@ splat_fwd_mfma_tile(int B, int Nall, int R, const float* __restrict__ rays, cons
     int b = blockIdx.y, tile = blockIdx.x;
     long list = 0;
     if (live_counts) {
-        list = live_order[blockIdx.x + gridDim.x * blockIdx.y];
+        list = blockIdx.x + gridDim.x * blockIdx.y;
+        if (live_order) list = live_order[list];             // (no table where every workgroup starts at once)
         b = (int)(list / gridDim.x);
         tile = (int)(list % gridDim.x);
     }
@@ -1548,8 +1550,11 @@ static CullPlan cull_fwd_plan(int variant, int B, int N, int R) {
     if (variant == 0 || variant == 2) variant = splat_fwd_choice(B, N, R);
     if (!cull_enabled() || N < 192) return {0, 1, 0, false};
     const int S = split_parts(variant);
-    if (variant == 5 || S > 1) return {256, S, split_part_rays(N, S), true};
-    if (variant == 3 || variant == 4) return {128, 1, 0, true};
+    // the work order (cull.h) matters once there are more lists than workgroups the chip starts at once; below
+    // that its launch is only latency
+    const long t256 = (long)B * ((R + 255) / 256) * ((R + 255) / 256) * S, t128 = (long)B * ((R + 127) / 128) * ((R + 127) / 128);
+    if (variant == 5 || S > 1) return {256, S, split_part_rays(N, S), t256 > 256};
+    if (variant == 3 || variant == 4) return {128, 1, 0, t128 > 256};
     // (tools/sweep_split.py at err 90 / sigma 0.01, k-split with and without lists: B=4, N=5000, R=512: 130 → 86 µs; B=2:
     // 69 → 46; B=8, N=2000, R=512: 102 → 70; nothing at N = 1000; with every ray live the extra launch costs ≈5 µs)
     if (variant == 9 && N >= 1024 && (long)B * N * R * R >= (1l << 31))
