@@ -1284,8 +1284,12 @@ static bool cull_bwd_wanted(int variant, int B, int N, int R) {
     if (!cull_bwd_possible(variant, B, N, R)) return false;
     const long ray_tiles = (N + 255) / 256;
     if (variant == 2) return (long)B * ((R + (R <= 128 ? 127 : 255)) / (R <= 128 ? 128 : 256)) * ray_tiles > 256;   // 1 tile per CU
-    // (both passes in one launch; two 4-wave workgroups fit a CU)
-    return N >= 1024 && 2l * B * ((R + 63) / 64) * ray_tiles > 512;
+    // (both passes in one launch; two 4-wave workgroups fit a CU; and enough footprint work for the ≈15 µs of the
+    // launches in front to be small beside it — grid A/B at err 90 / σs 0.01: B = 32, N = 5000, R = 64, 45 µs dense:
+    // 54 µs with lists; B = 4, N = 5000, R = 256, 85 µs: 72 µs; B = 256, N = 5000, R = 64, 325 µs: 271 µs)
+    // (tried: the listed rays' parameters compacted beside the indices, so that a workgroup's first load does not wait
+    // for another — no difference anywhere on the grid; the cost of a list with every ray live is its three launches)
+    return N >= 1024 && 2l * B * ((R + 63) / 64) * ray_tiles > 512 && (long)B * N * R * R >= (1l << 30);
 }
 
 // lists per image and pass: the LDS-tile kernels' c tiles where an image is 2..8 of them wide (cull.h), else 1
