@@ -126,7 +126,9 @@ cull_bwd_kernel(int N, int R, int TC, int CT, const float4* __restrict__ rays, c
 // grid (⌈N/256⌉, B): the moments a ray is NOT listed for are zeroed — what the dense kernels compute for them:
 // pass 0 owns components (0, 2, 4) of the tile's 64-wide column blocks, pass 1 components (1, 3) of its row blocks.
 // The same test on the same numbers as cull_bwd_kernel, one thread per ray: with few images the list's one
-// workgroup must not also write N·JB·20 bytes.
+// workgroup must not also write N·JB·20 bytes.  Block jb is a column block of pass 0's tile jb/per and a row block
+// of pass 1's: both verdicts first, then one visit per block (a ray that misses the receiver altogether — most of the
+// dead ones — gets its 20-byte records written whole).
 __global__ void __launch_bounds__(CULL_THREADS)
 cull_bwd_fill_kernel(int N, int R, int JB, int TC, int CT, const float4* __restrict__ rays, const float* __restrict__ xs,
                      const float* __restrict__ ys, float* __restrict__ moments) {
@@ -135,24 +137,24 @@ cull_bwd_fill_kernel(int N, int R, int JB, int TC, int CT, const float4* __restr
     const int n = blockIdx.x * CULL_THREADS + (int)threadIdx.x;
     float4 ray = make_float4(0.f, 0.f, 0.f, 0.f);
     if (n < N) ray = rays[(long)b * N + n];
-    const int per = TC / 64;                               // moment blocks per c tile
-    for (int pass = 0; pass < (CT > 1 ? 2 : 1); ++pass)
-        for (int tile = 0; tile < CT; ++tile) {
-            const CullBox bx = bwd_box<CULL_THREADS>(R, TC, CT, pass, tile, xs, ys, sm);     // (barriers: every thread)
-            if (n >= N || !cull_dead_strict(ray, bx)) continue;
-            const int j0 = CT > 1 ? tile * per : 0, j1 = CT > 1 ? min(JB, j0 + per) : JB;
-            for (int jb = j0; jb < j1; ++jb) {
-                float* o = moments + (((long)b * JB + jb) * N + n) * HELIO_MOMENT_STRIDE;
-                if (CT == 1) {
-#pragma unroll
-                    for (int k = 0; k < HELIO_MOMENT_STRIDE; ++k) o[k] = 0.0f;
-                } else if (pass == 0) {
-                    o[0] = 0.0f; o[2] = 0.0f; o[4] = 0.0f;
-                } else {
-                    o[1] = 0.0f; o[3] = 0.0f;
-                }
-            }
+    unsigned dead0 = 0, dead1 = 0;                          // bit t: dead on tile t of pass 0 / 1 (CT <= 8)
+    for (int tile = 0; tile < CT; ++tile) {
+        const CullBox b0 = bwd_box<CULL_THREADS>(R, TC, CT, 0, tile, xs, ys, sm);       // (barriers: every thread)
+        dead0 |= (unsigned)cull_dead_strict(ray, b0) << tile;
+        if (CT > 1) {
+            const CullBox b1 = bwd_box<CULL_THREADS>(R, TC, CT, 1, tile, xs, ys, sm);
+            dead1 |= (unsigned)cull_dead_strict(ray, b1) << tile;
         }
+    }
+    if (CT == 1) dead1 = dead0;                             // one list for both passes
+    if (n >= N || (dead0 | dead1) == 0) return;
+    const int per = CT > 1 ? TC / 64 : JB;                  // moment blocks per c tile
+    for (int jb = 0; jb < JB; ++jb) {
+        const bool z0 = (dead0 >> (jb / per)) & 1u, z1 = (dead1 >> (jb / per)) & 1u;
+        float* o = moments + (((long)b * JB + jb) * N + n) * HELIO_MOMENT_STRIDE;
+        if (z0) { o[0] = 0.0f; o[2] = 0.0f; o[4] = 0.0f; }
+        if (z1) { o[1] = 0.0f; o[3] = 0.0f; }
+    }
 }
 
 // ---- work order (cull.h): one workgroup each -----------------------------------------------------------

@@ -168,7 +168,8 @@ def test_rays_on_the_threshold_of_the_criterion(N, B, R, seed):
     assert torch.equal(bits(culled_m)[ok], bits(dense_m)[ok])
 
 
-@pytest.mark.parametrize("N,B,R", [(257, 3, 260), (700, 2, 512), (1000, 2, 128), (300, 4, 200), (520, 2, 600)])
+@pytest.mark.parametrize("N,B,R", [(257, 3, 260), (700, 2, 512), (1000, 2, 128), (300, 4, 200), (520, 2, 600),
+                                   (300, 1, 2100)])      # 2100: nine c tiles — past the eight that get lists of their own
 @pytest.mark.parametrize("sigma,err", [(0.01, 90.0), (0.01, 180.0), (0.1, 90.0)])
 def test_culled_backward_moments_equal_the_dense_ones_bit_for_bit(N, B, R, sigma, err):
     from doodle_amd import native
