@@ -389,6 +389,10 @@ def main():
                          "gathered loop is timed afterwards and reported as with_all_gather_every_step)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed and all-gather even with one rank (testing)")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="(development, no multi-GPU box at hand) walk the N > 1 control flow on ONE GPU: every rank uses "
+                         "cuda:0, the process group is gloo and the gather goes through torch.distributed.  The line "
+                         "carries \"rehearsal\": true — its figures mean nothing")
     ap.add_argument("--cfg5-suns", type=int, default=512, help="suns per GPU of the config-5 leg (BASELINE: 4096 / 8)")
     ap.add_argument("--cfg5-steps", type=int, default=20)
     args = ap.parse_args()
@@ -406,7 +410,7 @@ def main():
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC for RCCL; before HIP initialises
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = 0 if args.rehearse else int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     torch.cuda.set_device(local)
@@ -422,7 +426,10 @@ def main():
         import torch.distributed as dist
         for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29517"), ("RANK", "0"), ("WORLD_SIZE", "1")):
             os.environ.setdefault(k, v)          # only matters for a bare --force-dist run
-        dist.init_process_group("nccl", device_id=dev)
+        if args.rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     w = synthetic.CONFIGS[args.workload]
     helios, suns, errs, noise = synthetic.make_inputs(w, args.seed, b_offset=rank * w.B, b_count=w.B)
@@ -435,7 +442,7 @@ def main():
         # gathered legs are skipped and said so, the headline is still measured
         try:
             from doodle_amd.comm import ImageGather
-            gather = ImageGather()             # RCCL all-gather (libhelio_comm.so)
+            gather = ImageGather(transport="torch" if args.rehearse else "auto")     # RCCL all-gather (libhelio_comm.so)
             gathered = [torch.empty((world * w.B, w.R, w.R), dtype=torch.float32, device=dev) for _ in range(2)]
         except Exception as e:  # noqa: BLE001
             gather, gather_error = None, repr(e)
@@ -545,6 +552,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "preheat_s": args.preheat,
             "ms_per_step": round(el / args.steps * 1e3, 5), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            **({"rehearsal": True, "rehearsal_note": "all ranks on ONE GPU over gloo: control flow only, no figure of this line is a measurement"}
+               if args.rehearse else {}),
             "config": {"workload": f"{w.name} {'forward' if args.mode == 'fwd' else 'forward+backward'} "
                                    f"HelioField.render, sigma_scale={w.sigma_scale}, err={w.error_scale_mrad} mrad, "
                                    f"{w.B} suns per GPU",
