@@ -100,61 +100,47 @@ __device__ __forceinline__ CullBox bwd_box(int R, int TC, int CT, int pass, int 
 }
 
 // grid (CT, B, sets): the rays of image b whose moments of this (pass, c tile) are not identically zero, as
-// indices, in order; list = (pass·B + b)·CT + tile
-__global__ void __launch_bounds__(CULL_BWD_THREADS)
+// indices, in order; list = (pass·B + b)·CT + tile.  THREADS = 1024 with few lists (few images must not take
+// long), 256 with many (all of them resident at once: 51 → 20 µs at config 4).
+template <int THREADS>
+__global__ void __launch_bounds__(THREADS)
 cull_bwd_kernel(int N, int R, int TC, int CT, const float4* __restrict__ rays, const float* __restrict__ xs,
                 const float* __restrict__ ys, int* __restrict__ counts, int* __restrict__ idx) {
-    __shared__ float sm[3 * CULL_BWD_THREADS / 64];
-    __shared__ int sw[CULL_BWD_THREADS / 64];
+    __shared__ float sm[3 * THREADS / 64];
+    __shared__ int sw[THREADS / 64];
     const int tile = blockIdx.x, b = blockIdx.y, pass = blockIdx.z;
     const long list = ((long)pass * gridDim.y + b) * CT + tile;
-    const CullBox bx = bwd_box<CULL_BWD_THREADS>(R, TC, CT, pass, tile, xs, ys, sm);
+    const CullBox bx = bwd_box<THREADS>(R, TC, CT, pass, tile, xs, ys, sm);
     const float4* __restrict__ rb = rays + (long)b * N;
     int* __restrict__ out = idx + list * N;
     int base = 0;
-    for (int n0 = 0; n0 < N; n0 += CULL_BWD_THREADS) {
+    for (int n0 = 0; n0 < N; n0 += THREADS) {
         const int n = n0 + (int)threadIdx.x;
         const bool live = n < N && !cull_dead_strict(rb[n], bx);
         int total;
-        const int at = block_rank<CULL_BWD_THREADS>(live, sw, total);
+        const int at = block_rank<THREADS>(live, sw, total);
         if (live) out[base + at] = n;
         base += total;
     }
     if (threadIdx.x == 0) counts[list] = base;
 }
 
-// grid (⌈N/256⌉, B): the moments a ray is NOT listed for are zeroed — what the dense kernels compute for them:
-// pass 0 owns components (0, 2, 4) of the tile's 64-wide column blocks, pass 1 components (1, 3) of its row blocks.
-// The same test on the same numbers as cull_bwd_kernel, one thread per ray: with few images the list's one
-// workgroup must not also write N·JB·20 bytes.  Block jb is a column block of pass 0's tile jb/per and a row block
-// of pass 1's: both verdicts first, then one visit per block (a ray that misses the receiver altogether — most of the
-// dead ones — gets its 20-byte records written whole).
+// The moments a ray is NOT listed for must read zero — what the dense kernels compute for them (pass 0 owns
+// components (0, 2, 4) of a tile's 64-wide column blocks, pass 1 components (1, 3) of its row blocks).  The whole
+// buffer is cleared in front of the passes, which then write the listed rays' entries: whole cache lines at
+// streaming rate.  (A kernel that zeroed exactly the dead entries — the criterion once more, per ray — took 81 µs
+// at config 4, 54 µs with coalesced stores: partial lines; this takes what 164 MB of stores take.)
 __global__ void __launch_bounds__(CULL_THREADS)
-cull_bwd_fill_kernel(int N, int R, int JB, int TC, int CT, const float4* __restrict__ rays, const float* __restrict__ xs,
-                     const float* __restrict__ ys, float* __restrict__ moments) {
-    __shared__ float sm[3 * CULL_THREADS / 64];
-    const int b = blockIdx.y;
-    const int n = blockIdx.x * CULL_THREADS + (int)threadIdx.x;
-    float4 ray = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (n < N) ray = rays[(long)b * N + n];
-    unsigned dead0 = 0, dead1 = 0;                          // bit t: dead on tile t of pass 0 / 1 (CT <= 8)
-    for (int tile = 0; tile < CT; ++tile) {
-        const CullBox b0 = bwd_box<CULL_THREADS>(R, TC, CT, 0, tile, xs, ys, sm);       // (barriers: every thread)
-        dead0 |= (unsigned)cull_dead_strict(ray, b0) << tile;
-        if (CT > 1) {
-            const CullBox b1 = bwd_box<CULL_THREADS>(R, TC, CT, 1, tile, xs, ys, sm);
-            dead1 |= (unsigned)cull_dead_strict(ray, b1) << tile;
-        }
-    }
-    if (CT == 1) dead1 = dead0;                             // one list for both passes
-    if (n >= N || (dead0 | dead1) == 0) return;
-    const int per = CT > 1 ? TC / 64 : JB;                  // moment blocks per c tile
-    for (int jb = 0; jb < JB; ++jb) {
-        const bool z0 = (dead0 >> (jb / per)) & 1u, z1 = (dead1 >> (jb / per)) & 1u;
-        float* o = moments + (((long)b * JB + jb) * N + n) * HELIO_MOMENT_STRIDE;
-        if (z0) { o[0] = 0.0f; o[2] = 0.0f; o[4] = 0.0f; }
-        if (z1) { o[1] = 0.0f; o[3] = 0.0f; }
-    }
+cull_zero_kernel(float* __restrict__ p, long n) {
+    // 16-byte stores over the aligned middle, dwords at the ragged ends (the ABI asks 4-byte alignment of moments_d)
+    const long head = min(n, (long)((16 - (reinterpret_cast<unsigned long long>(p) & 15)) & 15) / 4);
+    const long n4 = (n - head) / 4;
+    const long tid = blockIdx.x * (long)CULL_THREADS + threadIdx.x, stride = (long)gridDim.x * CULL_THREADS;
+    float4* __restrict__ q = reinterpret_cast<float4*>(p + head);
+    for (long i = tid; i < n4; i += stride) q[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tid < head) p[tid] = 0.0f;
+    const long tail0 = head + 4 * n4;
+    if (tid < n - tail0) p[tail0 + tid] = 0.0f;
 }
 
 // ---- work order (cull.h): one workgroup each -----------------------------------------------------------
@@ -249,10 +235,15 @@ CullBwd launch_cull_bwd(int B, int N, int R, int JB, int TC, int CT, bool with_m
     int* idx = reinterpret_cast<int*>(base + cull_pad256(4 * T));
     int* total = reinterpret_cast<int*>(base + cull_pad256(4 * T) + cull_pad256(4 * T * N));
     int2* map = reinterpret_cast<int2*>(reinterpret_cast<char*>(total) + 256);
-    hipLaunchKernelGGL(cull_bwd_kernel, dim3(CT, B, sets), dim3(CULL_BWD_THREADS), 0, st, N, R, TC, CT,
-                       reinterpret_cast<const float4*>(rays), xs, ys, counts, idx);
-    hipLaunchKernelGGL(cull_bwd_fill_kernel, dim3((N + CULL_THREADS - 1) / CULL_THREADS, B), dim3(CULL_THREADS), 0, st, N, R, JB,
-                       TC, CT, reinterpret_cast<const float4*>(rays), xs, ys, moments);
+    if (T >= 512)
+        hipLaunchKernelGGL(cull_bwd_kernel<256>, dim3(CT, B, sets), dim3(256), 0, st, N, R, TC, CT,
+                           reinterpret_cast<const float4*>(rays), xs, ys, counts, idx);
+    else
+        hipLaunchKernelGGL(cull_bwd_kernel<CULL_BWD_THREADS>, dim3(CT, B, sets), dim3(CULL_BWD_THREADS), 0, st, N, R, TC, CT,
+                           reinterpret_cast<const float4*>(rays), xs, ys, counts, idx);
+    const long nm = (long)B * JB * N * HELIO_MOMENT_STRIDE;
+    hipLaunchKernelGGL(cull_zero_kernel, dim3((unsigned)min(8192l, (nm / 4 + CULL_THREADS - 1) / CULL_THREADS + 1)), dim3(CULL_THREADS), 0, st,
+                       moments, nm);
     if (with_map)
         hipLaunchKernelGGL(cull_map_bwd_kernel, dim3(sets), dim3(ORDER_THREADS), 0, st, (int)(T / sets), (int)nt, counts, total, map);
     return CullBwd{counts, idx, total, map, CT, T / sets, T / sets * nt, N};

@@ -183,7 +183,7 @@ splat_bwd_mfma(int B, int N, int R, const float* __restrict__ rays, const float*
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // scalar: nothing of it is kept in (or spilled from) VGPRs
     const int lr = lane & 31, lh = lane >> 5;
     // (cull.h) with lists of the rays whose moments are not identically zero, the ray axis of the tiles runs over
-    // a list: L entries, entry p is ray lidx[p] (the moments of the rays not listed were zeroed with the list).
+    // a list: L entries, entry p is ray lidx[p] (the moment buffer was cleared with the lists: rays not listed read zero).
     // A ray's moments involve no other ray, so which tile computes them changes nothing.  One list per image
     // serving all its c tiles (live_ct = 1), or one per (image, c tile) of THIS pass (live_ct = c_tiles).  The
     // workgroup's (list, ray tile) comes from the table of non-empty tiles, in id order, and the ids past the
