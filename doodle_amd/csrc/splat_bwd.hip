@@ -158,11 +158,11 @@ typedef __attribute__((address_space(3))) const float lds_cf;
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 template <int PASS, bool VEC, int WC = 4>
-__global__ void __launch_bounds__(256 * WC)
-splat_bwd_mfma(int B, int N, int R, const float* __restrict__ rays, const float* __restrict__ xs,
-               const float* __restrict__ ys, const float* __restrict__ gimg, float* __restrict__ moments,
-               const int* __restrict__ live_counts, const int* __restrict__ live_idx, const int* __restrict__ live_total,
-               const int2* __restrict__ live_map, int live_ct) {
+__device__ __forceinline__ void
+splat_bwd_mfma_body(int B, int N, int R, const float* __restrict__ rays, const float* __restrict__ xs,
+                    const float* __restrict__ ys, const float* __restrict__ gimg, float* __restrict__ moments,
+                    const int* __restrict__ live_counts, const int* __restrict__ live_idx, const int* __restrict__ live_total,
+                    const int2* __restrict__ live_map, int live_ct) {
     static_assert(!(VEC && PASS == 1), "16-byte staging is pass 0's");
     // Row pitch of the two LDS tables.  Pass 1 writes the slab transposed (lanes ↔ k at stride LD):
     // an odd pitch keeps that conflict-free.  Pass 0 writes it along c and stages it 16 bytes at a time
@@ -375,6 +375,34 @@ splat_bwd_mfma(int B, int N, int R, const float* __restrict__ rays, const float*
             if (PASS == 0) { o[0] = t0; o[2] = t1; o[4] = t2; }
             else { o[1] = t1; o[3] = t2; }
         }
+    }
+}
+
+template <int PASS, bool VEC, int WC = 4>
+__global__ void __launch_bounds__(256 * WC)
+splat_bwd_mfma(int B, int N, int R, const float* __restrict__ rays, const float* __restrict__ xs,
+               const float* __restrict__ ys, const float* __restrict__ gimg, float* __restrict__ moments,
+               const int* __restrict__ live_counts, const int* __restrict__ live_idx, const int* __restrict__ live_total,
+               const int2* __restrict__ live_map, int live_ct) {
+    splat_bwd_mfma_body<PASS, VEC, WC>(B, N, R, rays, xs, ys, gimg, moments, live_counts, live_idx, live_total, live_map, live_ct);
+}
+
+// Both passes in ONE launch (blockIdx.z = pass; the grid is walked x, y, z: all of pass 0, then pass 1): the tail
+// of pass 0 — the last, partly filled round of its workgroups — runs beside the head of pass 1.  set_lists /
+// set_items: where pass 1's lists and map start when every (pass, c tile) has lists of its own (cull.h), else 0.
+template <bool VEC, int WC>
+__global__ void __launch_bounds__(256 * WC)
+splat_bwd_mfma_both(int B, int N, int R, const float* __restrict__ rays, const float* __restrict__ xs,
+                    const float* __restrict__ ys, const float* __restrict__ gimg, float* __restrict__ moments,
+                    const int* __restrict__ live_counts, const int* __restrict__ live_idx, const int* __restrict__ live_total,
+                    const int2* __restrict__ live_map, int live_ct, long set_lists, long set_items) {
+    if (blockIdx.z == 0) {
+        splat_bwd_mfma_body<0, VEC, WC>(B, N, R, rays, xs, ys, gimg, moments, live_counts, live_idx, live_total, live_map, live_ct);
+    } else {
+        const bool own = live_counts && live_ct > 1;
+        splat_bwd_mfma_body<1, false, WC>(B, N, R, rays, xs, ys, gimg, moments, own ? live_counts + set_lists : live_counts,
+                                          own ? live_idx + set_lists * N : live_idx, own ? live_total + 1 : live_total,
+                                          own ? live_map + set_items : live_map, live_ct);
     }
 }
 
@@ -789,6 +817,22 @@ static void launch_bwd_mfma_v(int B, int N, int R, const float* rays, const floa
                        c.counts, c.idx, c.total, c.map, c.ct);
 }
 
+template <bool VEC, int WC>
+static void launch_bwd_mfma_both_v(int B, int N, int R, const float* rays, const float* xs, const float* ys,
+                                   const float* gimg, float* moments, hipStream_t st, CullBwd c) {
+    constexpr int TC = 64 * WC;
+    const size_t lds = (64 * ((TC + 4) + 260) + TC + 64) * sizeof(float);      // pass 0's pitches: the larger of the two
+    static bool configured = false;
+    if (!configured) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(splat_bwd_mfma_both<VEC, WC>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        configured = true;
+    }
+    const int ct = (R + TC - 1) / TC, nt = (N + 255) / 256;
+    hipLaunchKernelGGL((splat_bwd_mfma_both<VEC, WC>), dim3(ct * nt, B, 2), dim3(256 * WC), lds, st, B, N, R, rays, xs, ys, gimg,
+                       moments, c.counts, c.idx, c.total, c.map, c.ct, c.set_lists, c.set_items);
+}
+
 template <int PASS>
 static void launch_bwd_mfma(int B, int N, int R, const float* rays, const float* xs, const float* ys,
                             const float* gimg, float* moments, hipStream_t st, CullBwd cull) {
@@ -803,6 +847,21 @@ static void launch_bwd_mfma(int B, int N, int R, const float* rays, const float*
     } else {
         return narrow ? launch_bwd_mfma_v<1, false, 2>(B, N, R, rays, xs, ys, gimg, moments, st, cull)
                       : launch_bwd_mfma_v<1, false, 4>(B, N, R, rays, xs, ys, gimg, moments, st, cull);
+    }
+}
+
+// both passes: one launch for the 256-wide tiles; the 128-wide form (R <= 128) keeps two — merged, pass 0 would run
+// at pass 1's register count (165 against 113: three waves a SIMD instead of four)
+static void launch_bwd_mfma_both(int B, int N, int R, const float* rays, const float* xs, const float* ys,
+                                 const float* gimg, float* moments, hipStream_t st, CullBwd cull) {
+    static const bool two_launches = [] { const char* e = getenv("HELIO_BWD_PASSES"); return e && e[0] == '2'; }();   // A/B runs
+    if (R <= 128 || two_launches) {
+        launch_bwd_mfma<0>(B, N, R, rays, xs, ys, gimg, moments, st, cull);
+        launch_bwd_mfma<1>(B, N, R, rays, xs, ys, gimg, moments, st, cull);
+    } else if ((R & 3) == 0) {
+        launch_bwd_mfma_both_v<true, 4>(B, N, R, rays, xs, ys, gimg, moments, st, cull);
+    } else {
+        launch_bwd_mfma_both_v<false, 4>(B, N, R, rays, xs, ys, gimg, moments, st, cull);
     }
 }
 
@@ -1361,8 +1420,7 @@ int launch_splat_bwd(int B, int N, int R, const float* rays, const float* xs, co
                 cull = launch_cull_bwd(B, N, R, splat_bwd_blocks(R), R <= 128 ? 128 : 256, ct, /*with_map=*/true, rays, xs, ys,
                                        moments, scratch, st);
         }
-        launch_bwd_mfma<0>(B, N, R, rays, xs, ys, gimg, moments, st, cull);
-        launch_bwd_mfma<1>(B, N, R, rays, xs, ys, gimg, moments, st, cull);
+        launch_bwd_mfma_both(B, N, R, rays, xs, ys, gimg, moments, st, cull);
         return HELIO_OK;
     }
     if (variant != 1) return HELIO_E_INVALID;
