@@ -127,14 +127,27 @@ def time_interleaved(fns, iters, warm=2):
     return [sum(e0.elapsed_time(e1) for e0, e1 in ps) * 1e-3 / iters for ps in pairs]
 
 
-def preheat(fn, seconds, burst=None, fence=None):
+def preheat(fn, seconds, burst=None, fence=None, dist=None, device=None):
     """Run ``fn`` for ``seconds`` of wall time.  With ``burst`` and ``fence``: in bursts of ``burst`` calls
     followed by ``fence()`` — the pattern of the timed region itself.  (Measured, tools/launch_jitter.py:
     after a long run of unsynchronised launches the first three or four "20 calls + synchronize" samples
     take 210–260 µs, then 156–168 µs for good; a preheat that never synchronises leaves the timed sample
-    in that transient.)"""
+    in that transient.)
+
+    With a process group (``dist``) ``fn`` and ``fence`` contain collectives, so every rank must run the SAME
+    number of bursts: whether to go on is agreed by all ranks (an all-reduce of each rank's own clock
+    verdict) — a loop that every rank ends by its own clock runs one burst more on some ranks than on others
+    whenever a burst ends within the ranks' start skew of the deadline, and the job hangs in the unmatched
+    barrier (found by the two-rank rehearsal, ``--rehearse``: one run in six)."""
     t0 = time.perf_counter()
-    while time.perf_counter() - t0 < seconds:
+    while True:
+        go = time.perf_counter() - t0 < seconds
+        if dist is not None:
+            verdict = torch.tensor([1 if go else 0], dtype=torch.int32, device=device)
+            dist.all_reduce(verdict, op=dist.ReduceOp.MIN)
+            go = bool(verdict.item())
+        if not go:
+            return
         if burst is None:
             fn()
         else:
@@ -480,7 +493,7 @@ def main():
         step()
     # disclosed (preheat_s): host path and GPU clocks at steady state, in bursts of K steps + fence like
     # the timed region (at least four of them)
-    preheat(step, args.preheat, burst=args.steps, fence=fence)
+    preheat(step, args.preheat, burst=args.steps, fence=fence, dist=dist, device=dev)
     for _ in range(4 if args.steps <= 1000 else 0):
         for _ in range(args.steps):
             step()
@@ -525,7 +538,7 @@ def main():
         gather_now[0] = not gather_now[0]
         for _ in range(min(args.warmup, 50)):
             step()
-        preheat(step, min(args.preheat, 0.2), burst=args.steps, fence=fence)
+        preheat(step, min(args.preheat, 0.2), burst=args.steps, fence=fence, dist=dist, device=dev)
         fence()
         t0 = time.perf_counter()
         for _ in range(args.steps):
