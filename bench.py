@@ -8,7 +8,9 @@ A "step" is one ``HelioField.render`` forward over one batch of B synthetic sun 
 (``--preheat`` seconds of the same call, default 0.5 — disclosed in the line as ``preheat_s``):
 a fresh host path and a GPU coming out of idle run slow for their first ~0.1 s, and a K = 20
 sample is only ≈0.1 ms long.  Then EXACTLY K steps are timed between barrier + synchronize
-fences, MAX over ranks.  The process first binds all its threads — the runtime's helper threads too — to
+fences, MAX over ranks (with N > 1 the clock stops at each rank's own synchronize and the closing barrier
+follows — the barrier's own latency is tens of µs beside a 91 µs sample; the reading with the clock stopped
+behind it is in the line too, ``ms_per_step_with_closing_barrier``).  The process first binds all its threads — the runtime's helper threads too — to
 one last-level-cache group (CCD) of its GPU's NUMA node (doodle_amd/affinity.py — what ``taskset`` would
 do; measured: tools/core_sweep.py; disclosed as ``config.host_affinity``; the CPU baseline runs under the
 original mask).
@@ -488,6 +490,25 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def stop_clock(t0):
+        """End of a timed region: the clock stops when THIS rank's K steps are done (its collectives waited for, its
+        device synchronised); the closing barrier + synchronize of the bracket follow, and the job's time is the MAX
+        over ranks — the moment the slowest rank was done.  With the clock stopped behind the barrier instead, a 91 µs
+        sample would mostly measure the barrier's own latency (tens of µs over 8 ranks, none at all with one rank);
+        that reading is reported beside it (``ms_per_step_with_closing_barrier``).  → (seconds, seconds incl. barrier)"""
+        if gather is not None:
+            gather.wait()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if dist is None:
+            return el, el
+        dist.barrier()
+        torch.cuda.synchronize()
+        el_b = time.perf_counter() - t0
+        t = torch.tensor([el, el_b], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t[0].item()), float(t[1].item())
+
     gather_now = [bool(args.gather_every_step)]
     for _ in range(args.warmup):
         step()
@@ -511,8 +532,7 @@ def main():
                 t0 = time.perf_counter()
                 for _ in range(K):
                     render(suns_d, action, None)
-                fence()
-                el = time.perf_counter() - t0
+                el, el_barrier = stop_clock(t0)
         finally:
             if gc_was:
                 gc.enable()
@@ -520,12 +540,7 @@ def main():
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
-        fence()
-        el = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([el], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
+        el, el_barrier = stop_clock(t0)
 
     # the same shards with the other treatment of the images (gathered every step / left on their
     # rank): at config 2 the gathered loop is bound by delivering (N-1) x 1.64 MB to every rank per
@@ -543,10 +558,7 @@ def main():
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
-        fence()
-        t = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el_other = float(t.item())
+        el_other, _ = stop_clock(t0)
         gather_now[0] = not gather_now[0]
 
     # the multi-GPU figure of record, on EVERY rank (collective): the real per-GPU shard of BASELINE
@@ -564,6 +576,7 @@ def main():
             "metric": "HelioField.render frames/sec", "value": round(frames / el, 1), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "preheat_s": args.preheat,
             "ms_per_step": round(el / args.steps * 1e3, 5), "higher_is_better": True, "scaling": "weak",
+            **({"ms_per_step_with_closing_barrier": round(el_barrier / args.steps * 1e3, 5)} if world > 1 else {}),
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             **({"rehearsal": True, "rehearsal_note": "all ranks on ONE GPU over gloo: control flow only, no figure of this line is a measurement"}
                if args.rehearse else {}),
@@ -576,7 +589,8 @@ def main():
                           else (", no data-path collective (images stay on the rank that rendered them)" if world > 1 else "")),
                        "timing": f"{args.warmup} warm-up steps, {args.preheat} s time-based preheat (untimed, in bursts of "
                                  f"{args.steps} steps + fence), then {args.steps} timed steps between barrier + synchronize "
-                                 "fences, max over ranks",
+                                 "fences, max over ranks" + ("; the clock stops at each rank's own synchronize, the closing barrier "
+                                 "follows (ms_per_step_with_closing_barrier: the clock stopped behind it)" if world > 1 else ""),
                        "host_affinity": (f"all threads of the process bound to one last-level-cache group (CPUs {numa['l3_group']}, "
                                          f"{numa['cpus']} of them) of the GPU's NUMA node {numa['numa_node']}"
                                          if numa is not None else "scheduler's choice")},
@@ -826,9 +840,12 @@ def cfg5_shard_leg(dev, rank, world, gather, dist, seed, b_local=512, steps=20):
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
-    fence()
-    el = time.perf_counter() - t0
+    if gather is not None:
+        gather.wait()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0             # (the clock stops at the rank's own synchronize; the closing barrier follows)
     if dist is not None:
+        dist.barrier()
         t = torch.tensor([el], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())

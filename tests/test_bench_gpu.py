@@ -56,7 +56,7 @@ def test_two_ranks_walk_the_multi_gpu_control_flow(attempt):
     d = _one_json_line(_run(cmd, 240))                 # rank 0 alone prints, and prints one line
     assert all(k in d for k in CONTRACT) and d["n_gpus"] == 2 and d["rehearsal"] is True
     assert d["config"]["global_batch"] == 50 and d["scaling"] == "weak" and d["value"] > 0
-    assert d["collective"]["world_size"] == 2
+    assert d["collective"]["world_size"] == 2 and d["ms_per_step_with_closing_barrier"] >= d["ms_per_step"] > 0
     assert d["with_all_gather_every_step"]["frames_per_s"] > 0          # the gathered loop ran on both ranks
     shard = d["multi_gpu_of_record"]
     assert "error" not in shard and shard["n_gpus"] == 2 and shard["frames_per_s"] > 0
