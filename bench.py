@@ -452,20 +452,29 @@ def main():
     suns_d = suns.to(dev)
     action = make_action(field, suns_d, noise)
     gather, gathered, gather_error = None, None, None
-    if dist is not None:
-        # the timed loop does not need the collective; if the communicator cannot be created the
-        # gathered legs are skipped and said so, the headline is still measured
+
+    def make_gather():
+        """The image all-gather (RCCL through libhelio_comm.so) and its two output buffers; all ranks get one or none
+        does.  If the communicator cannot be created the gathered legs are skipped and said so."""
+        nonlocal gather, gathered, gather_error
         try:
             from doodle_amd.comm import ImageGather
-            gather = ImageGather(transport="torch" if args.rehearse else "auto")     # RCCL all-gather (libhelio_comm.so)
+            gather = ImageGather(transport="torch" if args.rehearse else "auto")
             gathered = [torch.empty((world * w.B, w.R, w.R), dtype=torch.float32, device=dev) for _ in range(2)]
         except Exception as e:  # noqa: BLE001
             gather, gather_error = None, repr(e)
         flag = torch.tensor([0 if gather is not None else 1], device=dev)
-        dist.all_reduce(flag)                  # all ranks gather, or none does
+        dist.all_reduce(flag)
         if int(flag.item()) != 0 and gather is not None:
             gather.close()
             gather, gather_error = None, "another rank could not create the communicator"
+
+    # The headline loop has no collective, so the communicator is made AFTER it unless the loop itself gathers
+    # (--gather-every-step): a second RCCL instance in the process (its proxy threads beside the launching thread, on
+    # the one CCD all threads are bound to) costs a launch-bound loop 20–45 % (one box, K = 20, five runs each: 5.0–5.7 M
+    # frames/s without it, 3.1–4.4 M with it, 5.1–5.7 M with only torch.distributed's own communicator).
+    if dist is not None and args.gather_every_step:
+        make_gather()
     stepno = [0]
     if args.mode == "fwdbwd":
         action.requires_grad_(True)
@@ -546,6 +555,8 @@ def main():
     # rank): at config 2 the gathered loop is bound by delivering (N-1) x 1.64 MB to every rank per
     # step, DESIGN.md §5 — always reported beside `value`, never instead of it
     el_other = None
+    if dist is not None and gather is None and gather_error is None:
+        make_gather()
     if gather is not None and numa is not None:
         # the gathered legs are not launch-bound and run RCCL's proxy threads: the whole NUMA node for them
         affinity.widen_to_node(local)
