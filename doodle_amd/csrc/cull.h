@@ -59,9 +59,12 @@ __device__ __forceinline__ bool cull_dead_strict(const float4 ray, const CullBox
 // forward:  int counts[T] | int order[T] | float4 lists[T][P]          T = B·tiles²·S, tile = TE×TE pixels;
 //           S = 1, P = N normally; with the heliostat sum split across workgroups (splat_fwd.hip, "split"),
 //           S parts of P consecutive rays each and one list per (image, tile, part)
-// backward: int counts[T] | int idx[T][N] | int total[sets] (+pad) | int2 map[T·⌈N/256⌉]     T = sets·B·CT lists:
+// backward: int counts[T] | int idx[T][N] | int total[sets], tail_total[sets] (256 bytes) | int2 map[T·⌈N/256⌉] |
+//           int2 tail_map[T]     T = sets·B·CT lists:
 //           CT = 1: one list per image, shared by the two passes (sets = 1); CT > 1: one list per (pass, image,
-//           c tile) of the LDS-tile kernels (sets = 2), list = (pass·B + b)·CT + tile
+//           c tile) of the LDS-tile kernels (sets = 2), list = (pass·B + b)·CT + tile.  tail_map: the LAST tile of a
+//           list when it holds at most 128 rays — those run in the kernel's 128-ray form (splat_bwd.hip), the others
+//           (map) in the 256-ray form.
 // (every section padded to 256 bytes)
 __host__ __device__ inline long cull_pad256(long bytes) { return (bytes + 255) & ~255l; }
 inline long cull_fwd_bytes(int B, int N, int R, int TE, int S = 1, int P = 0) {
@@ -73,16 +76,18 @@ constexpr int CULL_BWD_MAX_CT = 8;           // c tiles per image that get lists
 inline long cull_bwd_lists(int B, int CT) { return (long)B * CT * (CT > 1 ? 2 : 1); }
 inline long cull_bwd_bytes(int B, int N, int CT = 1) {
     const long nt = (N + CULL_BWD_TILE - 1) / CULL_BWD_TILE, T = cull_bwd_lists(B, CT);
-    return cull_pad256(4 * T) + cull_pad256(4 * T * N) + 256 + 8 * T * nt;
+    return cull_pad256(4 * T) + cull_pad256(4 * T * N) + 256 + 8 * T * nt + 8 * T;
 }
 
 struct CullFwd { const int* counts; const int* order; const float4* lists; };      // counts == nullptr: dense
 // ct: lists per image and pass (1 = one per image for both passes); for_pass(): the set a pass walks
 struct CullBwd {
-    const int* counts; const int* idx; const int* total; const int2* map; int ct; long set_lists, set_items; int N;
+    const int* counts; const int* idx; const int* total; const int2* map; const int* tail_total; const int2* tail_map;
+    int ct; long set_lists, set_items; int N;
     CullBwd for_pass(int pass) const {
         if (!counts || ct <= 1 || pass == 0) return *this;
-        return CullBwd{counts + set_lists, idx + set_lists * N, total + 1, map + set_items, ct, set_lists, set_items, N};
+        return CullBwd{counts + set_lists, idx + set_lists * N, total + 1, map + set_items, tail_total + 1, tail_map + set_lists,
+                       ct, set_lists, set_items, N};
     }
 };
 
@@ -90,7 +95,7 @@ struct CullBwd {
 CullFwd launch_cull_fwd(int B, int N, int R, int TE, int S, int P, bool with_order, const float* rays, const float* xs,
                         const float* ys, void* scratch, hipStream_t st);
 // TC: width of a c tile in pixels, CT = ⌈R/TC⌉ or 1
-CullBwd launch_cull_bwd(int B, int N, int R, int JB, int TC, int CT, bool with_map, const float* rays, const float* xs,
+CullBwd launch_cull_bwd(int B, int N, int R, int JB, int TC, int CT, bool with_map, bool split_tails, const float* rays, const float* xs,
                         const float* ys, float* moments, void* scratch, hipStream_t st);
 bool cull_enabled();
 

@@ -186,22 +186,31 @@ cull_order_fwd_kernel(int T, int N, const int* __restrict__ counts, int* __restr
 }
 
 // map[] = (list, ray tile) of every tile of the lists that holds a ray, list-major (= image-major); *total = how
-// many.  grid (sets): one workgroup per set of `lists` lists.
+// many.  With split_tails the last tile of a list goes to tail_map[] instead when it holds at most 128 rays.
+// grid (sets): one workgroup per set of `lists` lists.
 __global__ void __launch_bounds__(ORDER_THREADS)
-cull_map_bwd_kernel(int lists, int nt, const int* __restrict__ counts, int* __restrict__ total_out, int2* __restrict__ map) {
+cull_map_bwd_kernel(int lists, int nt, int split_tails, const int* __restrict__ counts, int* __restrict__ total_out,
+                    int2* __restrict__ map, int* __restrict__ tail_total_out, int2* __restrict__ tail_map) {
     __shared__ int sw[ORDER_WAVES];
     counts += (long)blockIdx.x * lists;
     map += (long)blockIdx.x * lists * nt;
-    int running = 0;
+    tail_map += (long)blockIdx.x * lists;
+    int running = 0, running_tail = 0;
     for (int l0 = 0; l0 < lists; l0 += ORDER_THREADS) {
         const int l = l0 + (int)threadIdx.x;
-        const int t = l < lists ? (counts[l] + CULL_BWD_TILE - 1) / CULL_BWD_TILE : 0;
+        const int c = l < lists ? counts[l] : 0;
+        const int t = (c + CULL_BWD_TILE - 1) / CULL_BWD_TILE;
+        const int tail = split_tails && t > 0 && c - (t - 1) * CULL_BWD_TILE <= CULL_BWD_TILE / 2;
+        const int tf = t - tail;
         int total;
-        const int start = running + block_scan_incl(t, sw, total) - t;
-        for (int k = 0; k < t; ++k) map[start + k] = make_int2(l, k);
+        const int start = running + block_scan_incl(tf, sw, total) - tf;
+        for (int k = 0; k < tf; ++k) map[start + k] = make_int2(l, k);
         running += total;
+        const int start_t = running_tail + block_scan_incl(tail, sw, total) - tail;
+        if (tail) tail_map[start_t] = make_int2(l, t - 1);
+        running_tail += total;
     }
-    if (threadIdx.x == 0) total_out[blockIdx.x] = running;
+    if (threadIdx.x == 0) { total_out[blockIdx.x] = running; tail_total_out[blockIdx.x] = running_tail; }
 }
 
 // HELIO_CULL=0 switches the stage off (A/B runs): the dense kernels then run whatever scratch is passed
@@ -226,7 +235,7 @@ CullFwd launch_cull_fwd(int B, int N, int R, int TE, int S, int P, bool with_ord
     return CullFwd{counts, with_order ? order : nullptr, lists};
 }
 
-CullBwd launch_cull_bwd(int B, int N, int R, int JB, int TC, int CT, bool with_map, const float* rays, const float* xs,
+CullBwd launch_cull_bwd(int B, int N, int R, int JB, int TC, int CT, bool with_map, bool split_tails, const float* rays, const float* xs,
                         const float* ys, float* moments, void* scratch, hipStream_t st) {
     const int sets = CT > 1 ? 2 : 1;
     const long T = cull_bwd_lists(B, CT), nt = (N + CULL_BWD_TILE - 1) / CULL_BWD_TILE;
@@ -244,9 +253,13 @@ CullBwd launch_cull_bwd(int B, int N, int R, int JB, int TC, int CT, bool with_m
     const long nm = (long)B * JB * N * HELIO_MOMENT_STRIDE;
     hipLaunchKernelGGL(cull_zero_kernel, dim3((unsigned)min(8192l, (nm / 4 + CULL_THREADS - 1) / CULL_THREADS + 1)), dim3(CULL_THREADS), 0, st,
                        moments, nm);
+    int* tail_total = total + 8;
+    int2* tail_map = map + T * nt;
     if (with_map)
-        hipLaunchKernelGGL(cull_map_bwd_kernel, dim3(sets), dim3(ORDER_THREADS), 0, st, (int)(T / sets), (int)nt, counts, total, map);
-    return CullBwd{counts, idx, total, map, CT, T / sets, T / sets * nt, N};
+        hipLaunchKernelGGL(cull_map_bwd_kernel, dim3(sets), dim3(ORDER_THREADS), 0, st, (int)(T / sets), (int)nt, (int)split_tails, counts,
+                           total, map, tail_total, tail_map);
+    const bool tails = with_map && split_tails;
+    return CullBwd{counts, idx, total, map, tails ? tail_total : nullptr, tails ? tail_map : nullptr, CT, T / sets, T / sets * nt, N};
 }
 
 }  // namespace helio

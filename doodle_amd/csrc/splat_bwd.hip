@@ -157,7 +157,7 @@ typedef __attribute__((address_space(3))) const float lds_cf;
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-template <int PASS, bool VEC, int WC = 4>
+template <int PASS, bool VEC, int WC = 4, int WR = 4>
 __device__ __forceinline__ void
 splat_bwd_mfma_body(int B, int N, int R, const float* __restrict__ rays, const float* __restrict__ xs,
                     const float* __restrict__ ys, const float* __restrict__ gimg, float* __restrict__ moments,
@@ -173,7 +173,10 @@ splat_bwd_mfma_body(int B, int N, int R, const float* __restrict__ rays, const f
     // would be padding (R = 128, the reference's default resolution: 0.37 → of the peak with either the padded
     // tile or the small-tile kernel).  The ray extent stays 256: the factor table costs exps per (k, ray),
     // the slab only loads, so the narrow side is the slab's.
-    constexpr int KC = 64, T = 256, TC = 64 * WC, NT = 256 * WC, KPT = KC / WC;
+    // WR = ray blocks of 64 per workgroup: 4 → 256 rays; 2 → the 128-ray form for the LAST tile of a list when it holds
+    // at most 128 rays (8 waves: the slab is staged by half the threads, the factor table and the MFMAs are half) —
+    // a list's last tile is half empty on average, and lists are short (≈1100 rays at config 4: cull.h)
+    constexpr int KC = 64, T = 64 * WR, TC = 64 * WC, NT = 64 * WC * WR, KPT = KC / WC, NV = KC * TC / NT;
     constexpr int LDG = PASS == 0 ? TC + 4 : TC + 1, LD = PASS == 0 ? T + 4 : T + 1;
     extern __shared__ __attribute__((aligned(16))) float smem[];   // sG[KC][LDG] sF[KC][LD] ccoord[TC]
     float* __restrict__ sCc = smem + KC * (LDG + LD);
@@ -199,10 +202,10 @@ splat_bwd_mfma_body(int B, int N, int R, const float* __restrict__ rays, const f
         b = live_ct > 1 ? e.x / c_tiles : e.x;
         bx = e.y * c_tiles + (live_ct > 1 ? e.x % c_tiles : (int)(w % per));
     }
-    const int c0 = (bx % c_tiles) * TC, n0 = (bx / c_tiles) * T;
+    const int c0 = (bx % c_tiles) * TC, n0 = (bx / c_tiles) * CULL_BWD_TILE;     // (tiles are numbered in 256 rays whatever WR)
     const int L = live_counts ? live_counts[lst] : N;
     const int* __restrict__ lidx = live_counts ? live_idx + (long)lst * N : nullptr;
-    const int wc = (wave >> 2) * 64, wn = (wave & 3) * 64;
+    const int wc = (wave / WR) * 64, wn = (wave % WR) * 64;
     const float* __restrict__ ccoord = PASS == 0 ? ys : xs;   // coordinates along c
     const float* __restrict__ kcoord = PASS == 0 ? xs : ys;   // coordinates along k
     const float* __restrict__ G = gimg + (long)b * R * R;
@@ -211,7 +214,7 @@ splat_bwd_mfma_body(int B, int N, int R, const float* __restrict__ rays, const f
 
     // producer role for the factor table: ray (wave&3)*64 + lane of the tile, KPT = 64 / WC k of every chunk
     const int pr = wn + lane;
-    const int pk0 = (wave >> 2) * KPT;
+    const int pk0 = (wave / WR) * KPT;
     float4 q = make_float4(0.f, 0.f, 1.f, 1e30f);
     if (n0 + pr < L) q = reinterpret_cast<const float4*>(rays)[(long)b * N + (lidx ? lidx[n0 + pr] : n0 + pr)];
     const float sk = __builtin_sqrtf(q.z);
@@ -224,11 +227,11 @@ splat_bwd_mfma_body(int B, int N, int R, const float* __restrict__ rays, const f
     //           p = tid + 1024·v covers k = p>>6, c = 4(p&63)..+3 — a wave reads 1 KB of one image row and
     //           writes 1 KB of one LDS row.  Otherwise dword by dword, lanes ↔ c.
     //   pass 1: Gm[k][c] = G[c0+c][k0+k]:  k = idx&63, c = idx>>6   (lanes ↔ k, stride LD = 257 in LDS)
-    float gv[16];
+    float gv[NV];
     auto load_slab = [&](int k0) {
         if constexpr (VEC) {
 #pragma unroll
-            for (int v = 0; v < 4; ++v) {
+            for (int v = 0; v < NV / 4; ++v) {
                 const int p = tid + NT * v;
                 const int row = k0 + p / (TC / 4), col = c0 + 4 * (p % (TC / 4));
                 float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -237,7 +240,7 @@ splat_bwd_mfma_body(int B, int N, int R, const float* __restrict__ rays, const f
             }
         } else {
 #pragma unroll
-            for (int v = 0; v < 16; ++v) {
+            for (int v = 0; v < NV; ++v) {
                 const int idx = tid + NT * v;
                 const int k = PASS == 0 ? idx / TC : idx & 63, c = PASS == 0 ? idx % TC : idx >> 6;
                 const int row = PASS == 0 ? k0 + k : c0 + c, col = PASS == 0 ? c0 + c : k0 + k;
@@ -248,7 +251,7 @@ splat_bwd_mfma_body(int B, int N, int R, const float* __restrict__ rays, const f
     auto store_slab = [&]() {
         if constexpr (VEC) {
 #pragma unroll
-            for (int v = 0; v < 4; ++v) {
+            for (int v = 0; v < NV / 4; ++v) {
                 const int p = tid + NT * v;
                 *reinterpret_cast<float4*>(smem + (p / (TC / 4)) * LDG + 4 * (p % (TC / 4))) =
                     make_float4(gv[4 * v], gv[4 * v + 1], gv[4 * v + 2], gv[4 * v + 3]);
@@ -256,7 +259,7 @@ splat_bwd_mfma_body(int B, int N, int R, const float* __restrict__ rays, const f
         } else {
             lds_f* dst = (lds_f*)smem;
 #pragma unroll
-            for (int v = 0; v < 16; ++v) {
+            for (int v = 0; v < NV; ++v) {
                 const int idx = tid + NT * v;
                 const int k = PASS == 0 ? idx / TC : idx & 63, c = PASS == 0 ? idx % TC : idx >> 6;
                 dst[k * LDG + c] = gv[v];
@@ -389,20 +392,21 @@ splat_bwd_mfma(int B, int N, int R, const float* __restrict__ rays, const float*
 
 // Both passes in ONE launch (blockIdx.z = pass; the grid is walked x, y, z: all of pass 0, then pass 1): the tail
 // of pass 0 — the last, partly filled round of its workgroups — runs beside the head of pass 1.  set_lists /
-// set_items: where pass 1's lists and map start when every (pass, c tile) has lists of its own (cull.h), else 0.
-template <bool VEC, int WC>
-__global__ void __launch_bounds__(256 * WC)
+// map_stride: where pass 1's lists and its part of the work map start when every (pass, c tile) has lists of its
+// own (cull.h), else unused.  WR = 2: the 128-ray form, run over the map of short last tiles.
+template <bool VEC, int WC, int WR>
+__global__ void __launch_bounds__(64 * WC * WR)
 splat_bwd_mfma_both(int B, int N, int R, const float* __restrict__ rays, const float* __restrict__ xs,
                     const float* __restrict__ ys, const float* __restrict__ gimg, float* __restrict__ moments,
                     const int* __restrict__ live_counts, const int* __restrict__ live_idx, const int* __restrict__ live_total,
-                    const int2* __restrict__ live_map, int live_ct, long set_lists, long set_items) {
+                    const int2* __restrict__ live_map, int live_ct, long set_lists, long map_stride) {
     if (blockIdx.z == 0) {
-        splat_bwd_mfma_body<0, VEC, WC>(B, N, R, rays, xs, ys, gimg, moments, live_counts, live_idx, live_total, live_map, live_ct);
+        splat_bwd_mfma_body<0, VEC, WC, WR>(B, N, R, rays, xs, ys, gimg, moments, live_counts, live_idx, live_total, live_map, live_ct);
     } else {
         const bool own = live_counts && live_ct > 1;
-        splat_bwd_mfma_body<1, false, WC>(B, N, R, rays, xs, ys, gimg, moments, own ? live_counts + set_lists : live_counts,
-                                          own ? live_idx + set_lists * N : live_idx, own ? live_total + 1 : live_total,
-                                          own ? live_map + set_items : live_map, live_ct);
+        splat_bwd_mfma_body<1, false, WC, WR>(B, N, R, rays, xs, ys, gimg, moments, own ? live_counts + set_lists : live_counts,
+                                              own ? live_idx + set_lists * N : live_idx, own ? live_total + 1 : live_total,
+                                              own ? live_map + map_stride : live_map, live_ct);
     }
 }
 
@@ -817,20 +821,27 @@ static void launch_bwd_mfma_v(int B, int N, int R, const float* rays, const floa
                        c.counts, c.idx, c.total, c.map, c.ct);
 }
 
-template <bool VEC, int WC>
+template <bool VEC, int WC, int WR>
 static void launch_bwd_mfma_both_v(int B, int N, int R, const float* rays, const float* xs, const float* ys,
                                    const float* gimg, float* moments, hipStream_t st, CullBwd c) {
-    constexpr int TC = 64 * WC;
-    const size_t lds = (64 * ((TC + 4) + 260) + TC + 64) * sizeof(float);      // pass 0's pitches: the larger of the two
+    constexpr int TC = 64 * WC, T = 64 * WR;
+    const size_t lds = (64 * ((TC + 4) + (T + 4)) + TC + 64) * sizeof(float);      // pass 0's pitches: the larger of the two
     static bool configured = false;
     if (!configured) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(splat_bwd_mfma_both<VEC, WC>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(splat_bwd_mfma_both<VEC, WC, WR>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         configured = true;
     }
     const int ct = (R + TC - 1) / TC, nt = (N + 255) / 256;
-    hipLaunchKernelGGL((splat_bwd_mfma_both<VEC, WC>), dim3(ct * nt, B, 2), dim3(256 * WC), lds, st, B, N, R, rays, xs, ys, gimg,
-                       moments, c.counts, c.idx, c.total, c.map, c.ct, c.set_lists, c.set_items);
+    if (WR == 4) {
+        hipLaunchKernelGGL((splat_bwd_mfma_both<VEC, WC, WR>), dim3(ct * nt, B, 2), dim3(64 * WC * WR), lds, st, B, N, R, rays, xs, ys, gimg,
+                           moments, c.counts, c.idx, c.total, c.map, c.ct, c.set_lists, c.set_items);
+    } else {
+        // the short last tiles: at most one per list (and c tile, where a list serves all of an image's c tiles)
+        const long items = c.set_lists * (c.ct > 1 ? 1 : ct);
+        hipLaunchKernelGGL((splat_bwd_mfma_both<VEC, WC, WR>), dim3((unsigned)items, 1, 2), dim3(64 * WC * WR), lds, st, B, N, R, rays, xs, ys,
+                           gimg, moments, c.counts, c.idx, c.tail_total, c.tail_map, c.ct, c.set_lists, c.set_lists);
+    }
 }
 
 template <int PASS>
@@ -859,10 +870,20 @@ static void launch_bwd_mfma_both(int B, int N, int R, const float* rays, const f
         launch_bwd_mfma<0>(B, N, R, rays, xs, ys, gimg, moments, st, cull);
         launch_bwd_mfma<1>(B, N, R, rays, xs, ys, gimg, moments, st, cull);
     } else if ((R & 3) == 0) {
-        launch_bwd_mfma_both_v<true, 4>(B, N, R, rays, xs, ys, gimg, moments, st, cull);
+        launch_bwd_mfma_both_v<true, 4, 4>(B, N, R, rays, xs, ys, gimg, moments, st, cull);
+        if (cull.tail_map) launch_bwd_mfma_both_v<true, 4, 2>(B, N, R, rays, xs, ys, gimg, moments, st, cull);
     } else {
-        launch_bwd_mfma_both_v<false, 4>(B, N, R, rays, xs, ys, gimg, moments, st, cull);
+        launch_bwd_mfma_both_v<false, 4, 4>(B, N, R, rays, xs, ys, gimg, moments, st, cull);
+        if (cull.tail_map) launch_bwd_mfma_both_v<false, 4, 2>(B, N, R, rays, xs, ys, gimg, moments, st, cull);
     }
+}
+
+// the last tile of a list in the 128-ray form when it holds at most 128 rays (cull.h): only with the one-launch form of
+// the 256-wide tiles, and HELIO_BWD_TAIL=0 switches it off (A/B runs)
+static bool bwd_split_tails(int R) {
+    static const bool off = [] { const char* e = getenv("HELIO_BWD_TAIL"); return e && e[0] == '0'; }();
+    static const bool two_launches = [] { const char* e = getenv("HELIO_BWD_PASSES"); return e && e[0] == '2'; }();
+    return R > 128 && !off && !two_launches;
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -1382,7 +1403,7 @@ int launch_splat_bwd(int B, int N, int R, const float* rays, const float* xs, co
         static const int ks_exp = [] { const char* e = getenv("HELIO_BWD_KSX"); return e ? atoi(e) : 0; }();     // tuning runs
         CullBwd cull{};
         if (scratch && cull_bwd_possible(variant, B, N, R) && scratch_bytes >= cull_bwd_bytes(B, N))
-            cull = launch_cull_bwd(B, N, R, splat_bwd_blocks(R), R, 1, /*with_map=*/false, rays, xs, ys, moments, scratch, st);
+            cull = launch_cull_bwd(B, N, R, splat_bwd_blocks(R), R, 1, /*with_map=*/false, false, rays, xs, ys, moments, scratch, st);
         // tools/sweep_bwd_nrb.py: from N = 600 — with workgroups enough — no split of the contracted axis at all
         // (4 independent waves of 64 rays each: one epilogue per 2·R MFMAs): B = 25: N = 1000, R = 128: 37 → 30 µs,
         // R = 256: 112 → 98 µs; B = 256, N = 1000, R = 64: 96 → 62 µs; at N = 300 it is 1.5× slower.  (Held to 128
@@ -1417,7 +1438,7 @@ int launch_splat_bwd(int B, int N, int R, const float* rays, const float* xs, co
             int ct = cull_bwd_ct(2, B, N, R);
             if (scratch_bytes < cull_bwd_bytes(B, N, ct)) ct = 1;
             if (scratch_bytes >= cull_bwd_bytes(B, N, ct))
-                cull = launch_cull_bwd(B, N, R, splat_bwd_blocks(R), R <= 128 ? 128 : 256, ct, /*with_map=*/true, rays, xs, ys,
+                cull = launch_cull_bwd(B, N, R, splat_bwd_blocks(R), R <= 128 ? 128 : 256, ct, /*with_map=*/true, bwd_split_tails(R), rays, xs, ys,
                                        moments, scratch, st);
         }
         launch_bwd_mfma_both(B, N, R, rays, xs, ys, gimg, moments, st, cull);

@@ -50,10 +50,10 @@ def bwd_lists_per_image(R, variant):
 
 
 def bwd_scratch_need(B, N, R, variant, per_image=False):
-    pad = lambda n: (n + 255) // 256 * 256      # noqa: E731  counts | idx | total | map (csrc/cull.h)
+    pad = lambda n: (n + 255) // 256 * 256      # noqa: E731  counts | idx | totals | map | tail map (csrc/cull.h)
     ct = 1 if per_image else bwd_lists_per_image(R, variant)
     T = B * ct * (2 if ct > 1 else 1)
-    return pad(4 * T) + pad(4 * T * N) + 256 + 8 * T * ((N + 255) // 256), T
+    return pad(4 * T) + pad(4 * T * N) + 256 + 8 * T * ((N + 255) // 256) + 8 * T, T
 
 
 def splat_bwd_with_list(rays, xs, ys, G, variant, per_image=False):

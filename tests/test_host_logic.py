@@ -77,8 +77,8 @@ def test_abi_rejects_bad_arguments_without_launching():
     assert lib.helio_fwd_scratch_bytes(512, 2000, 512, 0) == 2 * t + 16 * 512 * 4 * 2000
     assert lib.helio_fwd_scratch_bytes(512, 2000, 512, 6) == 0 and lib.helio_fwd_scratch_bytes(512, 2000, 512, 7) == 0
     lists = 2 * 512 * 2                   # one per (pass, image, 256-wide c tile) at R = 512
-    assert lib.helio_bwd_scratch_bytes(512, 2000, 512, 0) == 4 * lists + 4 * lists * 2000 + 256 + 8 * lists * 8
-    assert lib.helio_bwd_scratch_bytes(512, 5000, 256, 0) == 4 * 512 + 4 * 512 * 5000 + 256 + 8 * 512 * 20     # one per image
+    assert lib.helio_bwd_scratch_bytes(512, 2000, 512, 0) == 4 * lists + 4 * lists * 2000 + 256 + 8 * lists * 8 + 8 * lists
+    assert lib.helio_bwd_scratch_bytes(512, 5000, 256, 0) == 4 * 512 + 4 * 512 * 5000 + 256 + 8 * 512 * 20 + 8 * 512     # one per image
     # the small-tile kernel: lists only with footprint work enough to carry the launches in front of it
     assert lib.helio_bwd_scratch_bytes(32, 5000, 64, 0) == 0 and lib.helio_bwd_scratch_bytes(256, 5000, 64, 0) > 0
     assert lib.helio_bwd_scratch_bytes(4, 5000, 256, 0) > 0

@@ -23,7 +23,7 @@ mode = os.environ.get("CULL", "1")          # 1: the lists the size query asks f
 nb = lib.helio_bwd_scratch_bytes(w.B, w.N, w.R, 2) if mode != "0" else 0
 if mode == "image":
     pad = lambda n: (n + 255) // 256 * 256      # noqa: E731
-    nb = min(nb, pad(4 * w.B) + pad(4 * w.B * w.N) + 256 + 8 * w.B * ((w.N + 255) // 256))
+    nb = min(nb, pad(4 * w.B) + pad(4 * w.B * w.N) + 256 + 8 * w.B * ((w.N + 255) // 256) + 8 * w.B)
 scratch = torch.empty(max(nb, 1), dtype=torch.uint8, device=dev)
 args = (w.B, w.N, w.R, rays.data_ptr(), f._xs.data_ptr(), f._ys.data_ptr(), G.data_ptr(), mom.data_ptr(), 2,
         scratch.data_ptr() if nb else None, nb, native._stream())

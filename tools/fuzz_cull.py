@@ -54,7 +54,7 @@ for case in range(cases):
         sizes = [(1, 1)] + ([(ct, 2)] if v == 2 and R > 128 and 2 <= ct <= 8 else [])     # one list per image; per (pass, c tile)
         for lists_per_image, sets in sizes:
             T = B * lists_per_image * sets
-            need = pad(4 * T) + pad(4 * T * N) + 256 + 8 * T * ((N + 255) // 256)
+            need = pad(4 * T) + pad(4 * T * N) + 256 + 8 * T * ((N + 255) // 256) + 8 * T
             scratch = torch.full((need,), 0x55, dtype=torch.uint8, device=dev)
             mom = torch.full_like(dense, float("nan"))
             rc = lib.helio_splat_bwd(B, N, R, rays.data_ptr(), f._xs.data_ptr(), f._ys.data_ptr(), G.data_ptr(), mom.data_ptr(), v,
