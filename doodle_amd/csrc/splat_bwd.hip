@@ -176,7 +176,9 @@ splat_bwd_mfma_body(int B, int N, int R, const float* __restrict__ rays, const f
     // WR = ray blocks of 64 per workgroup: 4 → 256 rays; 2 → the 128-ray form for the LAST tile of a list when it holds
     // at most 128 rays (8 waves: the slab is staged by half the threads, the factor table and the MFMAs are half) —
     // a list's last tile is half empty on average, and lists are short (≈1100 rays at config 4: cull.h)
-    constexpr int KC = 64, T = 64 * WR, TC = 64 * WC, NT = 64 * WC * WR, KPT = KC / WC, NV = KC * TC / NT;
+    // (the 128-ray form stages 32 k at a time: the same 16 slab values per thread as the 256-ray form, 50 KB of LDS and —
+    // held to 128 registers by its launch bounds — two workgroups per CU, each in the other's producer phase)
+    constexpr int KC = WR == 2 ? 32 : 64, T = 64 * WR, TC = 64 * WC, NT = 64 * WC * WR, KPT = KC / WC, NV = KC * TC / NT;
     constexpr int LDG = PASS == 0 ? TC + 4 : TC + 1, LD = PASS == 0 ? T + 4 : T + 1;
     extern __shared__ __attribute__((aligned(16))) float smem[];   // sG[KC][LDG] sF[KC][LD] ccoord[TC]
     float* __restrict__ sCc = smem + KC * (LDG + LD);
@@ -242,7 +244,7 @@ splat_bwd_mfma_body(int B, int N, int R, const float* __restrict__ rays, const f
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
                 const int idx = tid + NT * v;
-                const int k = PASS == 0 ? idx / TC : idx & 63, c = PASS == 0 ? idx % TC : idx >> 6;
+                const int k = PASS == 0 ? idx / TC : idx & (KC - 1), c = PASS == 0 ? idx % TC : idx / KC;
                 const int row = PASS == 0 ? k0 + k : c0 + c, col = PASS == 0 ? c0 + c : k0 + k;
                 gv[v] = (row < R && col < R) ? G[(long)row * R + col] : 0.0f;
             }
@@ -261,7 +263,7 @@ splat_bwd_mfma_body(int B, int N, int R, const float* __restrict__ rays, const f
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
                 const int idx = tid + NT * v;
-                const int k = PASS == 0 ? idx / TC : idx & 63, c = PASS == 0 ? idx % TC : idx >> 6;
+                const int k = PASS == 0 ? idx / TC : idx & (KC - 1), c = PASS == 0 ? idx % TC : idx / KC;
                 dst[k * LDG + c] = gv[v];
             }
         }
@@ -395,7 +397,7 @@ splat_bwd_mfma(int B, int N, int R, const float* __restrict__ rays, const float*
 // map_stride: where pass 1's lists and its part of the work map start when every (pass, c tile) has lists of its
 // own (cull.h), else unused.  WR = 2: the 128-ray form, run over the map of short last tiles.
 template <bool VEC, int WC, int WR>
-__global__ void __launch_bounds__(64 * WC * WR)
+__global__ void __launch_bounds__(64 * WC * WR, 4)          // four waves a SIMD: one 16-wave workgroup or two 8-wave ones per CU
 splat_bwd_mfma_both(int B, int N, int R, const float* __restrict__ rays, const float* __restrict__ xs,
                     const float* __restrict__ ys, const float* __restrict__ gimg, float* __restrict__ moments,
                     const int* __restrict__ live_counts, const int* __restrict__ live_idx, const int* __restrict__ live_total,
@@ -824,8 +826,8 @@ static void launch_bwd_mfma_v(int B, int N, int R, const float* rays, const floa
 template <bool VEC, int WC, int WR>
 static void launch_bwd_mfma_both_v(int B, int N, int R, const float* rays, const float* xs, const float* ys,
                                    const float* gimg, float* moments, hipStream_t st, CullBwd c) {
-    constexpr int TC = 64 * WC, T = 64 * WR;
-    const size_t lds = (64 * ((TC + 4) + (T + 4)) + TC + 64) * sizeof(float);      // pass 0's pitches: the larger of the two
+    constexpr int TC = 64 * WC, T = 64 * WR, KC = WR == 2 ? 32 : 64;
+    const size_t lds = (KC * ((TC + 4) + (T + 4)) + TC + 64) * sizeof(float);      // pass 0's pitches: the larger of the two
     static bool configured = false;
     if (!configured) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(splat_bwd_mfma_both<VEC, WC, WR>),
