@@ -881,11 +881,14 @@ static void launch_bwd_mfma_both(int B, int N, int R, const float* rays, const f
 }
 
 // the last tile of a list in the 128-ray form when it holds at most 128 rays (cull.h): only with the one-launch form of
-// the 256-wide tiles, and HELIO_BWD_TAIL=0 switches it off (A/B runs)
-static bool bwd_split_tails(int R) {
+// the 256-wide tiles, and only where the short tiles — about every other list's — can fill the chip: their launch
+// runs AFTER the 256-ray launch, so a handful of them is a workgroup's duration of pure latency instead of a place in
+// the last round of that launch (B = 32, N = 5000, R = 256 at err 90: 64 lists, 312 → 368 µs; B = 256, N = 1000,
+// R = 256: 512 lists, 587 → 460 µs; config 4: 4096 lists).  HELIO_BWD_TAIL=0 switches it off (A/B runs).
+static bool bwd_split_tails(int R, long lists_both_passes) {
     static const bool off = [] { const char* e = getenv("HELIO_BWD_TAIL"); return e && e[0] == '0'; }();
     static const bool two_launches = [] { const char* e = getenv("HELIO_BWD_PASSES"); return e && e[0] == '2'; }();
-    return R > 128 && !off && !two_launches;
+    return R > 128 && !off && !two_launches && lists_both_passes >= 512;
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -1440,7 +1443,7 @@ int launch_splat_bwd(int B, int N, int R, const float* rays, const float* xs, co
             int ct = cull_bwd_ct(2, B, N, R);
             if (scratch_bytes < cull_bwd_bytes(B, N, ct)) ct = 1;
             if (scratch_bytes >= cull_bwd_bytes(B, N, ct))
-                cull = launch_cull_bwd(B, N, R, splat_bwd_blocks(R), R <= 128 ? 128 : 256, ct, /*with_map=*/true, bwd_split_tails(R), rays, xs, ys,
+                cull = launch_cull_bwd(B, N, R, splat_bwd_blocks(R), R <= 128 ? 128 : 256, ct, /*with_map=*/true, bwd_split_tails(R, 2l * B * ct), rays, xs, ys,
                                        moments, scratch, st);
         }
         launch_bwd_mfma_both(B, N, R, rays, xs, ys, gimg, moments, st, cull);
