@@ -397,7 +397,9 @@ splat_bwd_mfma(int B, int N, int R, const float* __restrict__ rays, const float*
 // map_stride: where pass 1's lists and its part of the work map start when every (pass, c tile) has lists of its
 // own (cull.h), else unused.  WR = 2: the 128-ray form, run over the map of short last tiles.
 template <bool VEC, int WC, int WR>
-__global__ void __launch_bounds__(64 * WC * WR, 4)          // four waves a SIMD: one 16-wave workgroup or two 8-wave ones per CU
+// (launch bounds — 256-wide tiles: four waves a SIMD, one 16-wave workgroup or two 8-wave ones per CU; 128-wide: two, one
+// 8-wave workgroup with its 101 KB of LDS)
+__global__ void __launch_bounds__(64 * WC * WR, WC == 4 ? 4 : 2)
 splat_bwd_mfma_both(int B, int N, int R, const float* __restrict__ rays, const float* __restrict__ xs,
                     const float* __restrict__ ys, const float* __restrict__ gimg, float* __restrict__ moments,
                     const int* __restrict__ live_counts, const int* __restrict__ live_idx, const int* __restrict__ live_total,
@@ -863,15 +865,20 @@ static void launch_bwd_mfma(int B, int N, int R, const float* rays, const float*
     }
 }
 
-// both passes: one launch for the 256-wide tiles; the 128-wide form (R <= 128) keeps two — merged, pass 0 would run
-// at pass 1's register count (165 against 113: three waves a SIMD instead of four)
+// both passes in one launch (HELIO_BWD_PASSES=2: two, for A/B runs)
 static void launch_bwd_mfma_both(int B, int N, int R, const float* rays, const float* xs, const float* ys,
                                  const float* gimg, float* moments, hipStream_t st, CullBwd cull) {
     static const bool two_launches = [] { const char* e = getenv("HELIO_BWD_PASSES"); return e && e[0] == '2'; }();   // A/B runs
-    if (R <= 128 || two_launches) {
+    const bool vec = (R & 3) == 0;
+    if (two_launches) {
         launch_bwd_mfma<0>(B, N, R, rays, xs, ys, gimg, moments, st, cull);
         launch_bwd_mfma<1>(B, N, R, rays, xs, ys, gimg, moments, st, cull);
-    } else if ((R & 3) == 0) {
+    } else if (R <= 128) {
+        // 128-wide c tiles: one 8-wave workgroup per CU either way (101 KB of LDS), so pass 0 loses nothing by running
+        // at pass 1's register count
+        if (vec) launch_bwd_mfma_both_v<true, 2, 4>(B, N, R, rays, xs, ys, gimg, moments, st, cull);
+        else launch_bwd_mfma_both_v<false, 2, 4>(B, N, R, rays, xs, ys, gimg, moments, st, cull);
+    } else if (vec) {
         launch_bwd_mfma_both_v<true, 4, 4>(B, N, R, rays, xs, ys, gimg, moments, st, cull);
         if (cull.tail_map) launch_bwd_mfma_both_v<true, 4, 2>(B, N, R, rays, xs, ys, gimg, moments, st, cull);
     } else {
