@@ -1343,11 +1343,21 @@ int splat_bwd_blocks(int R) { return (R + BW_JT - 1) / BW_JT; }
 // 4 = few-ray streaming kernel, 5 = split-bf16 MFMA kernels (opt-in), 6 / 7 = the small kernel with 4 / 8 waves
 // the kernel family variant 0 stands for at this size
 static int splat_bwd_choice(int B, int N, int R) {
-    const long wgs = (long)B * ((R + 255) / 256) * ((N + 255) / 256);
-    // tools/sweep_bwd.py, tools/sweep_bwd_mid.py: the LDS-tile kernels (256 rays × 256 c, or × 128 c
-    // for images of at most 128 pixels across) pay off once there are enough tiles; below 65 pixels
-    // even the narrow tile is half padding and the small-tile kernel is its equal
-    return splat_bwd_is_few(B, N) ? 4 : (R > 64 && N >= 96 && wgs >= 128) ? 2 : 3;
+    if (splat_bwd_is_few(B, N)) return 4;
+    // tools/sweep_bwd.py, tools/sweep_bwd_mid.py: the LDS-tile kernels (256 rays × 256 c, or × 128 c for images of at
+    // most 128 pixels across) against the small-tile kernel; below 65 pixels even the narrow tile is half padding and
+    // the small-tile kernel is its equal.  Both passes of the LDS-tile kernels are ONE launch of 2·tiles workgroups, one
+    // per CU at a time, so its duration is a step function of its rounds of 256 (23 / 69 / 130 µs a round at R = 128 /
+    // 256 / 512) while the small-tile kernel's grows with the work: the LDS tiles win where their rounds are well
+    // filled — by workgroups and, inside a tile, by rays (N = 300 is two ray tiles, the second 17 % full).  Measured
+    // crossover: a fill of ≈0.6 (tiles = 80 of N ≥ 1000: 23 against 29 µs at R = 128, 69 / 80 at 256, 132 / 145 at 512;
+    // tiles = 64: 23 / 20, 69 / 54, 130 / 103; N = 300, tiles = 192: 44 / 38, 136 / 118, 260 / 207).
+    if (R <= 64 || N < 96) return 3;
+    const long ray_tiles = (N + 255) / 256, tiles = (long)B * (R <= 128 ? 1 : (R + 255) / 256) * ray_tiles;
+    if (tiles >= 512) return 2;
+    const long rounds = (2 * tiles + 255) / 256;
+    const double fill = (double)(2 * tiles) / (256.0 * rounds) * N / (256.0 * ray_tiles);
+    return fill >= 0.58 ? 2 : 3;
 }
 
 // the small-tile kernel's form without a split of the contracted axis (4 independent waves of 64 rays each): from
@@ -1375,7 +1385,7 @@ static bool cull_bwd_wanted(int variant, int B, int N, int R) {
     if (variant == 0) variant = splat_bwd_choice(B, N, R);
     if (!cull_bwd_possible(variant, B, N, R)) return false;
     const long ray_tiles = (N + 255) / 256;
-    if (variant == 2) return (long)B * ((R + (R <= 128 ? 127 : 255)) / (R <= 128 ? 128 : 256)) * ray_tiles > 256;   // 1 tile per CU
+    if (variant == 2) return 2l * B * ((R + (R <= 128 ? 127 : 255)) / (R <= 128 ? 128 : 256)) * ray_tiles > 256;   // (both passes are one launch)
     // (both passes in one launch; two 4-wave workgroups fit a CU; and enough footprint work for the ≈15 µs of the
     // launches in front to be small beside it — grid A/B at err 90 / σs 0.01: B = 32, N = 5000, R = 64, 45 µs dense:
     // 54 µs with lists; B = 4, N = 5000, R = 256, 85 µs: 72 µs; B = 256, N = 5000, R = 64, 325 µs: 271 µs)

@@ -422,9 +422,11 @@ def test_small_tile_backward_with_lists_equals_the_dense_one_bit_for_bit(N, B, R
     dense launch — forced (variant 3) and as the size rule chooses —, the gradient through render_bwd too."""
     from doodle_amd import native
     ops = native.get_ops()
-    assert ops.lib.helio_bwd_scratch_bytes(2, 5000, 512, 0) > 0          # 640 workgroups of the small-tile kernel: a list
+    # the size query (the LDS-tile kernels' two passes are ONE launch): a list where that launch is more than one round
+    assert ops.lib.helio_bwd_scratch_bytes(256, 5000, 64, 0) > 0         # R <= 64: the small-tile kernel, 10240 workgroups
     assert ops.lib.helio_bwd_scratch_bytes(1, 5000, 256, 0) == 0 and ops.lib.helio_bwd_scratch_bytes(B, N, R, 6) == 0
-    assert ops.lib.helio_bwd_scratch_bytes(4, 5000, 512, 0) == 0       # 160 tiles of the LDS-tile kernel: one round, no list
+    assert ops.lib.helio_bwd_scratch_bytes(2, 5000, 512, 0) == 0         # 80 tiles a pass of the LDS-tile kernel: one round
+    assert ops.lib.helio_bwd_scratch_bytes(4, 5000, 512, 0) > 0          # 160 a pass: 320 workgroups, more than one round
     f, suns, act, rays = field_and_rays(N, B, R, sigma, err, seed=N + R + B + 5, span=40.0)
     G = torch.randn(B, R, R, device=DEV, generator=torch.Generator(device=DEV).manual_seed(9))
     dense = ops.splat_bwd(rays, f._xs, f._ys, G, variant=3, cull=False)

@@ -81,7 +81,8 @@ def test_abi_rejects_bad_arguments_without_launching():
     assert lib.helio_bwd_scratch_bytes(512, 5000, 256, 0) == 4 * 512 + 4 * 512 * 5000 + 256 + 8 * 512 * 20 + 8 * 512     # one per image
     # the small-tile kernel: lists only with footprint work enough to carry the launches in front of it
     assert lib.helio_bwd_scratch_bytes(32, 5000, 64, 0) == 0 and lib.helio_bwd_scratch_bytes(256, 5000, 64, 0) > 0
-    assert lib.helio_bwd_scratch_bytes(4, 5000, 256, 0) > 0
+    # the LDS-tile kernels (both passes one launch): lists where that launch is more than one round of the chip
+    assert lib.helio_bwd_scratch_bytes(4, 5000, 256, 0) == 0 and lib.helio_bwd_scratch_bytes(4, 5000, 512, 0) > 0
     assert lib.helio_bwd_scratch_bytes(512, 2000, 512, 5) == 0 and lib.helio_bwd_scratch_bytes(512, 200, 512, 0) == 0
     assert lib.helio_notify_wait(None, 1, 0.0) == -1 and lib.helio_notify_destroy(None) == 0
 

@@ -20,7 +20,7 @@ for B, N, R in ((1, 5000, 512), (2, 5000, 512), (4, 5000, 512), (8, 2000, 512), 
     G = torch.randn(B, R, R, device=dev)
     with torch.no_grad():
         rays = ops.render_fwd(f.heliostat_positions, sd, normals, trig, stride, f._plane, f._xs, f._ys)[3]
-        tf = time_kernel(lambda: ops.render_fwd(f.heliostat_positions, sd, normals, trig, stride, f._plane, f._xs, f._ys, rays=rays), 30)
-        tb = time_kernel(lambda: ops.render_bwd(f.heliostat_positions, sd, normals, trig, stride, f._plane, rays, f._xs, f._ys, G, None, None), 30)
+        tf = time_kernel(lambda: ops.render_fwd(f.heliostat_positions, sd, normals, trig, stride, f._plane, f._xs, f._ys, rays=rays), 30, repeats=3)
+        tb = time_kernel(lambda: ops.render_bwd(f.heliostat_positions, sd, normals, trig, stride, f._plane, rays, f._xs, f._ys, G, None, None), 30, repeats=3)
     print(f"B={B:3d} N={N:5d} R={R:4d}: fwd {tf*1e6:7.1f} us (variant {ops.render_choice(B, N, R):2d}, scratch {ops.lib.helio_fwd_scratch_bytes(B, N, R, 0):9d} B)   "
           f"bwd {tb*1e6:7.1f} us (scratch {ops.lib.helio_bwd_scratch_bytes(B, N, R, 0):8d} B)", flush=True)
