@@ -24,7 +24,7 @@ for R in (64, 128, 256, 512):
                 if v == 4 and N > 64:
                     res[v] = float("inf")
                     continue
-                args = (B, N, R, rays.data_ptr(), xs.data_ptr(), ys.data_ptr(), G.data_ptr(), mom.data_ptr(), v, st)
+                args = (B, N, R, rays.data_ptr(), xs.data_ptr(), ys.data_ptr(), G.data_ptr(), mom.data_ptr(), v, None, 0, st)
                 iters = max(3, min(100, int(1e11 / (2.0 * B * N * R * R))))
                 res[v] = time_kernel(lambda: lib.helio_splat_bwd(*args), iters, warm=2) * 1e6
             best = min((1, 2, 3, 4), key=lambda v: res[v])

@@ -20,7 +20,7 @@ for B, N, R in shapes:
     G = torch.randn(B, R, R, device=dev)
     mom = torch.empty(B, lib.helio_splat_bwd_blocks(R), N, native.MOMENT_STRIDE, device=dev)
     for v, out in ((3, out3), (2, out2)):
-        args = (B, N, R, rays.data_ptr(), xs.data_ptr(), ys.data_ptr(), G.data_ptr(), mom.data_ptr(), v, st)
+        args = (B, N, R, rays.data_ptr(), xs.data_ptr(), ys.data_ptr(), G.data_ptr(), mom.data_ptr(), v, None, 0, st)
         iters = max(5, min(100, int(2e11 / (4.0 * B * N * R * R))))
         out.append(f"{min(time_kernel(lambda: lib.helio_splat_bwd(*args), iters, warm=2) for _ in range(2)) * 1e6:7.1f}")
 print(f"NRB={os.environ.get('HELIO_BWD_NRB', 'rule'):5s} v3 " + " ".join(out3), flush=True)

@@ -19,7 +19,7 @@ for B, N, R in [(64, 1000, 128), (128, 1000, 128), (256, 1000, 64), (512, 1000, 
     img = torch.empty(B, R, R, device=dev)
     res = {}
     for v in (3, 5, 6, 9):
-        args = (B, N, R, rays.data_ptr(), xs.data_ptr(), ys.data_ptr(), img.data_ptr(), v, st)
+        args = (B, N, R, rays.data_ptr(), xs.data_ptr(), ys.data_ptr(), img.data_ptr(), v, None, 0, st)
         iters = max(5, min(100, int(3e11 / (2.0 * B * N * R * R))))
         res[v] = min(time_kernel(lambda: lib.helio_splat_fwd(*args), iters, warm=2) for _ in range(2)) * 1e6
     best = min(res, key=res.get)

@@ -16,7 +16,7 @@ for B, N, R in [(25, 1000, 128), (25, 1000, 256), (25, 5000, 256), (40, 1000, 25
     xs = torch.linspace(-7.5, 7.5, R, device=dev); ys = xs.clone()
     rays = torch.rand(B, N, 4, device=dev) * torch.tensor([10., 10., 0.5, 0.01], device=dev) - torch.tensor([5., 5., 0., 0.], device=dev)
     img = torch.empty(B, R, R, device=dev)
-    args = (B, N, R, rays.data_ptr(), xs.data_ptr(), ys.data_ptr(), img.data_ptr(), 9, st)
+    args = (B, N, R, rays.data_ptr(), xs.data_ptr(), ys.data_ptr(), img.data_ptr(), 9, None, 0, st)
     iters = max(5, min(100, int(3e11 / (2.0 * B * N * R * R))))
     t = min(time_kernel(lambda: lib.helio_splat_fwd(*args), iters, warm=2) for _ in range(2)) * 1e6
     out.append(f"{t:7.1f}")

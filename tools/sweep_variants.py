@@ -20,7 +20,7 @@ for R in (64, 128, 256, 512):
             img = torch.empty(B, R, R, device=dev)
             res = {}
             for v in (3, 4, 5, 6, 0):
-                args = (B, N, R, rays.data_ptr(), xs.data_ptr(), ys.data_ptr(), img.data_ptr(), v, st)
+                args = (B, N, R, rays.data_ptr(), xs.data_ptr(), ys.data_ptr(), img.data_ptr(), v, None, 0, st)
                 flops = 2.0 * B * N * R * R
                 iters = max(3, min(100, int(3e11 / flops)))
                 res[v] = time_kernel(lambda: lib.helio_splat_fwd(*args), iters, warm=2) * 1e6
