@@ -394,3 +394,38 @@ def test_library_switches_change_the_size_rules_they_name():
     assert run(HELIO_CULL="0") == [0, 0, 16, required, 0, 0]           # dense everywhere; the split sum keeps its partial images
     fwd2, bwd2, choice2, required2, _, _ = run(HELIO_SPLIT="0")
     assert choice2 == 9 and required2 == 0 and fwd2 == fwd and bwd2 == bwd
+
+
+def test_scratch_size_queries_are_consistent_over_random_sizes():
+    """helio_*_scratch_bytes are host code: over random sizes they are never negative, the required part never exceeds
+    the whole, the backward size is 0 or exactly one of the two layouts of csrc/cull.h (one list per image; one per
+    (pass, 256-wide c tile) where an image is 2..8 tiles wide), and forcing a variant that takes no lists gives 0."""
+    import random
+    from doodle_amd import native
+    lib = native.load_library()
+    rng = random.Random(7)
+    pad = lambda n: (n + 255) // 256 * 256  # noqa: E731
+
+    def bwd_layout(B, N, lists_per_image, sets):
+        T = B * lists_per_image * sets
+        return pad(4 * T) + pad(4 * T * N) + 256 + 8 * T * ((N + 255) // 256) + 8 * T
+
+    seen_lists = seen_ctile = 0
+    for _ in range(3000):
+        B = rng.choice([1, 2, 4, 7, 25, 32, 100, 256, 512, 4096])
+        N = rng.choice([1, 50, 96, 200, 257, 300, 1000, 1024, 2000, 5000, 20000])
+        R = rng.choice([16, 64, 65, 100, 128, 129, 256, 257, 512, 1000, 2048, 2100])
+        fwd, req, bwd = lib.helio_fwd_scratch_bytes(B, N, R, 0), lib.helio_fwd_scratch_required(B, N, R, 0), lib.helio_bwd_scratch_bytes(B, N, R, 0)
+        assert 0 <= req <= fwd and bwd >= 0 and fwd % 16 == 0
+        if bwd:
+            ct = -(-R // 256)
+            per_image, per_ctile = bwd_layout(B, N, 1, 1), bwd_layout(B, N, ct, 2)
+            assert bwd == per_image or (R > 128 and 2 <= ct <= 8 and bwd == per_ctile), (B, N, R, bwd)
+            seen_lists += 1
+            seen_ctile += bwd == per_ctile and ct > 1
+            assert N > 256
+        for v in (1, 4, 5, 6, 7, 8):
+            assert lib.helio_bwd_scratch_bytes(B, N, R, v) == 0
+        for v in (1, 6, 7, 8, 10, 11, 12, 13):
+            assert lib.helio_fwd_scratch_bytes(B, N, R, v) == 0
+    assert seen_lists > 100 and seen_ctile > 20
