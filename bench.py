@@ -129,7 +129,7 @@ def time_interleaved(fns, iters, warm=2):
     return [sum(e0.elapsed_time(e1) for e0, e1 in ps) * 1e-3 / iters for ps in pairs]
 
 
-def preheat(fn, seconds, burst=None, fence=None, dist=None, device=None):
+def preheat(fn, seconds, burst=None, fence=None, dist=None, device=None, clock=time.perf_counter):
     """Run ``fn`` for ``seconds`` of wall time.  With ``burst`` and ``fence``: in bursts of ``burst`` calls
     followed by ``fence()`` — the pattern of the timed region itself.  (Measured, tools/launch_jitter.py:
     after a long run of unsynchronised launches the first three or four "20 calls + synchronize" samples
@@ -140,16 +140,19 @@ def preheat(fn, seconds, burst=None, fence=None, dist=None, device=None):
     number of bursts: whether to go on is agreed by all ranks (an all-reduce of each rank's own clock
     verdict) — a loop that every rank ends by its own clock runs one burst more on some ranks than on others
     whenever a burst ends within the ranks' start skew of the deadline, and the job hangs in the unmatched
-    barrier (found by the two-rank rehearsal, ``--rehearse``: one run in six)."""
-    t0 = time.perf_counter()
+    barrier (found by the two-rank rehearsal, ``--rehearse``: one run in six).  ``clock``: the wall clock (tests
+    inject per-rank clocks that disagree about the deadline: tests/test_bench_preheat.py).  → bursts run."""
+    t0 = clock()
+    bursts = 0
     while True:
-        go = time.perf_counter() - t0 < seconds
+        go = clock() - t0 < seconds
         if dist is not None:
             verdict = torch.tensor([1 if go else 0], dtype=torch.int32, device=device)
             dist.all_reduce(verdict, op=dist.ReduceOp.MIN)
             go = bool(verdict.item())
         if not go:
-            return
+            return bursts
+        bursts += 1
         if burst is None:
             fn()
         else:

@@ -53,8 +53,7 @@ class ImageGather:
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.comm = None
         self.stream = None
-        auto = transport == "auto"
-        if auto:
+        if transport == "auto":
             transport = os.environ.get("HELIO_COMM") or (
                 "rccl" if (torch.cuda.is_available() and dist.is_initialized()
                            and dist.get_backend(group) == "nccl") else "torch")
@@ -62,10 +61,15 @@ class ImageGather:
             try:
                 self._init_rccl()
             except (RuntimeError, OSError) as e:
-                if not auto:
-                    raise
-                import warnings
-                warnings.warn(f"libhelio_comm RCCL transport unavailable ({e}); using torch.distributed")
+                # no silent change of transport: on an 8-GPU run it would change what is measured, and "auto" picks
+                # RCCL only where it is expected to work (GPUs, an nccl process group).  The other transport is one
+                # explicit word away.
+                raise RuntimeError(
+                    f"ImageGather: the RCCL transport (libhelio_comm.so) could not be set up: {e}.  Build it with "
+                    "`python -m doodle_amd.build`, or ask for the torch.distributed transport explicitly "
+                    "(transport=\"torch\" / HELIO_COMM=torch)") from e
+        elif transport != "torch":
+            raise ValueError(f"ImageGather: unknown transport {transport!r} (auto, rccl, torch)")
         self.transport = "rccl" if self.comm is not None else "torch"
 
     def _init_rccl(self):

@@ -50,6 +50,7 @@ void launch_geometry_bwd_losses(int, int, int, const float*, const float*, const
                                 hipStream_t);
 long env_step_fused_workspace(int, int);
 bool render_bwd_is_fused(int, int, int);
+int render_bwd_choice(int, int, int);
 bool launch_render_bwd_fused(int, int, int, const float*, const float*, const float*, const float*, const float*,
                              const float*, const float*, const float*, long, const helio_plane*, const float*,
                              const float*, float*, const float*, const float*, const float*, const float*,
@@ -161,6 +162,11 @@ int helio_render_fwd(int B, int N, int R, const float* helios_d, const float* su
                                             helio::splat_fwd_scratch_required(B, N, R, variant))
                                      : fail(HELIO_E_INVALID, "render_fwd: unknown variant %d", variant);
     return after_launch("render_fwd");
+}
+
+int helio_render_bwd_choice(int B, int N, int R) {
+    if (!sizes_ok(B, N) || R < 1 || R > 16384) return 0;
+    return helio::render_bwd_choice(B, N, R);
 }
 
 int helio_render_fwd_launches(int B, int N, int R) {

@@ -274,6 +274,15 @@ struct RenderCtx {
         fp(helios, "heliostat_positions"); fp(xs, "xs"); fp(ys, "ys"); fp(trig, "trig");
     }
     void bind_errors(const at::Tensor& e) { errs = e; errs_version = (int64_t)e._version(); }
+    // the receiver's tensors the plane record was made from (HelioField.target_position, target_normal, plane_u,
+    // plane_v): render_checked declines once one of them has been written in place
+    std::vector<at::Tensor> receiver;
+    std::vector<int64_t> receiver_versions;
+    void bind_receiver(const std::vector<at::Tensor>& ts) {
+        receiver = ts;
+        receiver_versions.clear();
+        for (const at::Tensor& t : ts) receiver_versions.push_back((int64_t)t._version());
+    }
 
     struct Outputs { at::Tensor image, actual, refl; };
     // image [B,R,R] ([R,R] when !batched), actual [B,N,3], refl [B·N,3] (the reference's monitor shape)
@@ -297,30 +306,26 @@ struct RenderCtx {
         }
         return o;
     }
-    // HelioField.render's whole no-autograd call for the arguments as the caller passed them, in the reference's
-    // return shapes: (image, actual) or (image, actual, refl [B·N,3]); a 1-D sun gives image [R,R], actual [1,N,3].
-    // None — the caller then takes the general path — unless: both are plain float32 tensors on the field's device,
-    // contiguous, of matching sizes; no gradient is being recorded for the action; the error tensor this context
-    // was bound to has not been written since; nothing the context was built from has been reassigned
-    // (generation); and the batch size is one this context's trig table serves.
-    py::object render_checked(py::handle sun_h, py::handle action_h, bool want_refl) {
-        if (!THPVariable_CheckExact(sun_h.ptr()) || !THPVariable_CheckExact(action_h.ptr())) return py::none();
-        const at::Tensor& sun = THPVariable_Unpack(sun_h.ptr());
-        const at::Tensor& action = THPVariable_Unpack(action_h.ptr());
-        if (generation != g_generation.load(std::memory_order_relaxed) || !errs.defined() ||
-            (int64_t)errs._version() != errs_version)
-            return py::none();
-        if (action.requires_grad() && at::GradMode::is_enabled()) return py::none();
-        const int64_t N = helios.size(0), R = xs.size(0);
+    // ONE no-autograd render path: the argument test both entry points share …
+    // (plain float32 tensors on the field's device, contiguous, sun [B,3] (or [3] when !batched), B·N·3 action values,
+    // and a batch size this context's trig table serves) → B, or -1: the caller takes the general path
+    int64_t conforming_batch(const at::Tensor& sun, const at::Tensor& action, bool strict_trig) const {
+        const int64_t N = helios.size(0);
         const bool batched = sun.dim() == 2;
-        if (!(batched || (sun.dim() == 1 && sun.size(0) == 3))) return py::none();
+        if (!(batched ? sun.size(1) == 3 : (sun.dim() == 1 && sun.size(0) == 3))) return -1;
         const int64_t B = batched ? sun.size(0) : 1;
-        if (batched && sun.size(1) != 3) return py::none();
-        if (trig_b_stride == 0 ? B != 1 : (B < 2 || trig.numel() < B * N * 4)) return py::none();
         if (!(sun.scalar_type() == at::kFloat && action.scalar_type() == at::kFloat && sun.device() == helios.device() &&
               action.device() == helios.device() && sun.is_contiguous() && action.is_contiguous() &&
               action.numel() == B * N * 3))
-            return py::none();
+            return -1;
+        if (trig_b_stride != 0 && trig.numel() < B * N * 4) return -1;
+        // the memoised entry also holds the table to the batch sizes the reference's rule gives it (:340-353)
+        if (strict_trig && (trig_b_stride == 0 ? B != 1 : B < 2)) return -1;
+        return B;
+    }
+    // … and the call itself: allocation, scratch, helio_render_fwd
+    Outputs launch(const at::Tensor& sun, const at::Tensor& action, int64_t B, bool want_refl, bool batched) {
+        const int64_t N = helios.size(0), R = xs.size(0);
         Outputs o = outputs(B, N, R, want_refl, batched);
         if (!rays_ws.defined() || rays_ws.size(0) != B) rays_ws = at::empty({B, N, HELIO_RAY_STRIDE}, helios.options());
         const Scratch sc = scratch_for(B, N, R);
@@ -330,29 +335,36 @@ struct RenderCtx {
                                o.actual.data_ptr<float>(), want_refl ? o.refl.data_ptr<float>() : nullptr,
                                rays_ws.data_ptr<float>(), o.image.data_ptr<float>(), (int)variant, sc.p, sc.bytes,
                                cur_stream(helios)));
+        return o;
+    }
+    // HelioField.render's whole no-autograd call for the arguments as the caller passed them, in the reference's
+    // return shapes: (image, actual) or (image, actual, refl [B·N,3]); a 1-D sun gives image [R,R], actual [1,N,3].
+    // None — the caller then takes the general path — unless: the arguments conform (conforming_batch); no gradient
+    // is being recorded for the action; neither the error tensor this context was bound to nor a tensor of the
+    // receiver has been written since; nothing the context was built from has been reassigned (generation).
+    py::object render_checked(py::handle sun_h, py::handle action_h, bool want_refl) {
+        if (!THPVariable_CheckExact(sun_h.ptr()) || !THPVariable_CheckExact(action_h.ptr())) return py::none();
+        const at::Tensor& sun = THPVariable_Unpack(sun_h.ptr());
+        const at::Tensor& action = THPVariable_Unpack(action_h.ptr());
+        if (generation != g_generation.load(std::memory_order_relaxed) || !errs.defined() ||
+            (int64_t)errs._version() != errs_version)
+            return py::none();
+        for (size_t k = 0; k < receiver.size(); ++k)
+            if ((int64_t)receiver[k]._version() != receiver_versions[k]) return py::none();
+        if (action.requires_grad() && at::GradMode::is_enabled()) return py::none();
+        const int64_t B = conforming_batch(sun, action, /*strict_trig=*/true);
+        if (B < 0) return py::none();
+        Outputs o = launch(sun, action, B, want_refl, sun.dim() == 2);
         if (want_refl) return py::make_tuple(o.image, o.actual, o.refl);
         return py::make_tuple(o.image, o.actual);
     }
-    // → (image [B,R,R], actual [B,N,3]) or, with want_refl, (image, actual, refl [B,N,3]); None when the
-    // tensors need a dtype / device / layout fix-up (the caller then takes the general path)
+    // → (image [B,R,R], actual [B,N,3]) or, with want_refl, (image, actual, refl [B,N,3]) for a [B,3] sun; None when
+    // the tensors need a dtype / device / layout fix-up (the caller then takes the general path)
     py::object render(const at::Tensor& sun, const at::Tensor& action, bool want_refl) {
-        const int64_t N = helios.size(0), R = xs.size(0);
-        if (!(sun.dim() == 2 && sun.scalar_type() == at::kFloat && action.scalar_type() == at::kFloat &&
-              sun.device() == helios.device() && action.device() == helios.device() && sun.is_contiguous() &&
-              action.is_contiguous() && action.numel() == sun.size(0) * N * 3))
-            return py::none();
-        const int64_t B = sun.size(0);
-        if (trig_b_stride != 0 && trig.numel() < B * N * 4) return py::none();
-        Outputs o = outputs(B, N, R, want_refl, true);
-        if (!rays_ws.defined() || rays_ws.size(0) != B) rays_ws = at::empty({B, N, HELIO_RAY_STRIDE}, helios.options());
-        const Scratch sc = scratch_for(B, N, R);
-        check(helio_render_fwd((int)B, (int)N, (int)R, helios.data_ptr<float>(), sun.data_ptr<float>(),
-                               action.data_ptr<float>(), trig.data_ptr<float>(), (long)trig_b_stride,
-                               reinterpret_cast<const helio_plane*>(plane), xs.data_ptr<float>(), ys.data_ptr<float>(),
-                               o.actual.data_ptr<float>(), want_refl ? o.refl.data_ptr<float>() : nullptr,
-                               rays_ws.data_ptr<float>(), o.image.data_ptr<float>(), (int)variant, sc.p, sc.bytes,
-                               cur_stream(helios)));
-        if (want_refl) return py::make_tuple(o.image, o.actual, o.refl.view({B, N, 3}));
+        const int64_t B = sun.dim() == 2 ? conforming_batch(sun, action, /*strict_trig=*/false) : -1;
+        if (B < 0) return py::none();
+        Outputs o = launch(sun, action, B, want_refl, true);
+        if (want_refl) return py::make_tuple(o.image, o.actual, o.refl.view({B, helios.size(0), 3}));
         return py::make_tuple(o.image, o.actual);
     }
     // Measurement aid (tools/launch_floor.py): wall-clock nanoseconds per repetition of the pieces of
@@ -934,6 +946,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         .def("host_costs", &RenderCtx::host_costs)
         .def("render_checked", &RenderCtx::render_checked)
         .def("bind_errors", &RenderCtx::bind_errors)
+        .def("bind_receiver", &RenderCtx::bind_receiver)
         .def_readonly("trig", &RenderCtx::trig)
         .def_readonly("variant", &RenderCtx::variant);
     m.def("step_losses_fwd", &step_losses_fwd, py::arg("img"), py::arg("target"), py::arg("tx"), py::arg("dmaps"),

@@ -765,7 +765,10 @@ render_bwd_fused_small(int B, int N, int R, const float* __restrict__ rays, cons
 // kernel's regime (not the few-ray one).  HELIO_BWD_FUSED=0 switches the choice off; variant 8 forces it.
 bool render_bwd_is_fused(int B, int N, int R) {
     static const bool off = [] { const char* e = getenv("HELIO_BWD_FUSED"); return e && e[0] == '0'; }();
-    if (off || splat_bwd_is_few(B, N) || R > 256 || (R > 128 && N >= 96)) return false;
+    // (R > 128: round 3 let images of up to 256 pixels in while N < 96 — its CT = 4 form cuts the contracted axis between
+    // two waves only, and tools/rule_regret.py showed it 2.3x behind the two launches there: B = 4, N = 50, R = 256,
+    // 34.6 against ≈15 µs)
+    if (off || splat_bwd_is_few(B, N) || R > 128) return false;
     return (long)B * ((N + 31) / 32) <= 64;
 }
 
@@ -799,13 +802,13 @@ static int bwd_small_ks(int B, int N, int R) {
 }
 
 // ray blocks per wave of the small backward kernel (1, 2 or 4); HELIO_BWD_NRB forces one — tuning runs only
-static int bwd_small_nrb(int B, int N, int R) {
+static int bwd_small_nrb(int N, int ks) {
     static const int forced = [] { const char* e = getenv("HELIO_BWD_NRB"); return e ? atoi(e) : 0; }();
     if (forced == 1 || forced == 2 || forced == 4) return forced;
     // tools/sweep_bwd_nrb.py: two ray blocks per wave are 3–10 % ahead from N = 300 (B = 25: 36.5 → 35.3 µs at
     // N = 1000, R = 128; 110.9 → 101.8 at R = 256), behind below (N = 100: 7.2 → 8.3 µs); four never pay
     // (344 registers: one wave per SIMD).  Same sums per ray: the bits do not change.
-    return (N >= 300 && bwd_small_ks(B, N, R) == 4) ? 2 : 1;
+    return (N >= 300 && ks == 4) ? 2 : 1;
 }
 
 template <int PASS, bool VEC, int WC>
@@ -1367,6 +1370,28 @@ static bool small_whole_k(int B, int N, int R) {
     return ks_exp == 0 && N >= 600 && 2l * ((R + 63) / 64) * ((N + 255) / 256) * B >= 256;
 }
 
+// The forms of the small-tile kernel that differ in their BITS are the ways its contracted axis is cut: 9 = not at
+// all (the whole-k form), 10 = between four waves, 11 = between eight (ray blocks per wave, lists and workgroup shape
+// change which wave holds a ray, never the order of its sums).  Variant 3 stands for the one the size rules pick.
+static int small_form(int B, int N, int R) { return small_whole_k(B, N, R) ? 9 : bwd_small_ks(B, N, R) == 8 ? 11 : 10; }
+
+// What helio_render_bwd's variant 0 resolves to at (B, N, R), as a variant that pins every choice the bits of the
+// gradient depend on (include/helio.h, helio_render_bwd_choice): a shard of a batch that passes the WHOLE batch's
+// choice gets the unsharded gradient's rows bit for bit.
+int render_bwd_choice(int B, int N, int R) {
+    if (render_bwd_is_fused(B, N, R)) return 8;
+    const int v = splat_bwd_choice(B, N, R);
+    return v == 3 ? small_form(B, N, R) : v;
+}
+
+// variant → the kernel family and form it stands for at this size (0, 3 and 8 are resolved by the size rules)
+static int resolve_bwd(int variant, int B, int N, int R) {
+    if (variant == 8) variant = 3;       // 8 is helio_render_bwd's single-launch form; its moments alone are the small kernel's
+    if (variant == 0) variant = splat_bwd_choice(B, N, R);
+    if (variant == 3) variant = small_form(B, N, R);
+    return variant;
+}
+
 // Skipping rays whose footprint is identically zero on the image (cull.h): the LDS-tile kernels walk 256-ray
 // tiles of a per-image list, the small-tile kernel in its whole-k form (few images of many heliostats) 256-ray
 // groups of it.  In the backward a list means FEWER workgroups, not shorter ones (a ray's moments are a sum over
@@ -1376,13 +1401,13 @@ static bool small_whole_k(int B, int N, int R) {
 // (tools/bench_few_images.py).
 // → the kernel this call runs CAN walk a list (what a launch with enough scratch does) …
 static bool cull_bwd_possible(int variant, int B, int N, int R) {
-    if (variant == 0) variant = splat_bwd_choice(B, N, R);
+    variant = resolve_bwd(variant, B, N, R);
     if (!cull_enabled() || N <= 256) return false;
-    return variant == 2 || (variant == 3 && small_whole_k(B, N, R));
+    return variant == 2 || variant == 9;
 }
 // … and it PAYS (what the size query answers: a caller that sizes its scratch by the query hands none otherwise)
 static bool cull_bwd_wanted(int variant, int B, int N, int R) {
-    if (variant == 0) variant = splat_bwd_choice(B, N, R);
+    variant = resolve_bwd(variant, B, N, R);
     if (!cull_bwd_possible(variant, B, N, R)) return false;
     const long ray_tiles = (N + 255) / 256;
     if (variant == 2) return 2l * B * ((R + (R <= 128 ? 127 : 255)) / (R <= 128 ? 128 : 256)) * ray_tiles > 256;   // (both passes are one launch)
@@ -1396,7 +1421,7 @@ static bool cull_bwd_wanted(int variant, int B, int N, int R) {
 
 // lists per image and pass: the LDS-tile kernels' c tiles where an image is 2..8 of them wide (cull.h), else 1
 static int cull_bwd_ct(int variant, int B, int N, int R) {
-    if (variant == 0) variant = splat_bwd_choice(B, N, R);
+    variant = resolve_bwd(variant, B, N, R);
     const int c_tiles = (R + 255) / 256;
     return variant == 2 && R > 128 && c_tiles > 1 && c_tiles <= CULL_BWD_MAX_CT ? c_tiles : 1;
 }
@@ -1407,8 +1432,8 @@ long splat_bwd_scratch_bytes(int B, int N, int R, int variant) {
 
 int launch_splat_bwd(int B, int N, int R, const float* rays, const float* xs, const float* ys,
                      const float* gimg, float* moments, int variant, void* scratch, long scratch_bytes, hipStream_t st) {
-    if (variant == 8) variant = 3;       // 8 is helio_render_bwd's single-launch form; its moments alone are the small kernel's
-    if (variant == 0) variant = splat_bwd_choice(B, N, R);
+    const bool by_rule = variant == 0 || variant == 3 || variant == 8;      // (the tuning switches below act on the rules' own choice only)
+    variant = resolve_bwd(variant, B, N, R);
     if (variant == 5) {
         launch_bwd_bf16x3<0>(B, N, R, rays, xs, ys, gimg, moments, st);
         launch_bwd_bf16x3<1>(B, N, R, rays, xs, ys, gimg, moments, st);
@@ -1419,10 +1444,15 @@ int launch_splat_bwd(int B, int N, int R, const float* rays, const float* xs, co
         launch_bwd_few<false>(B, N, R, rays, xs, ys, gimg, LossGradArgs{}, moments, st);
         return HELIO_OK;
     }
-    if (variant == 3 || variant == 6 || variant == 7) {        // 6 / 7: the small kernel with 4 / 8 waves (tests, tuning)
+    if (variant == 6 || variant == 7 || (variant >= 9 && variant <= 11)) {
+        // 9 / 10 / 11: the small kernel's forms (small_form above: what 3 resolves to); 6 / 7: four / eight waves and
+        // ONE ray block per wave whatever the size (tests, tuning)
         const int ct = (R + 63) / 64, nt = (N + 31) / 32;
-        const int nrb = variant == 3 ? bwd_small_nrb(B, N, R) : 1;
-        static const int ks_exp = [] { const char* e = getenv("HELIO_BWD_KSX"); return e ? atoi(e) : 0; }();     // tuning runs
+        const int ks = (variant == 7 || variant == 11) ? 8 : 4;
+        const int nrb = variant >= 9 ? bwd_small_nrb(N, ks) : 1;
+        static const int ks_exp_env = [] { const char* e = getenv("HELIO_BWD_KSX"); return e ? atoi(e) : 0; }();     // tuning runs
+        const int ks_exp = by_rule ? ks_exp_env : 0;
+        const bool v3 = variant >= 9;
         CullBwd cull{};
         if (scratch && cull_bwd_possible(variant, B, N, R) && scratch_bytes >= cull_bwd_bytes(B, N))
             cull = launch_cull_bwd(B, N, R, splat_bwd_blocks(R), R, 1, /*with_map=*/false, false, rays, xs, ys, moments, scratch, st);
@@ -1431,22 +1461,22 @@ int launch_splat_bwd(int B, int N, int R, const float* rays, const float* xs, co
         // R = 256: 112 → 98 µs; B = 256, N = 1000, R = 64: 96 → 62 µs; at N = 300 it is 1.5× slower.  (Held to 128
         // registers — four waves per SIMD instead of two — it is no faster: 35.6 µs; the two passes alone take
         // 16.5 and 21.0 µs of the 31 µs they take together.)
-        const bool whole_k = variant == 3 && small_whole_k(B, N, R);
+        const bool whole_k = variant == 9;
         if (whole_k && cull.counts)
             hipLaunchKernelGGL((splat_bwd_mfma_small<1, 2, 4, true>), dim3(ct * ((N + 255) / 256), B, 2), dim3(256), 0, st, N, R, rays, xs, ys, gimg, moments, cull.counts, cull.idx);
-        else if (whole_k || (variant == 3 && ks_exp == 1 && nrb == 2))
+        else if (whole_k || (v3 && ks_exp == 1 && nrb == 2))
             hipLaunchKernelGGL((splat_bwd_mfma_small<1, 2, 4>), dim3(ct * ((N + 255) / 256), B, 2), dim3(256), 0, st, N, R, rays, xs, ys, gimg, moments, nullptr, nullptr);
-        else if (variant == 3 && ks_exp == 1 && nrb == 1)
+        else if (v3 && ks_exp == 1 && nrb == 1)
             hipLaunchKernelGGL((splat_bwd_mfma_small<1, 1, 4>), dim3(ct * ((N + 127) / 128), B, 2), dim3(256), 0, st, N, R, rays, xs, ys, gimg, moments, nullptr, nullptr);
-        else if (variant == 3 && ks_exp == 2 && nrb == 1)
+        else if (v3 && ks_exp == 2 && nrb == 1)
             hipLaunchKernelGGL((splat_bwd_mfma_small<2, 1, 2>), dim3(ct * ((N + 63) / 64), B, 2), dim3(256), 0, st, N, R, rays, xs, ys, gimg, moments, nullptr, nullptr);
-        else if (variant == 3 && ks_exp == 2 && nrb == 2)
+        else if (v3 && ks_exp == 2 && nrb == 2)
             hipLaunchKernelGGL((splat_bwd_mfma_small<2, 2, 2>), dim3(ct * ((N + 127) / 128), B, 2), dim3(256), 0, st, N, R, rays, xs, ys, gimg, moments, nullptr, nullptr);
         else if (nrb == 4)
             hipLaunchKernelGGL((splat_bwd_mfma_small<4, 4>), dim3(ct * ((N + 127) / 128), B, 2), dim3(256), 0, st, N, R, rays, xs, ys, gimg, moments, nullptr, nullptr);
         else if (nrb == 2)
             hipLaunchKernelGGL((splat_bwd_mfma_small<4, 2>), dim3(ct * ((N + 63) / 64), B, 2), dim3(256), 0, st, N, R, rays, xs, ys, gimg, moments, nullptr, nullptr);
-        else if (variant == 7 || (variant == 3 && bwd_small_ks(B, N, R) == 8))
+        else if (ks == 8)
             hipLaunchKernelGGL(splat_bwd_mfma_small<8>, dim3(ct * nt, B, 2), dim3(512), 0, st, N, R, rays, xs, ys, gimg, moments, nullptr, nullptr);
         else
             hipLaunchKernelGGL(splat_bwd_mfma_small<4>, dim3(ct * nt, B, 2), dim3(256), 0, st, N, R, rays, xs, ys, gimg, moments, nullptr, nullptr);

@@ -163,26 +163,27 @@ class HelioEnv(_EnvBase):
         cached until either changes."""
         errs = self.ref_field.batch_error_angles_mrad
         single = self.ref_field.error_angles_mrad
+        plane, xs, _ = self.ref_field._receiver()      # new records whenever a receiver attribute of the field changed
         hit = self._ref_cache
         if hit is not None:
             # the same tensor objects, not written to since (this runs on every step): cheap test first
-            sun0, sv, e0, ev, s0, ssv, sig, h0 = hit[6]
+            sun0, sv, e0, ev, s0, ssv, p0, x0, h0 = hit[6]
             if (sun0 is self.sun_pos and sv == sun0._version and e0 is errs and (errs is None or ev == errs._version)
-                    and s0 is single and ssv == single._version and sig == self.ref_field.sigma_scale
+                    and s0 is single and ssv == single._version and p0 is plane and x0 is xs
                     and h0 is self.ref_field.heliostat_positions):
                 return hit[1:5]
         key = (self.sun_pos.data_ptr(), self.sun_pos._version,
                None if errs is None else (errs.data_ptr(), errs._version), single.data_ptr(), single._version,
-               self.ref_field.sigma_scale, self.ref_field.heliostat_positions.data_ptr())
+               id(plane), id(xs), self.ref_field.heliostat_positions.data_ptr())
         if self._ref_cache is None or self._ref_cache[0] != key:
             with torch.no_grad():
                 ideal = self.ref_field.calculate_ideal_normals(self.sun_pos)
                 target, _ = self.ref_field.render(self.sun_pos, ideal.flatten(1), ideal)
                 tx = target.amax((1, 2)).clamp_min(1e-6)
-            self._ref_cache = (key, ideal, target, tx, ideal.view([-1, 3]), (errs, single), None)
+            self._ref_cache = (key, ideal, target, tx, ideal.view([-1, 3]), (errs, single, plane, xs), None)
         self._ref_cache = self._ref_cache[:6] + ((self.sun_pos, self.sun_pos._version, errs,
                                                   None if errs is None else errs._version, single, single._version,
-                                                  self.ref_field.sigma_scale, self.ref_field.heliostat_positions),)
+                                                  plane, xs, self.ref_field.heliostat_positions),)
         return self._ref_cache[1:5]
 
     def set_sun_pos(self, sun_positions: torch.Tensor):
@@ -222,6 +223,58 @@ class HelioEnv(_EnvBase):
                 state[name] = None
         return state
 
+    def _run_step(self, action, consts):
+        """The step's render + loss block: → ((img, actual, refl [B·N,3], mse, dist, bound, alignment_loss, flag,
+        mae [B,1], angles [B·N], all_bounds [B,N], aux, normals [B,N,3]), ticket).
+
+        The ONE place that decides how ``helio_env_step_fwd`` is reached — every route is the same C call with the same
+        arguments and gives the same bits (tests/test_gpu_more.py::test_env_step_routes_agree):
+          1. the compiled step context (everything constant between steps bound once; per step two tensors and a
+             ticket), as one autograd node when the action records a gradient;
+          2. the compiled binding's unbound entry, for an action that needs a dtype / device / layout fix-up;
+          3. without the compiled binding: ``losses.env_step_fused`` (the same node as a Python autograd Function) or
+             the ctypes call.
+        A new invalidation rule goes into the context key below and nowhere else."""
+        nf, ops = self.noisy_field, _field._get_ops()
+        differentiate = torch.is_grad_enabled() and action.requires_grad
+        notify = bool(self.check_finite)
+        trig, stride = nf._select_trig(self.batch_size)
+        plane, xs, ys = nf._receiver()
+        make_ctx = getattr(ops, "env_step_context", None)
+        if make_ctx is not None and type(action) is torch.Tensor:
+            key = self._step_ctx_key
+            if (key is None or key[0] is not consts or key[1] is not trig or key[2] != ops.splat_variant
+                    or key[3] is not ops.hb or key[4] is not plane or key[5] is not nf.heliostat_positions
+                    or key[6] is not xs):
+                # constants, errors, forced kernel variant, binding, the receiver (a new plane record / pixel
+                # grid) or the heliostat tensor changed: rebind the step context
+                self._step_ctx = make_ctx(nf, trig, stride, consts)
+                self._step_ctx_key = (consts, trig, ops.splat_variant, ops.hb, plane, nf.heliostat_positions, xs)
+            ctx = self._step_ctx
+            if ctx is not None:                                          # route 1
+                ticket = ops.next_ticket() if notify else 0
+                out = (ctx.step_grad(self.sun_pos, action, ops.bwd_variant, ticket) if differentiate
+                       else ctx.step(self.sun_pos, action, ticket))
+                if out is not None:
+                    return out, ticket
+            if not differentiate:                                        # route 2
+                out = ops.env_step_nograd(nf, self.sun_pos, action, trig, stride, consts, notify=notify)
+                if out is not None:
+                    return out[:-1], out[-1]
+        normals = action.view(self.batch_size, -1, 3)                    # :460          (route 3)
+        if differentiate:
+            (img, actual, reflected, mse, dist_l, bound, alignment_loss, mae, angles, all_bounds,
+             flag, ticket) = env_step_fused(nf, self.sun_pos, normals.contiguous(), consts, notify=notify)
+        else:
+            n3 = torch.as_tensor(action, dtype=torch.float32, device=self.device).detach().reshape(
+                self.batch_size, -1, 3).contiguous()
+            (img, actual, reflected, _rays, out5, mae, angles, all_bounds, _keep, _aux, ticket) = ops.env_step_fwd(
+                nf.heliostat_positions, self.sun_pos, n3, trig, stride, plane, xs, ys, consts, notify=notify)
+            mse, dist_l, bound, alignment_loss, flag = out5[0], out5[1], out5[2], out5[3], out5[4]
+        aux = torch.cat([self.sun_pos.detach(), action.flatten(1)], dim=1)
+        return (img, actual, reflected.view([-1, 3]), mse, dist_l, bound, alignment_loss, flag, mae.view([-1, 1]),
+                angles.view([-1]), all_bounds, aux, normals), ticket
+
     def step(self, action):
         """Render ``action`` on the noisy field and score it (:402-516).
 
@@ -243,63 +296,8 @@ class HelioEnv(_EnvBase):
                                    self._tp3, self._tn3, float(self.targ_area[0]), float(self.targ_area[1]),
                                    bool(self.exponential_risk), mask_ratio)
             self._consts_cache = (target, self.distance_maps, self.exponential_risk, mask_ratio, consts)
-        fast, ticket = None, 0
-        differentiate = torch.is_grad_enabled() and action.requires_grad
-        if type(action) is torch.Tensor:
-            ops = _field._get_ops()
-            make_ctx = getattr(ops, "env_step_context", None)
-            if make_ctx is not None:     # everything in one call of the compiled binding
-                trig, stride = self.noisy_field._select_trig(self.batch_size)
-                key = self._step_ctx_key
-                nf = self.noisy_field
-                if (key is None or key[0] is not consts or key[1] is not trig or key[2] != ops.splat_variant
-                        or key[3] is not ops.hb or key[4] is not nf._plane or key[5] is not nf.heliostat_positions):
-                    # constants, errors, forced kernel variant, binding, sigma_scale (a new plane record) or
-                    # the heliostat tensor changed: rebind the step context
-                    self._step_ctx = make_ctx(nf, trig, stride, consts)
-                    self._step_ctx_key = (consts, trig, ops.splat_variant, ops.hb, nf._plane, nf.heliostat_positions)
-                ctx = self._step_ctx
-                if ctx is not None:
-                    ticket = ops.next_ticket() if self.check_finite else 0
-                    if differentiate:    # one autograd node (render + loss block + the aux row), shapes made in C++
-                        step_grad = getattr(ctx, "step_grad", None)
-                        fast = step_grad(self.sun_pos, action, ops.bwd_variant, ticket) if step_grad is not None else None
-                    else:
-                        fast = ctx.step(self.sun_pos, action, ticket)
-                if fast is None and differentiate:
-                    ticket = 0           # (the Python path below issues its own)
-                elif fast is None:       # (the action needs a dtype / device / layout fix-up)
-                    ticket = 0
-                    step_fn = getattr(ops, "env_step_nograd", None)
-                    if step_fn is not None:
-                        fast = step_fn(self.noisy_field, self.sun_pos, action, trig, stride, consts,
-                                       notify=self.check_finite)
-                        if fast is not None:
-                            ticket, fast = fast[-1], fast[:-1]
-        if fast is not None:
-            (img, actual, reflected, mse, dist_l, bound, alignment_loss, flag, mae, angles, all_bounds, aux,
-             normals) = fast
-        else:
-            normals = action.view(self.batch_size, -1, 3)                # :460
-            if differentiate:
-                # render + loss block as one autograd node
-                (img, actual, reflected, mse, dist_l, bound, alignment_loss, mae, angles, all_bounds,
-                 flag, ticket) = env_step_fused(self.noisy_field, self.sun_pos, normals.contiguous(), consts,
-                                                notify=self.check_finite)
-            else:
-                # no compiled binding (or an action that needed a fix-up): the same ONE C call — helio_env_step_fwd,
-                # render + loss block — through the ctypes binding, so that this path and the differentiating one
-                # give the same bits whatever the binding
-                nf = self.noisy_field
-                n3 = torch.as_tensor(action, dtype=torch.float32, device=self.device).detach().reshape(
-                    self.batch_size, -1, 3).contiguous()
-                trig, stride = nf._select_trig(self.batch_size)
-                (img, actual, reflected, _rays, out5, mae, angles, all_bounds, _keep, _aux, ticket) = _field._get_ops().env_step_fwd(
-                    nf.heliostat_positions, self.sun_pos, n3, trig, stride, nf._plane, nf._xs, nf._ys, consts,
-                    notify=bool(self.check_finite))
-                mse, dist_l, bound, alignment_loss, flag = out5[0], out5[1], out5[2], out5[3], out5[4]
-            aux = torch.cat([self.sun_pos.detach(), action.flatten(1)], dim=1)
-            reflected, mae, angles = reflected.view([-1, 3]), mae.view([-1, 1]), angles.view([-1])
+        (img, actual, reflected, mse, dist_l, bound, alignment_loss, flag, mae, angles, all_bounds, aux,
+         normals), ticket = self._run_step(action, consts)
         metrics = {"mse": mse, "dist": dist_l, "bound": bound, "alignment_loss": alignment_loss}
         obs = {"img": img, "aux": aux}
         monitor = {

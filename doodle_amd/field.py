@@ -28,11 +28,12 @@ class _Render(torch.autograd.Function):
     """image, actual, refl = render(normals); differentiable w.r.t. ``normals`` only."""
 
     @staticmethod
-    def forward(ctx, normals, field, sun, trig, trig_stride, variant=None):
+    def forward(ctx, normals, field, sun, trig, trig_stride, variant=None, bwd_variant=None):
         image, actual, refl, rays = _get_ops().render_fwd(
             field.heliostat_positions, sun, normals, trig, trig_stride, field._plane, field._xs, field._ys,
             variant=variant)
-        ctx.field, ctx.trig_stride = field, trig_stride
+        ctx.field, ctx.trig_stride, ctx.bwd_variant = field, trig_stride, bwd_variant
+        ctx.consts = (field.heliostat_positions, field._plane, field._xs, field._ys)     # as rendered: a later assignment to the field does not reach this node
         ctx.save_for_backward(normals, sun, trig, rays)
         ctx.set_materialize_grads(False)          # unused outputs arrive as None, not as zero tensors
         return image, actual, refl
@@ -40,13 +41,14 @@ class _Render(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_image, g_actual, g_refl):
         normals, sun, trig, rays = ctx.saved_tensors
-        field = ctx.field
         if g_image is None and g_actual is None and g_refl is None:
-            return None, None, None, None, None, None
+            return None, None, None, None, None, None, None
+        helios, plane, xs, ys = ctx.consts
         c = lambda g: g.contiguous() if g is not None else None  # noqa: E731
-        g = _get_ops().render_bwd(field.heliostat_positions, sun, normals, trig, ctx.trig_stride, field._plane,
-                                  rays, field._xs, field._ys, c(g_image), c(g_actual), c(g_refl))
-        return g, None, None, None, None, None
+        kw = {} if ctx.bwd_variant is None else {"variant": ctx.bwd_variant}
+        g = _get_ops().render_bwd(helios, sun, normals, trig, ctx.trig_stride, plane,
+                                  rays, xs, ys, c(g_image), c(g_actual), c(g_refl), **kw)
+        return g, None, None, None, None, None, None
 
 
 class HelioField:
@@ -66,13 +68,14 @@ class HelioField:
         device="cpu",
         max_batch_size: int = 25,
     ) -> None:
+        object.__setattr__(self, "_ready", False)          # the receiver records are built once, at the end
         self.device = torch.device(device)
         self.max_batch_size = int(max_batch_size)
 
         self.heliostat_positions = torch.as_tensor(
             heliostat_positions, dtype=torch.float32, device=self.device).contiguous()
         self.num_heliostats = self.heliostat_positions.shape[0]
-        self.target_position = torch.as_tensor(target_position, dtype=torch.float32, device=self.device)
+        self.target_position = target_position
         self.target_width, self.target_height = target_area
 
         # The few constructor constants are computed with CPU torch ops — the same
@@ -86,24 +89,13 @@ class HelioField:
         else:
             v = torch.linalg.cross(tn, u)
             v = v / v.norm().clamp_min(_TINY)
-        self.target_normal = tn.to(self.device)
-        self.plane_u, self.plane_v = u.to(self.device), v.to(self.device)
+        self.target_normal = tn
+        self.plane_u, self.plane_v = u, v
 
         self.error_scale_mrad = float(error_scale_mrad)
         self.initial_action_noise = float(initial_action_noise)
-        self._sigma_scale = float(sigma_scale)
+        self.sigma_scale = float(sigma_scale)
         self.resolution = int(resolution)
-
-        # native-side constants: receiver frame (w = u × v closes the orthonormal
-        # frame of the separable footprint) and the pixel coordinates of :129-130
-        w = torch.linalg.cross(u.double(), v.double()).float()
-        tp = self.target_position.detach().cpu()
-        self._plane_vectors = (tuple(tp.tolist()), tuple(tn.tolist()), tuple(u.tolist()), tuple(v.tolist()),
-                               tuple(w.tolist()))
-        self._plane = native.Plane(*self._plane_vectors, self._sigma_scale)
-        self._target_xyz = tuple(tp.tolist())
-        self._xs = torch.linspace(-self.target_width / 2, self.target_width / 2, self.resolution).to(self.device)
-        self._ys = torch.linspace(-self.target_height / 2, self.target_height / 2, self.resolution).to(self.device)
 
         self._trig_cache = {}
         self._device_trig = os.environ.get("HELIO_DEVICE_TRIG", "0") == "1"
@@ -111,12 +103,14 @@ class HelioField:
         self._fast_render = None      # ops.render_context once resolved (False: compiled binding absent)
         self._render_ctx, self._ctx_key, self._ops = None, None, None
         self._fast = None             # the render context of the previous fast call (see __setattr__)
+        self._ready = True
+        self._rebuild_receiver()
         self.reset_errors()
         self.initial_action = None
 
     def __setattr__(self, name, value):
-        # any reassignment (errors, heliostats, sigma_scale → _plane, device_trig …) retires the memoised
-        # render context; the slots of the caches themselves are exempt
+        # any reassignment (errors, heliostats, the receiver's attributes → _plane / _xs / _ys, device_trig …)
+        # retires the memoised render context; the slots of the caches themselves are exempt
         object.__setattr__(self, name, value)
         if name != "_fast":
             object.__setattr__(self, "_fast", None)
@@ -134,17 +128,99 @@ class HelioField:
 
     def __setstate__(self, state):
         self.__dict__.update(state)
-        self.__dict__["_plane"] = native.Plane(*self._plane_vectors, self._sigma_scale)
+        self._rebuild_receiver()
 
-    @property
-    def sigma_scale(self) -> float:
-        return self._sigma_scale
+    # -------------------------------------------------------------- the receiver, as live as the reference's
+    # The reference reads target_position, target_normal, plane_u, plane_v, target_width, target_height, resolution and
+    # sigma_scale from the instance at EVERY render (:387-401), so a script that assigns one of them between renders
+    # sees it take effect.  Here they feed three native-side records — the plane (origin, normal, the orthonormal
+    # frame u, v, w = u × v of the separable footprint, sigma_scale), the pixel coordinates of :129-130 and the
+    # target of calculate_ideal_normals — which every assignment rebuilds (and with them the compiled contexts:
+    # they are keyed on the records' identity); an in-place write to one of the four tensors is caught by its
+    # version counter at the next render.
+    def _vector_attr(name, doc):        # noqa: N805 — class-body helper
+        slot = "_" + name
 
-    @sigma_scale.setter
-    def sigma_scale(self, value: float) -> None:
-        # a plain attribute in the reference (read at every render, :400): keep assignments effective
-        self._sigma_scale = float(value)
-        self._plane = native.Plane(*self._plane_vectors, self._sigma_scale)
+        def get(self):
+            return self.__dict__[slot]
+
+        def set_(self, value):
+            t = torch.as_tensor(value, dtype=torch.float32, device=self.device)
+            if t.shape != (3,):
+                raise ValueError(f"HelioField.{name} must have shape (3,), got {tuple(t.shape)}")
+            self._assign_receiver(slot, t)
+        return property(get, set_, doc=doc)
+
+    def _scalar_attr(name, cast, doc):  # noqa: N805
+        slot = "_" + name
+
+        def get(self):
+            return self.__dict__[slot]
+
+        def set_(self, value):
+            self._assign_receiver(slot, cast(value))
+        return property(get, set_, doc=doc)
+
+    target_position = _vector_attr("target_position", "centre of the receiver (:184-186); read at every render (:387)")
+    target_normal = _vector_attr("target_normal", "receiver normal, as assigned — the render divides by its norm again (:60)")
+    plane_u = _vector_attr("plane_u", "image dim-0 axis on the receiver (:206); must stay orthonormal with plane_v")
+    plane_v = _vector_attr("plane_v", "image dim-1 axis on the receiver (:207-213)")
+    target_width = _scalar_attr("target_width", float, "receiver extent along plane_u [m] (:187)")
+    target_height = _scalar_attr("target_height", float, "receiver extent along plane_v [m] (:187)")
+    resolution = _scalar_attr("resolution", int, "pixels per side (:199)")
+    sigma_scale = _scalar_attr("sigma_scale", float, "footprint sigma per metre of path (:198, read at :400)")
+    del _vector_attr, _scalar_attr
+
+    def _assign_receiver(self, slot, value) -> None:
+        d = self.__dict__
+        had, old = slot in d, d.get(slot)
+        d[slot] = value
+        self._fast = None
+        if d.get("_ready"):
+            try:
+                self._rebuild_receiver()
+            except ValueError:                   # a refused value is not kept
+                if had:
+                    d[slot] = old
+                else:
+                    del d[slot]
+                raise
+
+    def _receiver_versions(self):
+        d = self.__dict__
+        return tuple(d[k]._version for k in ("_target_position", "_target_normal", "_plane_u", "_plane_v"))
+
+    def _rebuild_receiver(self) -> None:
+        """The native-side records of the receiver from the current attribute values."""
+        d = self.__dict__
+        tp, tn, u, v = (d[k].detach().cpu() for k in ("_target_position", "_target_normal", "_plane_u", "_plane_v"))
+        # the footprint is evaluated in its separable form, |P_ij − x|² = (xs_i + a)² + (ys_j + b)² + c² (DESIGN §2),
+        # which IS the reference's Σ diffs² (:141-144) exactly when (u, v) are orthonormal — as the constructor makes
+        # them (:206-213); anything else is refused rather than rendered differently from the reference
+        uu, vv, uv = float(u.double() @ u.double()), float(v.double() @ v.double()), float(u.double() @ v.double())
+        if not (abs(uu - 1.0) <= 1e-5 and abs(vv - 1.0) <= 1e-5 and abs(uv) <= 1e-5):
+            raise ValueError("HelioField: plane_u / plane_v must be orthonormal (|u|² = %.6g, |v|² = %.6g, u·v = %.3g): the HIP "
+                             "footprint kernels evaluate the reference's Gaussian in its separable form" % (uu, vv, uv))
+        w = torch.linalg.cross(u.double(), v.double()).float()
+        vectors = (tuple(tp.tolist()), tuple(tn.tolist()), tuple(u.tolist()), tuple(v.tolist()), tuple(w.tolist()))
+        self._plane_vectors = vectors
+        self._plane = native.Plane(*vectors, self._sigma_scale)
+        self._target_xyz = vectors[0]
+        R = self._resolution
+        if R < 1:
+            raise ValueError(f"HelioField.resolution must be >= 1, got {R}")
+        xs_key = (self._target_width, self._target_height, R)
+        if d.get("_xs_key") != xs_key:                        # (sigma_scale or a vector alone leaves the pixel grid as it is)
+            self._xs = torch.linspace(-self._target_width / 2, self._target_width / 2, R).to(self.device)
+            self._ys = torch.linspace(-self._target_height / 2, self._target_height / 2, R).to(self.device)
+            self._xs_key = xs_key
+        self._receiver_seen = self._receiver_versions()
+
+    def _receiver(self):
+        """→ (plane record, xs, ys), rebuilt first if one of the receiver's tensors was written in place."""
+        if self._receiver_seen != self._receiver_versions():
+            self._rebuild_receiver()
+        return self._plane, self._xs, self._ys
 
     @property
     def device_trig(self) -> bool:
@@ -270,52 +346,33 @@ class HelioField:
         memo = self._fast
         if memo is not None:
             # the context of the previous call, still valid (every assignment to an attribute of this field
-            # clears the memo; in-place writes to the error tensor, a forced variant and gradient recording are
-            # checked inside): argument checks, allocation, launch and the reference's return shapes in one
-            # compiled call — at config 2 the kernel needs 3.7 µs, so every host microsecond shows
+            # clears the memo; in-place writes to the error tensor or to one of the receiver's tensors, a forced
+            # variant and gradient recording are checked inside): argument checks, allocation, launch and the
+            # reference's return shapes in one compiled call — at config 2 the kernel needs 3.7 µs, so every host
+            # microsecond shows
             out = memo.render_checked(sun_position, action, monitor)
             if out is not None:
                 return out
         picked = None        # the error table once selected for this call: the fresh-error branch draws from the RNG
         if (type(sun_position) is torch.Tensor and type(action) is torch.Tensor
                 and not (action.requires_grad and torch.is_grad_enabled())):
-            # launch-bound fast path (config 2 is ≈3.7 µs of GPU per call: every host microsecond shows):
-            # dtype / device / shape fix-ups, allocation and the launch happen inside the compiled binding
-            fast = self._fast_render
-            if fast is None:
-                self._ops = _get_ops()
-                fast = self._fast_render = getattr(self._ops, "render_context", False)
-            if fast:
-                batched = sun_position.dim() > 1
-                B = sun_position.shape[0] if batched else 1
-                batch = self.batch_error_angles_mrad
-                hit = self._trig_cache.get("batch") if B > 1 else None
-                if hit is not None and hit[2] is batch and hit[0][1] == batch._version and B <= batch.shape[0]:
-                    trig, stride = hit[1], 4 * self.num_heliostats      # the common case of _select_trig, inlined
-                    cached = True
-                else:
-                    trig, stride = self._select_trig(B)
-                    cached = B == 1 or (batch is not None and B <= batch.shape[0])   # else: errors drawn per call
-                picked = (trig, stride)
-                ops = self._ops
-                key = self._ctx_key
-                if (key is None or key[0] is not trig or key[1] != stride or key[2] != ops.splat_variant
-                        or key[3] is not ops.hb or key[4] is not self._plane or key[5] is not self.heliostat_positions):
-                    # rebuilt when the errors, the forced variant, the binding, sigma_scale (a new plane
-                    # record) or the heliostat tensor change
-                    self._render_ctx = fast(self, trig, stride)
-                    self._ctx_key = (trig, stride, ops.splat_variant, ops.hb, self._plane, self.heliostat_positions)
-                ctx = self._render_ctx
-                if ctx is not None:
-                    out = ctx.render(sun_position if batched else sun_position.unsqueeze(0), action, monitor)
-                    if out is not None:
-                        if cached:                               # the next call may skip all of the above
-                            ctx.bind_errors(self.error_angles_mrad if stride == 0 else batch)
-                            self._fast = ctx
-                        if not monitor:
-                            return out if batched else (out[0][0], out[1])
-                        img = out[0] if batched else out[0][0]
-                        return img, out[1], out[2].view(-1, 3)
+            # launch-bound path: dtype / device / shape fix-ups, allocation and the launch happen inside the compiled
+            # binding's render context (None without it)
+            batched = sun_position.dim() > 1
+            B = sun_position.shape[0] if batched else 1
+            ctx, trig, stride, cached = self._render_context(B)
+            picked = (trig, stride)
+            out = ctx.render(sun_position if batched else sun_position.unsqueeze(0), action, monitor) if ctx is not None else None
+            if out is not None:
+                if cached:                               # the next call may skip all of the above
+                    ctx.bind_errors(self.error_angles_mrad if stride == 0 else self.batch_error_angles_mrad)
+                    d = self.__dict__
+                    ctx.bind_receiver([d["_target_position"], d["_target_normal"], d["_plane_u"], d["_plane_v"]])
+                    self._fast = ctx
+                if not monitor:
+                    return out if batched else (out[0][0], out[1])
+                img = out[0] if batched else out[0][0]
+                return img, out[1], out[2].view(-1, 3)
         sun = torch.as_tensor(sun_position, dtype=torch.float32, device=self.device)
         batched = sun.dim() > 1
         if not batched:
@@ -328,22 +385,27 @@ class HelioField:
         return (img, actual, refl) if monitor else (img, actual)
 
     def _render_context(self, B: int):
-        """→ (compiled render context or None, trig table, batch stride) for a batch of ``B`` suns: the
-        context is rebuilt when the errors, the forced variant, the binding, sigma_scale (a new plane record) or
-        the heliostat tensor change."""
+        """→ (compiled render context or None, trig table, batch stride, cached) for a batch of ``B`` suns — the ONE
+        place that decides whether the context of an earlier call still serves: it is rebuilt when the errors, the
+        forced variant, the binding, the receiver (a new plane record / pixel grid: any of its attributes assigned or
+        written in place) or the heliostat tensor change.  ``cached``: the trig table belongs to stored errors (False:
+        drawn for this call, :349-353 — nothing to memoise)."""
         fast = self._fast_render
         if fast is None:
             self._ops = _get_ops()
             fast = self._fast_render = getattr(self._ops, "render_context", False)
         trig, stride = self._select_trig(B)
+        batch = self.batch_error_angles_mrad
+        cached = B == 1 or (batch is not None and B <= batch.shape[0])
+        plane, xs, _ = self._receiver()
         if not fast:
-            return None, trig, stride
+            return None, trig, stride, cached
         ops, key = self._ops, self._ctx_key
         if (key is None or key[0] is not trig or key[1] != stride or key[2] != ops.splat_variant
-                or key[3] is not ops.hb or key[4] is not self._plane or key[5] is not self.heliostat_positions):
+                or key[3] is not ops.hb or key[4] is not plane or key[5] is not self.heliostat_positions or key[6] is not xs):
             self._render_ctx = fast(self, trig, stride)
-            self._ctx_key = (trig, stride, ops.splat_variant, ops.hb, self._plane, self.heliostat_positions)
-        return self._render_ctx, trig, stride
+            self._ctx_key = (trig, stride, ops.splat_variant, ops.hb, plane, self.heliostat_positions, xs)
+        return self._render_ctx, trig, stride, cached
 
     def render_value_and_grad(self, sun_position, action, grad_image=None, grad_actual=None, grad_refl=None):
         """``render`` and the gradient of a scalar loss w.r.t. ``action`` in one call, for GIVEN cotangents
@@ -363,15 +425,16 @@ class HelioField:
             g, dtype=torch.float32, device=self.device).detach().reshape(shape).contiguous()
         g_img = fix(grad_image, (B, self.resolution, self.resolution))
         g_act, g_refl = fix(grad_actual, (B, N, 3)), fix(grad_refl, (B, N, 3))
-        ctx, trig, stride = self._render_context(B)
+        ctx, trig, stride, _ = self._render_context(B)
         out = ctx.render_and_grad(sun, act, g_img, g_act, g_refl, self._ops.bwd_variant) if ctx is not None else None
         if out is None:
             ops = _get_ops()
+            plane, xs, ys = self._receiver()
             ws = torch.empty((B, N, native.RAY_STRIDE), dtype=torch.float32, device=act.device)
-            image, actual, _, rays = ops.render_fwd(self.heliostat_positions, sun, act, trig, stride, self._plane,
-                                                    self._xs, self._ys, want_refl=False, rays=ws)
-            grad = ops.render_bwd(self.heliostat_positions, sun, act, trig, stride, self._plane, rays, self._xs,
-                                  self._ys, g_img, g_act, g_refl)
+            image, actual, _, rays = ops.render_fwd(self.heliostat_positions, sun, act, trig, stride, plane,
+                                                    xs, ys, want_refl=False, rays=ws)
+            grad = ops.render_bwd(self.heliostat_positions, sun, act, trig, stride, plane, rays, xs,
+                                  ys, g_img, g_act, g_refl)
             out = (image, actual, grad)
         image, actual, grad = out
         return (image if batched else image[0]), actual, grad.view(B, -1)
@@ -389,28 +452,32 @@ class HelioField:
         normals = act.reshape(B, N, 3).contiguous()
         trig, stride = _picked if _picked is not None else self._select_trig(global_batch, row_offset, B)
 
-        # a piece of a larger batch is rendered by the kernel the WHOLE batch would get (the size rules look at
-        # B; every kernel's summation order depends on N and R only): the rows of the unsharded render, bit
-        # for bit, whatever the shard size
-        # — passed DOWN with this call (an argument of helio_render_fwd), never written to the process-wide ops
-        # object: another thread rendering meanwhile keeps its own kernel choice.  Only the FORWARD is
-        # bit-identical across shards; the backward's kernel rules look at the shard's own size.
+        # a piece of a larger batch is rendered by the kernels the WHOLE batch would get (the size rules look at
+        # B; every kernel's summation order depends on N and R only): the rows of the unsharded render AND of its
+        # gradient, bit for bit, whatever the shard size
+        # — passed DOWN with this call (arguments of helio_render_fwd / helio_render_bwd), never written to the
+        # process-wide ops object: another thread rendering meanwhile keeps its own kernel choice.
         ops = _get_ops()
-        forced = None
-        if global_batch != B and getattr(ops, "splat_variant", 0) == 0:
-            choose = getattr(ops, "render_choice", None)
-            forced = (choose(global_batch, N, self.resolution) or None) if choose is not None else None
+        plane, xs, ys = self._receiver()
+        forced = forced_bwd = None
+        if global_batch != B:
+            if getattr(ops, "splat_variant", 0) == 0:
+                choose = getattr(ops, "render_choice", None)
+                forced = (choose(global_batch, N, self.resolution) or None) if choose is not None else None
+            if getattr(ops, "bwd_variant", 0) == 0:
+                choose = getattr(ops, "render_bwd_choice", None)
+                forced_bwd = (choose(global_batch, N, self.resolution) or None) if choose is not None else None
         if torch.is_grad_enabled() and normals.requires_grad:
             node = getattr(ops, "render_node", None)
-            out = node(self, sun, normals, trig, stride, variant=forced) if node is not None else None
+            out = node(self, sun, normals, trig, stride, variant=forced, bwd_variant=forced_bwd) if node is not None else None
             # (the same node as a C++ autograd Function when the compiled binding is built)
-            images, actual, refl = out if out is not None else _Render.apply(normals, self, sun, trig, stride, forced)
+            images, actual, refl = out if out is not None else _Render.apply(normals, self, sun, trig, stride, forced, forced_bwd)
         else:
             # no autograd: the ray work buffer is scratch, reuse it between calls
             ws = self._ray_ws
             if ws is None or ws.shape[0] != B or ws.device != normals.device:
                 ws = self._ray_ws = torch.empty((B, N, native.RAY_STRIDE), dtype=torch.float32, device=normals.device)
             images, actual, refl, _ = ops.render_fwd(
-                self.heliostat_positions, sun, normals, trig, stride, self._plane, self._xs, self._ys,
+                self.heliostat_positions, sun, normals, trig, stride, plane, xs, ys,
                 want_refl=monitor, rays=ws, variant=forced)
         return images, actual, (refl.view(-1, 3) if refl is not None else None)

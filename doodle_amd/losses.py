@@ -69,10 +69,12 @@ class _EnvStep(torch.autograd.Function):
     @staticmethod
     def forward(ctx, normals, field, sun, trig, trig_stride, consts, notify):
         ops = _field._get_ops()
+        plane, xs, ys = field._receiver()
         image, actual, refl, rays, out, mae, align, allb, keep, _, ticket = ops.env_step_fwd(
-            field.heliostat_positions, sun, normals, trig, trig_stride, field._plane, field._xs, field._ys, consts,
+            field.heliostat_positions, sun, normals, trig, trig_stride, plane, xs, ys, consts,
             notify=notify)
-        ctx.field, ctx.trig_stride, ctx.consts = field, trig_stride, consts
+        ctx.trig_stride, ctx.consts = trig_stride, consts
+        ctx.scene = (field.heliostat_positions, plane, xs, ys)      # as stepped: later assignments to the field do not reach this node
         ctx.save_for_backward(normals, sun, trig, rays, image, actual, keep)
         ctx.set_materialize_grads(False)
         flag = out[4]
@@ -82,14 +84,15 @@ class _EnvStep(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_image, g_actual, g_refl, g_mse, g_dist, g_bound, g_align, *_unused):
         normals, sun, trig, rays, image, actual, keep = ctx.saved_tensors
-        field, ops = ctx.field, _field._get_ops()
+        ops = _field._get_ops()
+        helios, plane, xs, ys = ctx.scene
         c = lambda g: g.contiguous() if g is not None else None  # noqa: E731
         step_bwd = getattr(ops, "env_step_bwd", None)
         if g_image is None and step_bwd is not None:
             # the whole backward in one C call (helio_env_step_bwd): 1-3 launches, no temporaries
             # for the ray-loss adjoints, no [B,R,R] image cotangent when there are few rays
-            g = step_bwd(field.heliostat_positions, sun, normals, trig, ctx.trig_stride, field._plane, rays,
-                         field._xs, field._ys, image, ctx.consts, c(g_mse), c(g_dist), c(g_bound), c(g_align), keep,
+            g = step_bwd(helios, sun, normals, trig, ctx.trig_stride, plane, rays,
+                         xs, ys, image, ctx.consts, c(g_mse), c(g_dist), c(g_bound), c(g_align), keep,
                          c(g_actual), c(g_refl))
             return g, None, None, None, None, None, None
         need_img = g_mse is not None or g_dist is not None
@@ -102,8 +105,8 @@ class _EnvStep(torch.autograd.Function):
         if g_image is None and g_actual is None and g_refl is None:
             g = gn
         else:
-            g = ops.render_bwd(field.heliostat_positions, sun, normals, trig, ctx.trig_stride, field._plane, rays,
-                               field._xs, field._ys, c(g_image), c(g_actual), c(g_refl))
+            g = ops.render_bwd(helios, sun, normals, trig, ctx.trig_stride, plane, rays,
+                               xs, ys, c(g_image), c(g_actual), c(g_refl))
             if gn is not None:
                 g = g + gn
         return g, None, None, None, None, None, None
@@ -114,6 +117,7 @@ def env_step_fused(field, sun, normals, consts: StepConstants, notify: bool = Fa
     alignment_loss, mae [B], angles [B,N], all_bounds [B,N], flag, ticket) — ``ticket`` (an int,
     0 without ``notify``) is the step's completion ticket for ``ops.notify_wait``."""
     trig, stride = field._select_trig(sun.shape[0])
+    field._receiver()            # (an in-place write to a receiver tensor since the last call → fresh records)
     node = getattr(_field._get_ops(), "env_step_node", None)
     out = node(field, sun, normals, trig, stride, consts, notify) if node is not None else None
     if out is not None:          # the same node as a C++ autograd Function (csrc/hostbind.cpp)

@@ -23,7 +23,7 @@ EXPORTS = (
     "helio_splat_fwd", "helio_render_fwd", "helio_render_bwd", "helio_render_fwd_launches", "helio_splat_bwd_blocks", "helio_splat_bwd", "helio_geometry_bwd",
     "helio_ideal_normals", "helio_init_actions", "helio_step_losses_workspace", "helio_step_losses_fwd", "helio_step_losses_bwd",
     "helio_distance_maps_workspace", "helio_distance_maps",
-    "helio_env_step_workspace", "helio_env_step_launches", "helio_render_fwd_choice", "helio_env_step_fwd",
+    "helio_env_step_workspace", "helio_env_step_launches", "helio_render_fwd_choice", "helio_render_bwd_choice", "helio_env_step_fwd",
     "helio_notify_create", "helio_notify_destroy", "helio_notify_wait",
     "helio_env_step_bwd_image_ws", "helio_env_step_bwd", "helio_fwd_scratch_bytes", "helio_bwd_scratch_bytes",
     "helio_fwd_scratch_required",
@@ -80,6 +80,7 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
         "helio_env_step_workspace": (_l, [_i, _i, _i]),
         "helio_env_step_launches": (_i, [_i, _i, _i]),
         "helio_render_fwd_choice": (_i, [_i, _i, _i]),
+        "helio_render_bwd_choice": (_i, [_i, _i, _i]),
         "helio_env_step_fwd": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _l, pp, _vp, _vp, _vp, _vp, _vp, _vp, _i]
                                + [_vp] * 4 + [_f3, _f3, _f, _f, _i, _f] + [_vp] * 7 + [_vp, _i, _vp, _l, _vp]),
         "helio_env_step_bwd_image_ws": (_i, [_i, _i, _i]),
@@ -234,6 +235,11 @@ class HipOps:
         shard of a batch of B suns forces so that it reproduces the unsharded render's rows bit for bit."""
         return int(self.lib.helio_render_fwd_choice(int(B), int(N), int(R)))
 
+    def render_bwd_choice(self, B, N, R):
+        """The variant ``helio_render_bwd``'s 0 resolves to at (B, N, R) (``helio_render_bwd_choice``): a shard that
+        passes the whole batch's choice gets the unsharded gradient's rows bit for bit."""
+        return int(self.lib.helio_render_bwd_choice(int(B), int(N), int(R)))
+
     def render_context(self, field, trig, trig_b_stride):
         """A compiled render context of ``field`` for the trig table ``trig`` (csrc/hostbind.cpp
         RenderCtx): ``ctx.render(sun, action, want_refl)`` is HelioField.render's no-autograd call with
@@ -336,14 +342,16 @@ class HipOps:
         return grad
 
     # -- the two autograd nodes as C++ torch::autograd::Function (compiled binding only) ------------
-    def render_node(self, field, sun, normals, trig, trig_b_stride, variant=None):
+    def render_node(self, field, sun, normals, trig, trig_b_stride, variant=None, bwd_variant=None):
         """``_Render.apply`` of field.py without the Python Function (None: binding not built).
-        ``variant``: a forced forward kernel for this call (None: ``self.splat_variant``)."""
+        ``variant`` / ``bwd_variant``: forced forward / backward kernels for this call (None: ``self.splat_variant``
+        / ``self.bwd_variant``)."""
         if self.hb is None:
             return None
         return self.hb.render_autograd(_plane_handle(self.hb, field._plane), field.heliostat_positions, sun, normals,
                                        trig, trig_b_stride, field._xs, field._ys,
-                                       self.splat_variant if variant is None else int(variant), self.bwd_variant)
+                                       self.splat_variant if variant is None else int(variant),
+                                       self.bwd_variant if bwd_variant is None else int(bwd_variant))
 
     def env_step_node(self, field, sun, normals, trig, trig_b_stride, c, notify=False):
         """``_EnvStep.apply`` of losses.py without the Python Function (None: binding not built).
@@ -412,11 +420,13 @@ class HipOps:
         return moments
 
     def render_bwd(self, helios, sun, normals, trig, trig_b_stride, plane, rays, xs, ys, grad_image, grad_actual,
-                   grad_refl):
-        """splat backward + geometry backward in ONE C call; any cotangent may be None."""
+                   grad_refl, variant=None):
+        """splat backward + geometry backward in ONE C call; any cotangent may be None.
+        ``variant``: a forced backward kernel for this call (None: ``self.bwd_variant``)."""
+        variant = self.bwd_variant if variant is None else int(variant)
         if self.hb is not None:
             return self.hb.render_bwd(_plane_handle(self.hb, plane), helios, sun, normals, trig, trig_b_stride, rays,
-                                      xs, ys, grad_image, grad_actual, grad_refl, self.bwd_variant)
+                                      xs, ys, grad_image, grad_actual, grad_refl, variant)
         B, N, R = normals.shape[0], normals.shape[1], xs.shape[0]
         grad = torch.empty_like(normals)
         moments = None
@@ -424,12 +434,12 @@ class HipOps:
             moments = torch.empty((B, self.lib.helio_splat_bwd_blocks(R), N, MOMENT_STRIDE), dtype=torch.float32,
                                   device=normals.device)
         ptr = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
-        _keep, sp, sn = (self._scratch(self.lib.helio_bwd_scratch_bytes, B, N, R, self.bwd_variant, normals)
+        _keep, sp, sn = (self._scratch(self.lib.helio_bwd_scratch_bytes, B, N, R, variant, normals)
                          if moments is not None else (None, None, 0))
         _check(self.lib, self.lib.helio_render_bwd(
             B, N, R, _dev(helios), _dev(sun), _dev(normals), _dev(trig), trig_b_stride, plane, _dev(rays),
             _dev(xs), _dev(ys), ptr(grad_image), ptr(grad_actual), ptr(grad_refl), ptr(moments), grad.data_ptr(),
-            self.bwd_variant, sp, sn, _stream()))
+            variant, sp, sn, _stream()))
         return grad
 
     def geometry_bwd(self, helios, sun, normals, trig, trig_b_stride, plane, moments, grad_actual, grad_refl):

@@ -180,6 +180,16 @@ int helio_render_fwd_launches(int B, int N, int R);
  */
 int helio_render_fwd_choice(int B, int N, int R);
 
+/*
+ * The same for the backward: the variant that helio_render_bwd's variant 0 resolves to at (B, N, R) — 8 (the
+ * single-launch form), 4, 2, or 9 / 10 / 11 (the small-tile kernel with its contracted axis whole / cut between
+ * four / eight waves); 0 for invalid sizes.  A ray's moments are sums over ITS image only, in an order fixed by the
+ * variant, N and R, so a shard that passes the whole batch's choice gets the unsharded gradient's rows bit for
+ * bit (the lists of helio_bwd_scratch_bytes and the workgroup shapes still follow the shard's own size: they
+ * never change a sum).  Additive in ABI version 2.
+ */
+int helio_render_bwd_choice(int B, int N, int R);
+
 /* Column blocks the backward splat splits an R-wide image into (the size of the
  * second dimension of moments_d). */
 int helio_splat_bwd_blocks(int R);
@@ -198,7 +208,9 @@ int helio_splat_bwd_blocks(int R);
  * for a handful of rays per image (bound by reading grad_image once), 5 = the split-bf16 MFMA
  * kernels (opt-in, never chosen by 0: grad-image values and factors split exactly into three
  * bf16 pieces, six partial products per product on the bf16 matrix pipe, f32 accumulation);
- * 6 / 7 = the small-tile kernel forced to 4 / 8 waves per workgroup (what 3 chooses by size).
+ * 6 / 7 = the small-tile kernel forced to 4 / 8 waves per workgroup and one ray block per wave (tests, tuning);
+ * 9 / 10 / 11 = the forms 3 chooses between by size: contracted axis whole / cut between four / eight waves
+ * (helio_render_bwd_choice).
  */
 int helio_splat_bwd(int B, int N, int R,
                     const float *rays_d, const float *xs_d, const float *ys_d,

@@ -176,17 +176,20 @@ def render_chunked(scene: Scene, sun, action, errs, b_chunk: int = 1, n_chunk: i
     return images, actual
 
 
-def grad_action_chunked(scene: Scene, sun, action, errs, G, H=None, n_chunk: int = 25):
+def grad_action_chunked(scene: Scene, sun, action, errs, G, H=None, n_chunk: int = 25, dtype=torch.float32):
     """d/d(action) of ``(images·G).sum() + (actual·H).sum()`` by the reference's own fp32 autograd
     for configurations whose ``[M,R,R,3]`` graph does not fit in memory.  The loss is additive over
     heliostats (``images = Σ_n gauss_n``, :404-406, and ray n's Gaussian depends on action row n
     only), so the gradient rows of a heliostat chunk come from a render of that chunk alone:
-    bit-identical with the unchunked autograd row by row."""
+    bit-identical with the unchunked autograd row by row.  ``dtype=torch.float64`` (with a float64
+    ``scene``) gives the fp64 truth of the same gradient for the accuracy tests."""
     import dataclasses
-    sun = torch.as_tensor(sun, dtype=torch.float32).reshape(-1, 3)
+    sun = torch.as_tensor(sun, dtype=dtype).reshape(-1, 3)
     B, N = sun.shape[0], scene.helios.shape[0]
-    normals = torch.as_tensor(action, dtype=torch.float32).reshape(B, N, 3)
-    grad = torch.empty(B, N, 3)
+    normals = torch.as_tensor(action, dtype=dtype).reshape(B, N, 3)
+    errs, G = errs.to(dtype), G.to(dtype)
+    H = None if H is None else H.to(dtype)
+    grad = torch.empty(B, N, 3, dtype=dtype)
     for b in range(B):
         for n0 in range(0, N, n_chunk):
             n1 = min(N, n0 + n_chunk)
@@ -232,19 +235,22 @@ def ideal_normals(helios: torch.Tensor, target_position: torch.Tensor, sun) -> t
 # ------------------------------------------------------------------------------------------
 # HelioEnv.step loss block (reference: test_environment.py) — oracle for the fused HIP losses
 # ------------------------------------------------------------------------------------------
-def angles_mrad(v1: torch.Tensor, v2: torch.Tensor, epsilon: float = 1e-10) -> torch.Tensor:
-    """calculate_angles_mrad, test_environment.py:132-155."""
+def angles_mrad(v1: torch.Tensor, v2: torch.Tensor, epsilon: float = 1e-10, clamp_dtype=None) -> torch.Tensor:
+    """calculate_angles_mrad, test_environment.py:132-155.  ``clamp_dtype`` (accuracy tests only): the dtype
+    the clamp bound ``nextafter(1, 0)`` is formed in — float32 keeps the fp32 path's bound when the rest runs
+    in float64; None = the inputs' dtype, as in the reference."""
     cosang = torch.sum(v1 * v2, dim=-1)
-    one = torch.tensor(1.0, dtype=cosang.dtype)
-    upper = torch.nextafter(one, torch.tensor(0.0, dtype=cosang.dtype))
+    cd = clamp_dtype or cosang.dtype
+    one = torch.tensor(1.0, dtype=cd)
+    upper = torch.nextafter(one, torch.tensor(0.0, dtype=cd))
     return torch.acos(torch.clamp(cosang, min=(-upper).item() + epsilon, max=upper.item() - epsilon)) * 1000
 
 
 def boundary_all(vects, heliostat_pos, targ_pos, targ_norm, targ_area):
     """boundary(..., return_all=True), test_environment.py:101-130, with the axes step() passes
     (:461-462): east (1,0,0), up (0,0,1)."""
-    u = torch.tensor([1.0, 0.0, 0.0])
-    v = torch.tensor([0.0, 0.0, 1.0])
+    u = torch.tensor([1.0, 0.0, 0.0], dtype=vects.dtype)
+    v = torch.tensor([0.0, 0.0, 1.0], dtype=vects.dtype)
     tol = 0.75
     dots = torch.einsum('bij,j->bi', -vects, targ_norm)
     valid = dots.abs() > 1e-6
@@ -262,7 +268,7 @@ def boundary_all(vects, heliostat_pos, targ_pos, targ_norm, targ_area):
 
 
 def step_losses(img, target, distance_maps, ideal, actual, action, heliostat_pos, targ_pos, targ_norm,
-                targ_area, exponential_risk: bool = False, error_mask_ratio=None):
+                targ_area, exponential_risk: bool = False, error_mask_ratio=None, clamp_dtype=None):
     """The loss block of HelioEnv.step, test_environment.py:436-488; ``error_mask_ratio`` selects
     the use_error_mask=True branch (:444-452: only the worst images, by torch.quantile of their
     mean error, enter mse and dist).
@@ -271,7 +277,7 @@ def step_losses(img, target, distance_maps, ideal, actual, action, heliostat_pos
     pred_n, targ_n = img / tx, target / tx
     err = (pred_n - targ_n).abs()
     mae = err.mean(dim=[-2, -1])
-    ang = angles_mrad(ideal, actual)
+    ang = angles_mrad(ideal, actual, clamp_dtype=clamp_dtype)
     if error_mask_ratio is None:
         mse = torch.nn.functional.mse_loss(pred_n, targ_n)
         dist_l = (err * distance_maps).sum((1, 2)).mean()

@@ -45,10 +45,11 @@ def launch_stubs() -> str:
             "splat_bwd_is_few": "return a1 <= 8 || (a1 <= 16 && a0 <= 64) || (a1 <= 32 && a0 <= 8);",
             "env_step_fused_workspace": "return 1024;",
             "render_fwd_choice": "return a1 <= 256 ? 12 : 6;",
+            "render_bwd_choice": "return a1 <= 8 ? 4 : 10;",
             "splat_fwd_scratch_bytes": "return (a1 >= 192 && (a3 == 5 || a3 == 0)) ? 4096 : 0;",
             "splat_fwd_scratch_required": "return (a3 >= 14 && a3 <= 17) ? 8192 : 0;",
             "splat_bwd_scratch_bytes": "return (a1 > 256 && (a3 == 2 || a3 == 0)) ? 4096 : 0;",
-            "render_bwd_is_fused": "return !(a1 <= 8 || (a1 <= 16 && a0 <= 64) || (a1 <= 32 && a0 <= 8)) && a2 <= 256 && !(a2 > 128 && a1 >= 96) && (long)a0 * ((a1 + 31) / 32) <= 64;",
+            "render_bwd_is_fused": "return !(a1 <= 8 || (a1 <= 16 && a0 <= 64) || (a1 <= 32 && a0 <= 8)) && a2 <= 128 && (long)a0 * ((a1 + 31) / 32) <= 64;",
         }
         args = [a.strip() for a in m.group(3).split(",")] if m.group(3).strip() else []
         named = ", ".join(f"{a} a{k}" for k, a in enumerate(args))

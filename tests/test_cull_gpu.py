@@ -10,6 +10,8 @@ import numpy as np
 import pytest
 import torch
 
+from conftest import check_grad
+from grad_floor import CONFIG_BAR
 from oracle import torch_oracle as to
 
 pytestmark = pytest.mark.gpu
@@ -268,7 +270,8 @@ def test_the_full_batch_launches_bench_times_are_held_to_the_oracle(cfg, seed, b
     (b) rows [0:24] are the bits of a 24-sun launch forced to the same kernel; (c) the LAST suns of the batch
     meet the oracle (rtol 1e-5 / atol 1e-8 and max|Δ| ≤ 1e-5·peak); (d) the full-batch backward
     (splat_bwd_mfma<0/1>, culled and dense bit-identical) gives the oracle's gradient for sun 511
-    (max|Δ| ≤ 2e-4·max|grad|; oracle chunked over heliostats, newenv_rl_test_multi_error.py:404-406)."""
+    (max|Δ| ≤ 1.1e-6·max|grad|, 2x the 5.3e-7 measured; oracle chunked over heliostats,
+    newenv_rl_test_multi_error.py:404-406; against the float64 truth: tests/test_grad_accuracy_gpu.py)."""
     from doodle_amd import native
     ops = native.get_ops()
     w, f, sc, suns, errs, act = _full_batch(cfg, seed, b_offset)
@@ -311,8 +314,7 @@ def test_the_full_batch_launches_bench_times_are_held_to_the_oracle(cfg, seed, b
     assert same_bits(grad, grad_dense)
     assert torch.isfinite(grad).all()
     grad_o = to.grad_action_chunked(sc, suns[511:], act[511:], errs[511:], G_last, H_last, n_chunk=25)
-    err = (grad[511:].cpu().reshape(grad_o.shape) - grad_o).abs().max().item()
-    assert err <= 2e-4 * grad_o.abs().max().item(), err / grad_o.abs().max().item()   # (d)
+    check_grad(grad[511:], grad_o, CONFIG_BAR, cfg)                                   # (d)
 
 
 def test_scratch_that_is_missing_or_too_small_runs_the_dense_kernels():

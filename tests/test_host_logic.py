@@ -11,10 +11,14 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import ENV_FIXTURES, ROOT, golden, render_fixture_names
+from conftest import ENV_FIXTURES, ROOT, check_grad, golden, render_fixture_names
 import oracle_backend
 
 NAMES = render_fixture_names()
+# gradients of the CPU model of the kernels' decomposition (tests/oracle_backend.py) against the reference fixtures:
+# max|Δ| / max|ref|, 2x the worst measured in this container (HELIO_RECORD_DEVS, see conftest.check_grad)
+CPU_MODEL_BAR = 1.6e-6
+CPU_MODEL_ENV_BAR = 9e-7
 
 
 def field_from(g, device="cpu"):
@@ -166,8 +170,7 @@ def test_decomposition_matches_reference(name, monkeypatch):
     for loss, key in (((img * G.reshape(img.shape)).sum(), "grad_from_image"),
                       ((actual * H).sum(), "grad_from_actual"), ((refl * Q).sum(), "grad_from_refl")):
         (ga,) = torch.autograd.grad(loss, act, retain_graph=True)
-        ref = g[key]
-        assert np.abs(ga.numpy().reshape(ref.shape) - ref).max() <= 2e-4 * max(np.abs(ref).max(), 1e-30), key
+        check_grad(ga, g[key], CPU_MODEL_BAR, key)
 
 
 @pytest.mark.parametrize("name", ["g1_readme_n50_b25_r64", "g1_single_1d_n50_r64", "g8_ragged_n33_b3_r100"])
@@ -184,7 +187,7 @@ def test_render_value_and_grad_matches_reference_gradients(name, monkeypatch):
     np.testing.assert_allclose(img.numpy(), g["image"], rtol=1e-5, atol=1e-8)
     ref = g["grad_all"]
     assert grad.shape == (np.atleast_2d(g["sun"]).shape[0], 3 * f.num_heliostats)
-    assert np.abs(grad.numpy().reshape(ref.shape) - ref).max() <= 2e-4 * np.abs(ref).max()
+    check_grad(grad, ref, CPU_MODEL_BAR, "grad_all")
     a = act.clone().requires_grad_(True)
     i2, a2, r2 = f.render(sun, a, None, monitor=True)
     (g2,) = torch.autograd.grad((i2 * G.reshape(i2.shape)).sum() + (a2 * H).sum() + (r2 * Q).sum(), a)
@@ -192,7 +195,7 @@ def test_render_value_and_grad_matches_reference_gradients(name, monkeypatch):
     # any subset of the cotangents
     _, _, g_img_only = f.render_value_and_grad(sun, act, G)
     ref = g["grad_from_image"]
-    assert np.abs(g_img_only.numpy().reshape(ref.shape) - ref).max() <= 2e-4 * np.abs(ref).max()
+    check_grad(g_img_only, ref, CPU_MODEL_BAR, "grad_from_image")
 
 
 def test_return_conventions_and_error_selection(monkeypatch):
@@ -307,7 +310,10 @@ def test_env_reset_step_match_reference(tag, monkeypatch):
         (ga,) = torch.autograd.grad(metrics[k], act, retain_graph=True, allow_unused=True)
         ref = g["grad_" + k]
         got = ga.numpy() if ga is not None else np.zeros_like(ref)
-        assert np.abs(got - ref).max() <= 5e-4 * max(np.abs(ref).max(), 1e-30), k
+        if np.any(ref):
+            check_grad(got, ref, CPU_MODEL_ENV_BAR, k)
+        else:
+            assert not np.any(got), k
     for k in monitor:
         np.testing.assert_allclose(monitor[k].detach().numpy(), g["monitor_" + k], rtol=1e-4, atol=2e-3, err_msg=k)
     # ndarray actions are accepted (:411-412); the dead reference branch is refused loudly
@@ -429,3 +435,50 @@ def test_scratch_size_queries_are_consistent_over_random_sizes():
         for v in (1, 6, 7, 8, 10, 11, 12, 13):
             assert lib.helio_fwd_scratch_bytes(B, N, R, v) == 0
     assert seen_lists > 100 and seen_ctile > 20
+
+
+def test_receiver_attributes_are_live(monkeypatch):
+    """The reference reads target_position / target_normal / plane_u / plane_v / target_width / target_height /
+    resolution / sigma_scale from the instance at every render (newenv_rl_test_multi_error.py:387-401).  Host logic on
+    the CPU model: after an assignment (or an in-place write) the field renders what a field CONSTRUCTED with the new
+    value renders, bit for bit; a frame the separable footprint cannot stand for is refused."""
+    from doodle_amd import HelioField
+    oracle_backend.install(monkeypatch)
+    g = golden("g3_tilted_n50_b5_r64")
+    sun, act = torch.from_numpy(g["sun"]), torch.from_numpy(g["action"])
+
+    def fresh(**kw):
+        args = dict(heliostat_positions=g["helios"], target_position=g["target_position"],
+                    target_area=tuple(float(x) for x in g["target_area"]), target_normal=g["target_normal"],
+                    error_scale_mrad=float(g["error_scale_mrad"]), sigma_scale=float(g["sigma_scale"]),
+                    resolution=int(g["resolution"]), max_batch_size=int(g["max_batch_size"]))
+        args.update(kw)
+        f = HelioField(**args)
+        f.error_angles_mrad = torch.from_numpy(g["error_angles_mrad"])
+        f.batch_error_angles_mrad = torch.from_numpy(g["batch_error_angles_mrad"])
+        return f
+
+    f = fresh()
+    base, _ = f.render(sun, act, None)
+    assert np.array_equal(base.numpy(), g["image"]) or np.allclose(base.numpy(), g["image"], rtol=1e-5, atol=1e-8)
+    tp = torch.tensor(g["target_position"]) + torch.tensor([0.5, 0.0, -0.25])
+    f.target_position = tp.tolist()                                   # lists are accepted, as in the constructor
+    assert isinstance(f.target_position, torch.Tensor) and f.target_position.dtype == torch.float32
+    moved, _ = f.render(sun, act, None)
+    assert torch.equal(moved, fresh(target_position=tp).render(sun, act, None)[0])
+    assert not torch.equal(moved, base)
+    f.target_position[0] += 1.0                                       # in place
+    tp2 = tp + torch.tensor([1.0, 0.0, 0.0])
+    assert torch.equal(f.render(sun, act, None)[0], fresh(target_position=tp2).render(sun, act, None)[0])
+    f.target_width, f.target_height, f.resolution, f.sigma_scale = 10.0, 8.0, 24, 0.07
+    want = fresh(target_position=tp2, target_area=(10.0, 8.0), resolution=24, sigma_scale=0.07).render(sun, act, None)[0]
+    got = f.render(sun, act, None)[0]
+    assert got.shape == (5, 24, 24) and torch.equal(got, want)
+    assert torch.equal(f.calculate_ideal_normals(sun), fresh(target_position=tp2).calculate_ideal_normals(sun))
+    with pytest.raises(ValueError, match="orthonormal"):
+        f.plane_u = torch.tensor([2.0, 0.0, 0.0])
+    with pytest.raises(ValueError, match="shape"):
+        f.target_normal = torch.zeros(4)
+    # a copy / pickle rebuilds the records from the attributes
+    import copy
+    assert torch.equal(copy.deepcopy(f).render(sun, act, None)[0], want)

@@ -4,13 +4,16 @@ reference.  Needs an MI355X: run with ``-m gpu``.
 Bars (BASELINE.json north_star):
   * ``actual`` and ``refl``: BIT-EXACT with the reference's CPU fp32 results;
   * image: ``allclose(rtol=1e-5, atol=1e-8)`` per pixel AND max|Δ| ≤ 1e-5·peak;
-  * grad_action (the reference's own fp32 autograd is noisy): max|Δ| ≤ 2e-4·max|grad|.
+  * grad_action: max|Δ| ≤ GRAD_BAR·max|grad| — per backward variant, 2x the worst deviation measured over the
+    fixtures (8e-7 … 2.7e-6; profiles/r04_a_grad_floor.txt).  The ACCURACY of the gradient — against the same formulas in
+    float64, next to the reference's own fp32 error of 2e-5 — is tests/test_grad_accuracy_gpu.py.
 """
 import numpy as np
 import pytest
 import torch
 
-from conftest import golden, render_fixture_names
+from conftest import check_grad, golden, render_fixture_names
+from grad_floor import RENDER_BAR as GRAD_BAR
 
 pytestmark = pytest.mark.gpu
 NAMES = render_fixture_names()
@@ -91,13 +94,9 @@ def test_backward_matches_reference_autograd(name, bwd_variant, monkeypatch):
                       ((actual * H).sum(), "grad_from_actual"),
                       ((refl * Q).sum(), "grad_from_refl")):
         (ga,) = torch.autograd.grad(loss, act, retain_graph=True)
-        ref = g[key]
-        scale = max(np.abs(ref).max(), 1e-30)
-        err = np.abs(ga.cpu().numpy().reshape(ref.shape) - ref).max()
-        assert err <= 2e-4 * scale, f"{key}: {err / scale:.3e}"
+        check_grad(ga, g[key], GRAD_BAR[bwd_variant], key)
     (ga,) = torch.autograd.grad((img * G.reshape(img.shape)).sum() + (actual * H).sum() + (refl * Q).sum(), act)
-    ref = g["grad_all"]
-    assert np.abs(ga.cpu().numpy().reshape(ref.shape) - ref).max() <= 2e-4 * np.abs(ref).max()
+    check_grad(ga, g["grad_all"], GRAD_BAR[bwd_variant], "grad_all")
 
 
 def test_ideal_normals_bit_exact():

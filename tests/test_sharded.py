@@ -96,3 +96,26 @@ def test_gloo_ranks_bit_identical_to_unsharded(tmp_path, monkeypatch, world, nsu
         assert other.numel() == 0 or float(other.abs().max()) == 0.0   # foreign rows: none (no collective)
         total += o["grad"]
     assert torch.equal(total, gfull)                               # the ranks' gradients tile the batch exactly
+
+
+def test_image_gather_never_changes_transport_silently(monkeypatch):
+    """A failed RCCL set-up raises — it does not fall back to torch.distributed with a warning: on a multi-GPU run
+    that would change what bench.py measures, with ``rccl_ranks: null`` as the only trace."""
+    from doodle_amd import comm
+
+    def broken(*a, **k):
+        raise OSError("libhelio_comm.so: cannot open shared object file")
+    monkeypatch.setattr(comm, "load_comm_library", broken)
+    with pytest.raises(RuntimeError, match="HELIO_COMM=torch"):
+        comm.ImageGather(transport="rccl")
+    monkeypatch.setenv("HELIO_COMM", "rccl")                       # what "auto" resolves to on GPUs with an nccl group
+    with pytest.raises(RuntimeError, match="could not be set up"):
+        comm.ImageGather(transport="auto")
+    monkeypatch.delenv("HELIO_COMM")
+    with pytest.raises(ValueError, match="unknown transport"):
+        comm.ImageGather(transport="mpi")
+    g = comm.ImageGather(transport="auto")                         # no GPU, no process group: torch transport, by rule
+    assert g.transport == "torch" and g.rccl_ranks is None
+    out = torch.empty(6)
+    g.gather(torch.arange(6.0), out)
+    assert torch.equal(out, torch.arange(6.0))

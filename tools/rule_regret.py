@@ -1,0 +1,108 @@
+#!/usr/bin/env python3
+"""Rule regret: how far the size rules' own choice (variant 0) is from the best forced variant, forward and backward.
+
+For every (B, N, R) of tools/sweep_render.py's grid plus the neighbourhood of the sizes the reference runs
+(R in {100, 128, 256} x N in {1, 8, 50, 96, 200} x B in {1, 4, 25, 60, 500}: train_with_env.py:227-241 is N=50, B=25,
+R=128; run_experiments.py:31-56 is N=1, B=500) one helio_render_fwd / helio_render_bwd call is timed (HIP events, least
+of three loops) with variant 0 and with every variant that exists at that size.  regret = t(auto) / t(best) - 1.
+The split-bf16 kernels (forward 7 / 8, backward 5) are opt-in, never chosen by the rules, and do not count as "best".
+Inputs: err 40 mrad, sigma_scale 0.02 — every ray lands on the image, so no list shortens anybody's work.
+
+usage: rule_regret.py [quick] [out.txt]
+"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from bench import build_field, make_action, time_kernel  # noqa: E402
+from doodle_amd import native, synthetic  # noqa: E402
+
+dev = torch.device("cuda")
+ops = native.get_ops()
+FWD = (1, 3, 4, 5, 6, 9, 10, 11, 12, 13, 14, 15, 16, 17)
+FWD_OPT_IN = (7, 8)
+BWD = (1, 2, 4, 6, 7, 8, 9, 10, 11)
+BWD_OPT_IN = (5,)
+
+
+def grid(quick):
+    g = [(B, N, R) for R in (64, 128, 256, 512) for N in (50, 200, 1000, 5000) for B in (4, 32, 256)
+         if B * N * R * R <= 3e11]
+    g += [(B, N, R) for R in (100, 128, 256) for N in (1, 8, 50, 96, 200) for B in (1, 4, 25, 60, 500)]
+    seen, out = set(), []
+    for p in g:
+        if p not in seen:
+            seen.add(p)
+            out.append(p)
+    return out[::5] if quick else out
+
+
+def timed(fn, flops):
+    iters = max(5, min(200, int(1e11 / max(flops, 1.0))))
+    try:
+        fn()
+        torch.cuda.synchronize()
+    except RuntimeError:
+        return None                                   # this variant does not exist at this size
+    return time_kernel(fn, iters, warm=3, repeats=3)
+
+
+def main():
+    quick = "quick" in sys.argv[1:]
+    outs = [a for a in sys.argv[1:] if a != "quick"]
+    lines, rows = [], []
+
+    def emit(s):
+        print(s, flush=True)
+        lines.append(s)
+
+    emit(f"{'B':>4} {'N':>5} {'R':>4} | {'fwd auto':>9} {'=v':>3} {'best':>9} {'v':>3} {'regret':>7} | "
+         f"{'bwd auto':>9} {'=v':>3} {'best':>9} {'v':>3} {'regret':>7}")
+    for B, N, R in grid(quick):
+        w = synthetic.Workload("s", N=N, B=B, R=R, sigma_scale=0.02, error_scale_mrad=40.0, span=30.0 if N > 100 else 10.0)
+        helios, suns, errs, noise = synthetic.make_inputs(w, 0)
+        f = build_field(w, helios, errs, dev)
+        suns_d = suns.to(dev)
+        act = make_action(f, suns_d, noise)
+        trig, stride = f._select_trig(B)
+        normals = act.reshape(B, N, 3).contiguous()
+        G = torch.randn(B, R, R, device=dev)
+        flops = 2.0 * B * N * R * R
+        hp, pl, xs, ys = f.heliostat_positions, f._plane, f._xs, f._ys
+        with torch.no_grad():
+            rays = ops.render_fwd(hp, suns_d, normals, trig, stride, pl, xs, ys)[3]
+            tf, tb = {}, {}
+            for v in (0,) + FWD + FWD_OPT_IN:
+                if 14 <= v <= 17 and N < 128 * (2 << (v - 14)):        # a split heliostat sum wants parts of >= 128 rays
+                    tf[v] = None
+                    continue
+                tf[v] = timed(lambda: ops.render_fwd(hp, suns_d, normals, trig, stride, pl, xs, ys, rays=rays, variant=v), flops)
+            ops.render_fwd(hp, suns_d, normals, trig, stride, pl, xs, ys, rays=rays)
+            for v in (0,) + BWD + BWD_OPT_IN:
+                tb[v] = timed(lambda: ops.render_bwd(hp, suns_d, normals, trig, stride, pl, rays, xs, ys, G, None, None, variant=v), 2 * flops)
+        bf = min((v for v in FWD if tf[v] is not None), key=lambda v: tf[v])
+        bb = min((v for v in BWD if tb[v] is not None), key=lambda v: tb[v])
+        rf, rb = tf[0] / tf[bf] - 1.0, tb[0] / tb[bb] - 1.0
+        cf, cb = ops.render_choice(B, N, R), ops.render_bwd_choice(B, N, R)
+        emit(f"{B:4d} {N:5d} {R:4d} | {tf[0] * 1e6:9.1f} {cf:3d} {tf[bf] * 1e6:9.1f} {bf:3d} {rf * 100:6.1f}% | "
+             f"{tb[0] * 1e6:9.1f} {cb:3d} {tb[bb] * 1e6:9.1f} {bb:3d} {rb * 100:6.1f}%")
+        rows.append((B, N, R, "fwd", cf, bf, tf[0], tf[bf], rf, {v: t for v, t in tf.items() if t is not None}))
+        rows.append((B, N, R, "bwd", cb, bb, tb[0], tb[bb], rb, {v: t for v, t in tb.items() if t is not None}))
+        del f, G, rays
+        torch.cuda.empty_cache()
+    emit("")
+    emit("worst ten (regret of the rules' choice against the best forced variant):")
+    for B, N, R, which, c, best, t0, tbest, reg, allv in sorted(rows, key=lambda r: -r[8])[:10]:
+        every = " ".join(f"v{v}={t * 1e6:.1f}" for v, t in sorted(allv.items()))
+        emit(f"  {which} B={B} N={N} R={R}: auto (= v{c}) {t0 * 1e6:.1f} us, best v{best} {tbest * 1e6:.1f} us, regret {reg * 100:.1f}%   [{every}]")
+    worst = max(r[8] for r in rows)
+    emit(f"max regret {worst * 100:.1f}% over {len(rows)} (size, direction) pairs")
+    if outs:
+        with open(outs[0], "w") as fh:
+            fh.write("\n".join(lines) + "\n")
+
+
+if __name__ == "__main__":
+    main()
