@@ -67,9 +67,12 @@ from doodle_amd import native, synthetic  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 F32_MFMA_PEAK_TF = 157.3     # dense f32 MFMA = f32 vector peak (spec)
-TRAFFIC_FILES = ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json")     # newest first
+TRAFFIC_FILES = ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json")     # newest first
+# the source file a kernel of the traffic files is built from: EVERY entry this file prints is checked against the hash
+# of that file as it is now (measured_traffic), so a pass taken on other code is refused, not quoted
 KERNEL_SOURCE = {"splat_fwd_mfma_tile": "splat_fwd.hip", "render_fwd_fused_small": "splat_fwd.hip",
-                 "splat_fwd_mfma_tile(culled)": "splat_fwd.hip"}
+                 "splat_fwd_mfma_tile(culled)": "splat_fwd.hip", "cull_fwd_kernel": "cull.hip",
+                 "render_fwd_few": "splat_fwd.hip"}
 
 
 def build_field(w, helios, errs, device, max_batch=None):
@@ -808,6 +811,26 @@ def hbm_leg(dev, B=512, N=2000, R=512, iters=20):
 
     t = time_kernel(fused, iters)
     out["env_step_bwd_few_ray(N=1)"] = entry(t, 12.0 * B * R * R, "img + target + distance map read once (2 launches)")
+    # … and the footprint FORWARD where it is HBM-bound: a handful of rays per image (the reference's test-time-compute
+    # sweeps run ONE heliostat and 500 suns, run_experiments.py:31-56) — render_fwd_few, the whole render in one launch,
+    # bound by writing the image once; north_star's ">= 60 % of peak HBM" has its measured counterpart here
+    for Bf, Nf2, Rf in ((B, 1, R), (B, 8, R), (500, 1, 128)):
+        wf = synthetic.Workload("few", N=Nf2, B=Bf, R=Rf, sigma_scale=0.02, error_scale_mrad=40.0)
+        hf, sf, ef, nf = synthetic.make_inputs(wf, 0)
+        ff = build_field(wf, hf, ef, dev)
+        sfd = sf.to(dev)
+        af = make_action(ff, sfd, nf).reshape(Bf, Nf2, 3).contiguous()
+        tg, sd = ff._select_trig(Bf)
+        with torch.no_grad():
+            ws = ops.render_fwd(ff.heliostat_positions, sfd, af, tg, sd, ff._plane, ff._xs, ff._ys, want_refl=False)[3]
+            xs_f, ys_f, pl_f = ff._xs, ff._ys, ff._plane
+            t = time_kernel(lambda: ops.render_fwd(ff.heliostat_positions, sfd, af, tg, sd, pl_f, xs_f, ys_f, want_refl=False,
+                                                   rays=ws, variant=13), max(iters, 50 if Bf * Rf * Rf < 1e8 else iters))
+        key = f"render_fwd_few(B={Bf},N={Nf2},R={Rf})"
+        out[key] = entry(t, 4.0 * Bf * Rf * Rf + 44.0 * Bf * Nf2, "the image written once, 44 B per ray (one launch = the whole render)")
+        tr, note = measured_traffic("render_fwd_few", Nf2, Bf, Rf)
+        if tr is not None or "stale" in note:
+            out[key]["traffic"], out[key]["traffic_source"] = tr, note
     return out
 
 
@@ -918,6 +941,8 @@ def large_leg(dev, seed, iters=20):
             "image_bit_identical_with_dense": culled[2]}
         r["culled"]["traffic"], r["culled"]["traffic_source"] = measured_traffic("splat_fwd_mfma_tile(culled)", w.N, w.B, w.R)
         r["culled"]["algorithmic_bytes"] = 4.0 * w.B * w.R * w.R + 16.0 * live * w.B * w.N * 4 + 8.0 * w.R
+        # the compaction launch in front of it: reads every ray once per tile row … writes the lists
+        r["culled"]["list_kernel_traffic"], r["culled"]["list_kernel_traffic_source"] = measured_traffic("cull_fwd_kernel", w.N, w.B, w.R)
     # backward at the same size: forward + backward kernels for given cotangents (no autograd graph), default
     # (culled) and dense, interleaved
     try:

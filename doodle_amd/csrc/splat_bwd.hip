@@ -383,6 +383,211 @@ splat_bwd_mfma_body(int B, int N, int R, const float* __restrict__ rays, const f
     }
 }
 
+// ---- the same tile with the two LDS tables DOUBLE-BUFFERED (round 4) ---------------------------------------------
+// The body above alternates two phases per 64-deep chunk, separated by barriers: every wave stores its share of the slab
+// and computes its share of the factor table (16 exponentials and their fused multiply-adds per thread: VALU), then
+// every wave issues its 128 MFMAs.  In the first phase the matrix pipe of all four SIMDs idles — PMC (round 2): pipe busy
+// 85.6 % of the kernel's cycles.  Here a chunk is 32 deep and the tables exist twice (2 × 66.5 KB): while a wave issues
+// the MFMAs of chunk c out of one pair of tables it produces chunk c + 1 into the other — one factor after every eight
+// MFMAs, in the shadow of the pipe — and ONE barrier per chunk hands the pairs over.  Same operands, same order of the
+// contracted axis, same epilogue: the moments are the bits of the single-buffered body.
+template <int PASS, bool VEC, int WC>
+__device__ __forceinline__ void
+splat_bwd_mfma_body_db(int B, int N, int R, const float* __restrict__ rays, const float* __restrict__ xs,
+                       const float* __restrict__ ys, const float* __restrict__ gimg, float* __restrict__ moments,
+                       const int* __restrict__ live_counts, const int* __restrict__ live_idx, const int* __restrict__ live_total,
+                       const int2* __restrict__ live_map, int live_ct) {
+    static_assert(!(VEC && PASS == 1), "16-byte staging is pass 0's");
+    constexpr int WR = 4, KC = 32, T = 64 * WR, TC = 64 * WC, NT = 64 * WC * WR, KPT = KC / WC, NV = KC * TC / NT;
+    static_assert(NV == 8 && (KPT == 8 || KPT == 16), "8 slab values and 8 or 16 factors per thread and chunk");
+    constexpr int LDG = PASS == 0 ? TC + 4 : TC + 1, LD = PASS == 0 ? T + 4 : T + 1;
+    constexpr int BUF = KC * (LDG + LD);                            // floats of one pair of tables
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // 2 × { sG[KC][LDG] sF[KC][LD] }  ccoord[TC]
+    float* __restrict__ sCc = smem + 2 * BUF;
+
+    const int c_tiles = (R + TC - 1) / TC;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 31, lh = lane >> 5;
+    int b = blockIdx.y, bx = blockIdx.x, lst = 0;
+    if (live_counts) {                                              // (cull.h: the tile comes from the work map)
+        const unsigned w = blockIdx.x + gridDim.x * blockIdx.y;
+        const unsigned per = live_ct > 1 ? 1u : (unsigned)c_tiles;
+        const unsigned item = w / per;
+        if (item >= (unsigned)*live_total) return;
+        const int2 e = live_map[item];
+        lst = e.x;
+        b = live_ct > 1 ? e.x / c_tiles : e.x;
+        bx = e.y * c_tiles + (live_ct > 1 ? e.x % c_tiles : (int)(w % per));
+    }
+    const int c0 = (bx % c_tiles) * TC, n0 = (bx / c_tiles) * CULL_BWD_TILE;
+    const int L = live_counts ? live_counts[lst] : N;
+    const int* __restrict__ lidx = live_counts ? live_idx + (long)lst * N : nullptr;
+    const int wc = (wave / WR) * 64, wn = (wave % WR) * 64;
+    const float* __restrict__ ccoord = PASS == 0 ? ys : xs;
+    const float* __restrict__ kcoord = PASS == 0 ? xs : ys;
+    const float* __restrict__ G = gimg + (long)b * R * R;
+
+    if (tid < TC) sCc[tid] = ccoord[min(c0 + tid, R - 1)];
+
+    // producer role for the factor table: ray wn + lane of the tile, KPT k of every chunk
+    const int pr = wn + lane;
+    const int pk0 = (wave / WR) * KPT;
+    float4 q = make_float4(0.f, 0.f, 1.f, 1e30f);
+    if (n0 + pr < L) q = reinterpret_cast<const float4*>(rays)[(long)b * N + (lidx ? lidx[n0 + pr] : n0 + pr)];
+    const float sk = __builtin_sqrtf(q.z);
+    const float fshift = (PASS == 0 ? q.x : q.y) * sk;
+    const float fcc = PASS == 0 ? q.w * q.z : 0.0f;
+    const int foff = KC * LDG + pk0 * LD + pr;                      // this thread's first factor, inside a pair of tables
+
+    // loader role for the grad-image slab Gm[k][c]: 8 dwords per thread and chunk (layouts as in the body above)
+    float gv[NV];
+    auto load_slab = [&](int k0) {
+        if constexpr (VEC) {
+#pragma unroll
+            for (int v = 0; v < NV / 4; ++v) {
+                const int p = tid + NT * v;
+                const int row = k0 + p / (TC / 4), col = c0 + 4 * (p % (TC / 4));
+                float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (row < R && col < R) t = *reinterpret_cast<const float4*>(G + (long)row * R + col);
+                gv[4 * v] = t.x; gv[4 * v + 1] = t.y; gv[4 * v + 2] = t.z; gv[4 * v + 3] = t.w;
+            }
+        } else {
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const int idx = tid + NT * v;
+                const int k = PASS == 0 ? idx / TC : idx & (KC - 1), c = PASS == 0 ? idx % TC : idx / KC;
+                const int row = PASS == 0 ? k0 + k : c0 + c, col = PASS == 0 ? c0 + c : k0 + k;
+                gv[v] = (row < R && col < R) ? G[(long)row * R + col] : 0.0f;
+            }
+        }
+    };
+    auto store_slab = [&](float* __restrict__ buf) {
+        if constexpr (VEC) {
+#pragma unroll
+            for (int v = 0; v < NV / 4; ++v) {
+                const int p = tid + NT * v;
+                *reinterpret_cast<float4*>(buf + (p / (TC / 4)) * LDG + 4 * (p % (TC / 4))) =
+                    make_float4(gv[4 * v], gv[4 * v + 1], gv[4 * v + 2], gv[4 * v + 3]);
+            }
+        } else {
+            lds_f* dst = (lds_f*)buf;
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const int idx = tid + NT * v;
+                const int k = PASS == 0 ? idx / TC : idx & (KC - 1), c = PASS == 0 ? idx % TC : idx / KC;
+                dst[k * LDG + c] = gv[v];
+            }
+        }
+    };
+    // factor j of the chunk at k0 → the pair of tables at `buf`; kc = the chunk's coordinate pk0 + j (wave-uniform)
+    auto factor = [&](float* __restrict__ buf, int k0, int j, float kc) {
+        const float t = __builtin_fmaf(kc, sk, fshift);
+        float f = __builtin_amdgcn_exp2f(-__builtin_fmaf(t, t, fcc));
+        if (k0 + pk0 + j >= R) f = 0.0f;                            // rows / columns past the image contract nothing
+        ((lds_f*)buf)[foff + j * LD] = f;
+    };
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[m][e] = 0.0f;
+
+    // chunk 0 into pair 0; chunk 1's slab into the registers, its coordinates into scalars
+    float kc[KPT];
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) kc[j] = kcoord[min(pk0 + j, R - 1)];
+    load_slab(0);
+    store_slab(smem);
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) factor(smem, 0, j, kc[j]);
+    load_slab(KC);
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) kc[j] = kcoord[min(KC + pk0 + j, R - 1)];
+    __syncthreads();
+
+    const int goff = lh * LDG + wc + lr, foff_c = KC * LDG + lh * LD + wn + lr;      // consumer operands inside a pair
+    for (int k0 = 0; k0 < R; k0 += KC) {
+        const int cur = (k0 / KC) & 1;
+        float* __restrict__ bufc = smem + cur * BUF;
+        float* __restrict__ bufn = smem + (cur ^ 1) * BUF;
+        lds_cf* pg = (lds_cf*)bufc + goff;
+        lds_cf* pf = (lds_cf*)bufc + foff_c;
+        const bool more = k0 + KC < R;                              // (uniform) a chunk to produce beside this one's MFMAs
+        // eight segments: two k-pairs (8 MFMAs) and a share of the next chunk's production each
+#pragma unroll
+        for (int seg = 0; seg < 8; ++seg) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int kp = 2 * seg + h;
+                const float g0 = pg[kp * 2 * LDG], g1 = pg[kp * 2 * LDG + 32];
+                const float f0 = pf[kp * 2 * LD], f1 = pf[kp * 2 * LD + 32];
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(g0, f0, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(g0, f1, acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(g1, f0, acc[2], 0, 0, 0);
+                acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(g1, f1, acc[3], 0, 0, 0);
+            }
+            if (more) {
+                if (seg == 0) store_slab(bufn);                     // chunk c + 1's slab (fetched a chunk ago)
+                if (seg == 1) load_slab(k0 + 2 * KC);               // chunk c + 2's: in flight for a whole chunk
+#pragma unroll
+                for (int jj = 0; jj < KPT / 8; ++jj) {
+                    const int j = seg * (KPT / 8) + jj;
+                    factor(bufn, k0 + KC, j, kc[j]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (more) {
+#pragma unroll
+            for (int j = 0; j < KPT; ++j) kc[j] = kcoord[min(k0 + 2 * KC + pk0 + j, R - 1)];
+        }
+        __syncthreads();                                            // pair cur consumed by everybody, pair cur^1 complete
+    }
+
+    // epilogue: as in the body above
+    const int JB = (R + 63) / 64;
+    const int cblock = (c0 + wc) / 64;
+    if (c0 + wc >= R) return;
+    const int lane2 = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const int lr2 = lane2 & 31, lh2 = lane2 >> 5;
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+        const int p = n0 + wn + 32 * nb + lr2;
+        const int n = p < L ? (lidx ? lidx[p] : p) : N;
+        float4 h = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n < N) h = reinterpret_cast<const float4*>(rays)[(long)b * N + n];
+        const float hshift = PASS == 0 ? h.y : h.x;
+        const float hcc = PASS == 0 ? 0.0f : h.w;
+        const f32x2 sh = {hshift, hshift}, cc2 = {hcc, hcc}, nk = {-h.z, -h.z};
+        f32x2 m0 = {0.f, 0.f}, m1 = {0.f, 0.f}, m2 = {0.f, 0.f};
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+#pragma unroll
+            for (int e = 0; e < 16; e += 2) {
+                const int cl = wc + 32 * cb + (e & 3) + 8 * (e >> 2) + 4 * lh2;
+                const f32x2 s = *reinterpret_cast<const f32x2*>(&sCc[cl]) + sh;
+                const f32x2 ss = s * s;
+                const f32x2 arg = (ss + cc2) * nk;
+                const f32x2 a = {acc[2 * cb + nb][e], acc[2 * cb + nb][e + 1]};
+                const f32x2 ex = {__builtin_amdgcn_exp2f(arg.x), __builtin_amdgcn_exp2f(arg.y)};
+                const f32x2 w = ex * a;
+                m0 += w;
+                m1 += s * w;
+                m2 += ss * w;
+            }
+        }
+        float t0 = m0.x + m0.y, t1 = m1.x + m1.y, t2 = m2.x + m2.y;
+        t0 += __shfl_xor(t0, 32); t1 += __shfl_xor(t1, 32); t2 += __shfl_xor(t2, 32);
+        if (lh2 == 0 && n < N) {
+            float* o = moments + (((long)b * JB + cblock) * N + n) * HELIO_MOMENT_STRIDE;
+            if (PASS == 0) { o[0] = t0; o[2] = t1; o[4] = t2; }
+            else { o[1] = t1; o[3] = t2; }
+        }
+    }
+}
+
 template <int PASS, bool VEC, int WC = 4>
 __global__ void __launch_bounds__(256 * WC)
 splat_bwd_mfma(int B, int N, int R, const float* __restrict__ rays, const float* __restrict__ xs,
@@ -396,7 +601,8 @@ splat_bwd_mfma(int B, int N, int R, const float* __restrict__ rays, const float*
 // of pass 0 — the last, partly filled round of its workgroups — runs beside the head of pass 1.  set_lists /
 // map_stride: where pass 1's lists and its part of the work map start when every (pass, c tile) has lists of its
 // own (cull.h), else unused.  WR = 2: the 128-ray form, run over the map of short last tiles.
-template <bool VEC, int WC, int WR>
+// DB: the double-buffered body (256-ray tiles only)
+template <bool VEC, int WC, int WR, bool DB = false>
 // (launch bounds — 256-wide tiles: four waves a SIMD, one 16-wave workgroup or two 8-wave ones per CU; 128-wide: two, one
 // 8-wave workgroup with its 101 KB of LDS)
 __global__ void __launch_bounds__(64 * WC * WR, WC == 4 ? 4 : 2)
@@ -404,13 +610,18 @@ splat_bwd_mfma_both(int B, int N, int R, const float* __restrict__ rays, const f
                     const float* __restrict__ ys, const float* __restrict__ gimg, float* __restrict__ moments,
                     const int* __restrict__ live_counts, const int* __restrict__ live_idx, const int* __restrict__ live_total,
                     const int2* __restrict__ live_map, int live_ct, long set_lists, long map_stride) {
+    static_assert(!DB || WR == 4, "the double-buffered body is the 256-ray tile's");
     if (blockIdx.z == 0) {
-        splat_bwd_mfma_body<0, VEC, WC, WR>(B, N, R, rays, xs, ys, gimg, moments, live_counts, live_idx, live_total, live_map, live_ct);
+        if constexpr (DB) splat_bwd_mfma_body_db<0, VEC, WC>(B, N, R, rays, xs, ys, gimg, moments, live_counts, live_idx, live_total, live_map, live_ct);
+        else splat_bwd_mfma_body<0, VEC, WC, WR>(B, N, R, rays, xs, ys, gimg, moments, live_counts, live_idx, live_total, live_map, live_ct);
     } else {
         const bool own = live_counts && live_ct > 1;
-        splat_bwd_mfma_body<1, false, WC, WR>(B, N, R, rays, xs, ys, gimg, moments, own ? live_counts + set_lists : live_counts,
-                                              own ? live_idx + set_lists * N : live_idx, own ? live_total + 1 : live_total,
-                                              own ? live_map + map_stride : live_map, live_ct);
+        const int* lc = own ? live_counts + set_lists : live_counts;
+        const int* li = own ? live_idx + set_lists * N : live_idx;
+        const int* lt = own ? live_total + 1 : live_total;
+        const int2* lm = own ? live_map + map_stride : live_map;
+        if constexpr (DB) splat_bwd_mfma_body_db<1, false, WC>(B, N, R, rays, xs, ys, gimg, moments, lc, li, lt, lm, live_ct);
+        else splat_bwd_mfma_body<1, false, WC, WR>(B, N, R, rays, xs, ys, gimg, moments, lc, li, lt, lm, live_ct);
     }
 }
 
@@ -699,6 +910,7 @@ splat_bwd_mfma_small(int N, int R, const float* __restrict__ rays, const float* 
 // at once.  Those lanes request their ray's inputs before the contraction starts; the moments never
 // touch memory.  Sums in fixed order (k parts, then c blocks — the order the two-launch path adds them in).
 bool splat_bwd_is_few(int B, int N);
+bool splat_bwd_is_few(int B, int N, int R);
 
 template <int CT>
 __global__ void __launch_bounds__(1024)
@@ -768,7 +980,7 @@ bool render_bwd_is_fused(int B, int N, int R) {
     // (R > 128: round 3 let images of up to 256 pixels in while N < 96 — its CT = 4 form cuts the contracted axis between
     // two waves only, and tools/rule_regret.py showed it 2.3x behind the two launches there: B = 4, N = 50, R = 256,
     // 34.6 against ≈15 µs)
-    if (off || splat_bwd_is_few(B, N) || R > 128) return false;
+    if (off || splat_bwd_is_few(B, N, R) || R > 128) return false;
     return (long)B * ((N + 31) / 32) <= 64;
 }
 
@@ -828,25 +1040,25 @@ static void launch_bwd_mfma_v(int B, int N, int R, const float* rays, const floa
                        c.counts, c.idx, c.total, c.map, c.ct);
 }
 
-template <bool VEC, int WC, int WR>
+template <bool VEC, int WC, int WR, bool DB = false>
 static void launch_bwd_mfma_both_v(int B, int N, int R, const float* rays, const float* xs, const float* ys,
                                    const float* gimg, float* moments, hipStream_t st, CullBwd c) {
-    constexpr int TC = 64 * WC, T = 64 * WR, KC = WR == 2 ? 32 : 64;
-    const size_t lds = (KC * ((TC + 4) + (T + 4)) + TC + 64) * sizeof(float);      // pass 0's pitches: the larger of the two
+    constexpr int TC = 64 * WC, T = 64 * WR, KC = (WR == 2 || DB) ? 32 : 64;
+    const size_t lds = ((DB ? 2 : 1) * KC * ((TC + 4) + (T + 4)) + TC + 64) * sizeof(float);      // pass 0's pitches: the larger of the two
     static bool configured = false;
     if (!configured) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(splat_bwd_mfma_both<VEC, WC, WR>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(splat_bwd_mfma_both<VEC, WC, WR, DB>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         configured = true;
     }
     const int ct = (R + TC - 1) / TC, nt = (N + 255) / 256;
     if (WR == 4) {
-        hipLaunchKernelGGL((splat_bwd_mfma_both<VEC, WC, WR>), dim3(ct * nt, B, 2), dim3(64 * WC * WR), lds, st, B, N, R, rays, xs, ys, gimg,
+        hipLaunchKernelGGL((splat_bwd_mfma_both<VEC, WC, WR, DB>), dim3(ct * nt, B, 2), dim3(64 * WC * WR), lds, st, B, N, R, rays, xs, ys, gimg,
                            moments, c.counts, c.idx, c.total, c.map, c.ct, c.set_lists, c.set_items);
     } else {
         // the short last tiles: at most one per list (and c tile, where a list serves all of an image's c tiles)
         const long items = c.set_lists * (c.ct > 1 ? 1 : ct);
-        hipLaunchKernelGGL((splat_bwd_mfma_both<VEC, WC, WR>), dim3((unsigned)items, 1, 2), dim3(64 * WC * WR), lds, st, B, N, R, rays, xs, ys,
+        hipLaunchKernelGGL((splat_bwd_mfma_both<VEC, WC, WR, DB>), dim3((unsigned)items, 1, 2), dim3(64 * WC * WR), lds, st, B, N, R, rays, xs, ys,
                            gimg, moments, c.counts, c.idx, c.tail_total, c.tail_map, c.ct, c.set_lists, c.set_lists);
     }
 }
@@ -882,7 +1094,11 @@ static void launch_bwd_mfma_both(int B, int N, int R, const float* rays, const f
         if (vec) launch_bwd_mfma_both_v<true, 2, 4>(B, N, R, rays, xs, ys, gimg, moments, st, cull);
         else launch_bwd_mfma_both_v<false, 2, 4>(B, N, R, rays, xs, ys, gimg, moments, st, cull);
     } else if (vec) {
-        launch_bwd_mfma_both_v<true, 4, 4>(B, N, R, rays, xs, ys, gimg, moments, st, cull);
+        // HELIO_BWD_DB=0: the single-buffered body (A/B runs; the same bits)
+        const char* e = getenv("HELIO_BWD_DB");        // (read per call — these launches are milliseconds — so that a test can compare the two bodies in one process)
+        const bool db = !(e && e[0] == '0');
+        if (db) launch_bwd_mfma_both_v<true, 4, 4, true>(B, N, R, rays, xs, ys, gimg, moments, st, cull);
+        else launch_bwd_mfma_both_v<true, 4, 4>(B, N, R, rays, xs, ys, gimg, moments, st, cull);
         if (cull.tail_map) launch_bwd_mfma_both_v<true, 4, 2>(B, N, R, rays, xs, ys, gimg, moments, st, cull);
     } else {
         launch_bwd_mfma_both_v<false, 4, 4>(B, N, R, rays, xs, ys, gimg, moments, st, cull);
@@ -1326,6 +1542,12 @@ static void launch_bwd_few(int B, int N, int R, const float* rays, const float* 
 // where the few-ray kernel wins (tools/sweep_bwd.py, MI355X): its time grows with B·N·R², the
 // MFMA kernels' with the number of 64-ray tiles
 bool splat_bwd_is_few(int B, int N) { return N <= 8 || (N <= 16 && B <= 64) || (N <= 32 && B <= 8); }
+// … and, knowing the image size, the rule the backward uses (round 4, tools/rule_regret.py): with 3..32 rays per image
+// and few pixels in all the small MFMA kernel's latency is the shorter one — N = 8, R = 128, B <= 60: 11.7 against
+// 8.8–9.4 µs; from ≈2 M pixels (B = 60, R = 256) the streaming kernel is level or ahead.  One or two rays: always.
+bool splat_bwd_is_few(int B, int N, int R) {
+    return splat_bwd_is_few(B, N) && (N <= 2 || (long)B * R * R >= (1l << 21));
+}
 
 // backward through the image losses with the cotangent formed on the fly (few rays only)
 void launch_splat_bwd_fused_loss(int B, int N, int R, const float* rays, const float* xs, const float* ys,
@@ -1346,7 +1568,7 @@ int splat_bwd_blocks(int R) { return (R + BW_JT - 1) / BW_JT; }
 // 4 = few-ray streaming kernel, 5 = split-bf16 MFMA kernels (opt-in), 6 / 7 = the small kernel with 4 / 8 waves
 // the kernel family variant 0 stands for at this size
 static int splat_bwd_choice(int B, int N, int R) {
-    if (splat_bwd_is_few(B, N)) return 4;
+    if (splat_bwd_is_few(B, N, R)) return 4;
     // tools/sweep_bwd.py, tools/sweep_bwd_mid.py: the LDS-tile kernels (256 rays × 256 c, or × 128 c for images of at
     // most 128 pixels across) against the small-tile kernel; below 65 pixels even the narrow tile is half padding and
     // the small-tile kernel is its equal.  Both passes of the LDS-tile kernels are ONE launch of 2·tiles workgroups, one

@@ -46,7 +46,11 @@ __device__ __forceinline__ float exp2_fast(float x) { return __builtin_amdgcn_ex
 #ifdef HELIO_STAMPS
 __device__ unsigned long long* g_stamps = nullptr;        // [workgroup][wave][HELIO_NSTAMP]
 #define HELIO_NSTAMP 12
-#define HSTAMP_DECL unsigned long long stamp_[HELIO_NSTAMP] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define HSTAMP_DECL unsigned long long stamp_[HELIO_NSTAMP] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; long stamp_slot_ = 0
+// two consecutive launches keep their stamps apart: launch_fused puts the slot helio_diag_set_slot() chose into bit 17 of
+// the R argument, and slot 1 writes behind slot 0's [workgroups][waves][HELIO_NSTAMP] block
+__device__ long g_stamp_slot_words = 0;
+#define HSTAMP_SLOT(x) stamp_slot_ = (long)(x) * g_stamp_slot_words
 #define HSTAMP(k)                                                                                   \
     do {                                                                                            \
         __builtin_amdgcn_sched_barrier(0);                                                          \
@@ -68,12 +72,13 @@ __device__ unsigned long long* g_stamps = nullptr;        // [workgroup][wave][H
 #define HSTAMP_FLUSH()                                                                              \
     do {                                                                                            \
         if (g_stamps && (threadIdx.x & 63) == 0) {                                                  \
-            unsigned long long* o_ = g_stamps + ((((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6)) * HELIO_NSTAMP; \
+            unsigned long long* o_ = g_stamps + stamp_slot_ + ((((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6)) * HELIO_NSTAMP; \
             for (int k_ = 0; k_ < HELIO_NSTAMP; ++k_) o_[k_] = stamp_[k_];                          \
         }                                                                                           \
     } while (0)
 #else
 #define HSTAMP_DECL
+#define HSTAMP_SLOT(x)
 #define HSTAMP(k)
 #define HSTAMP_VM(k)
 #define HSTAMP_REAL(k)
@@ -712,7 +717,7 @@ render_fwd_fused_small(int N, int R_and_flag, const float* __restrict__ helios, 
     // into scalar registers with the wave launch (-mllvm -amdgpu-kernarg-preload-count=14,
     // doodle_amd/build.py).  N <= 64·KG: one wave-load of rays per wave, no loop around the trace.
     const int R = R_and_flag & 0xFFFF;
-    const long trig_b_stride = (R_and_flag >> 16) ? 4l * N : 0l;
+    const long trig_b_stride = ((R_and_flag >> 16) & 1) ? 4l * N : 0l;
     constexpr int OWN = 16 / KG;                       // accumulator registers a wave owns after the exchange
     constexpr int Q4 = OWN / 4;                        // … as 16-byte groups
     __shared__ float4 sRay[64 * KG + 4];
@@ -726,6 +731,7 @@ render_fwd_fused_small(int N, int R_and_flag, const float* __restrict__ helios, 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     HSTAMP_DECL;
+    HSTAMP_SLOT((R_and_flag >> 17) & 1);               // (diagnostic build: which half of the stamp buffer this launch writes)
     HSTAMP_REAL(8);
     HSTAMP(0);
     LateRegs lr_;
@@ -973,6 +979,13 @@ render_fwd_fused_small(int N, int R_and_flag, const float* __restrict__ helios, 
 extern "C" int helio_diag_set_stamps(unsigned long long* stamps_d) {
     return hipMemcpyToSymbol(HIP_SYMBOL(helio::g_stamps), &stamps_d, sizeof(stamps_d)) == hipSuccess ? 0 : -1;
 }
+// … and, for stamping two CONSECUTIVE launches: the size of one launch's stamp block in 64-bit words, and the slot (0 / 1)
+// the launches enqueued from now on write (a host-side value carried by each launch's own arguments)
+static int g_diag_slot = 0;
+extern "C" int helio_diag_set_slot_words(long words) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(helio::g_stamp_slot_words), &words, sizeof(words)) == hipSuccess ? 0 : -1;
+}
+extern "C" void helio_diag_set_slot(int slot) { g_diag_slot = slot & 1; }
 namespace helio {
 #endif
 
@@ -981,22 +994,29 @@ namespace helio {
 // the target image and the distance map in — not by arithmetic, and 32×32 MFMA blocks would each
 // re-trace the same ray (the block kernel above ran that shape at 44 % of the HBM rate).  Here a
 // workgroup owns a band of FEW_ROWS image rows of one sun: threads 0..N-1 trace the rays once into LDS,
-// then every thread walks 16-byte pixel quads of the band (lanes ↔ consecutive quads: coalesced
-// float4 stores and loads), evaluating  Σ_n A_n[i]·E_n[j]  directly (1 + 4 exponentials per ray and
-// quad).  LOSS = true: HelioEnv.step's forward in the same launch — the band's share of the three image
-// sums from the pixels in registers, and band 0 also does the per-ray side work (outputs, the two ray
-// losses, the `aux` row).  Partials: [B, bands, 3] / [B, 2], reduced by step_losses_final in fixed
-// order.  Needs R % 4 == 0 and 16-byte aligned images; anything else takes the block kernel.
+// the band's row factors A_n[i] follow (one exponential per thread), and then a thread keeps ONE 16-byte
+// column quad for the whole band — its column factors E_n[j..j+3] live in registers, 4 exponentials per ray
+// and thread, once — and walks down the band's rows: per row and quad N broadcast LDS reads, 4·N FMAs and one
+// float4 store (lanes ↔ consecutive quads: a wave writes 1 KB of consecutive addresses).  Round 3's form
+// evaluated 1 + 4 exponentials per ray and QUAD: at N = 8 that is 40 quarter-rate instructions per 16 bytes,
+// compute-bound at a third of the HBM rate; the sums are the same fmaf chains over the same factors (same
+// bits).  LOSS = true: HelioEnv.step's forward in the same launch — the band's share of the three image sums
+// from the pixels in registers, and band 0 also does the per-ray side work (outputs, the two ray losses,
+// the `aux` row).  Partials: [B, bands, 3] / [B, 2], reduced by step_losses_final in fixed order.  Needs
+// R % 4 == 0 and 16-byte aligned images; anything else takes the block kernel.
 constexpr int FEW_ROWS = 32, FEW_MAX_RAYS = 8;
 
-template <bool LOSS>
-__global__ void __launch_bounds__(256)
+// NMAX: 1, 2, 4 or 8 >= N — the column factors are NMAX·4 registers, and with them the kernel fits 8 waves per SIMD
+// (its workgroups are short: a band of 32 rows; what hides a workgroup's trace and its two barriers is the other seven)
+template <bool LOSS, int NMAX>
+__global__ void __launch_bounds__(256, 2)
 render_fwd_few(int N, int R, const float* __restrict__ helios, const float* __restrict__ sun,
                const float* __restrict__ action, const float* __restrict__ trig, long trig_b_stride,
                const float* __restrict__ xs, const float* __restrict__ ys, PlaneK P,
                float* __restrict__ actual, float* __restrict__ refl, float* __restrict__ rays,
                float* __restrict__ image, StepLossArgs L) {
     __shared__ float4 sRay[FEW_MAX_RAYS];              // (a, b, k2, c2)
+    __shared__ __attribute__((aligned(16))) float sA[FEW_ROWS][FEW_MAX_RAYS];       // row factors of the band: A_n[i0 + il]
     __shared__ float sLoss[2 * FEW_MAX_RAYS];
     __shared__ float scratch[4];
     const int band = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
@@ -1028,6 +1048,9 @@ render_fwd_few(int N, int R, const float* __restrict__ helios, const float* __re
             }
         }
     }
+    // (requested while the rays are traced: the row coordinate of this thread's row factor)
+    const int fn = tid & (FEW_MAX_RAYS - 1), fil = tid >> 3;               // FEW_ROWS · FEW_MAX_RAYS = 256 threads
+    const float xrow = xs[min(i0 + fil, R - 1)];
     __syncthreads();
     if constexpr (LOSS) {
         if (band == 0 && tid == 0) {
@@ -1037,42 +1060,68 @@ render_fwd_few(int N, int R, const float* __restrict__ helios, const float* __re
             L.part_ray[2l * b + 1] = sb;
         }
     }
+    if (fn < N) {
+        const float4 q = sRay[fn];
+        const float t = xrow + q.x;
+        sA[fil][fn] = exp2_fast(-(__builtin_fmaf(t, t, q.w) * q.z));
+    }
     const int qpr = R >> 2;                            // 16-byte quads per row
+    // thread ↔ (column quad, row phase): rpar rows of the band are walked side by side when a row is shorter than
+    // the workgroup (R = 128: 32 quads, 8 rows at a time; consecutive rows are consecutive addresses)
+    const int rpar = qpr >= 256 ? 1 : 256 / qpr;
+    const int r0 = qpr >= 256 ? 0 : tid / qpr;
     const long base = (long)b * R * R + (long)i0 * R;
     const float sc = LOSS ? L.tx[b] : 1.0f;
     float sq = 0.f, ab = 0.f, ds = 0.f;
-    for (int qd = tid; qd < rows * qpr; qd += 256) {
-        const int il = qd / qpr, j = 4 * (qd - il * qpr);
-        const long p = base + (long)il * R + j;
-        float4 tg4 = make_float4(0.f, 0.f, 0.f, 0.f), dm4 = tg4;
-        if constexpr (LOSS) {                          // requested first: they are what the kernel waits for
-            tg4 = *reinterpret_cast<const float4*>(L.target + p);
-            dm4 = *reinterpret_cast<const float4*>(L.dmaps + p);
-        }
-        const float xi = xs[i0 + il];
+    __syncthreads();
+    for (int jq = qpr >= 256 ? tid : tid - r0 * qpr; jq < qpr && r0 < rpar; jq += 256) {     // (one pass unless R > 1024)
+        const int j = 4 * jq;
         const float4 yj = *reinterpret_cast<const float4*>(ys + j);
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int n = 0; n < N; ++n) {
-            const float4 q = sRay[n];                  // broadcast read
-            const float t = xi + q.x;
-            const float a = exp2_fast(-(__builtin_fmaf(t, t, q.w) * q.z));
-            const float u0 = yj.x + q.y, u1 = yj.y + q.y, u2 = yj.z + q.y, u3 = yj.w + q.y;
-            acc.x = __builtin_fmaf(a, exp2_fast(-((u0 * u0) * q.z)), acc.x);
-            acc.y = __builtin_fmaf(a, exp2_fast(-((u1 * u1) * q.z)), acc.y);
-            acc.z = __builtin_fmaf(a, exp2_fast(-((u2 * u2) * q.z)), acc.z);
-            acc.w = __builtin_fmaf(a, exp2_fast(-((u3 * u3) * q.z)), acc.w);
-        }
-        *reinterpret_cast<float4*>(image + p) = acc;
-        if constexpr (LOSS) {
-            const float pv[4] = {acc.x, acc.y, acc.z, acc.w}, tv[4] = {tg4.x, tg4.y, tg4.z, tg4.w};
-            const float dv[4] = {dm4.x, dm4.y, dm4.z, dm4.w};
+        float e[NMAX][4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float d = pv[k] / sc - tv[k] / sc;       // as the reference divides (:438-441)
-                const float ad = fabsf(d);
-                sq = __builtin_fmaf(d, d, sq);
-                ab += ad;
-                ds = __builtin_fmaf(ad, dv[k], ds);
+        for (int n = 0; n < NMAX; ++n) {
+            if (n < N) {                               // (uniform)
+                const float4 q = sRay[n];              // broadcast read
+                const float u0 = yj.x + q.y, u1 = yj.y + q.y, u2 = yj.z + q.y, u3 = yj.w + q.y;
+                e[n][0] = exp2_fast(-((u0 * u0) * q.z)); e[n][1] = exp2_fast(-((u1 * u1) * q.z));
+                e[n][2] = exp2_fast(-((u2 * u2) * q.z)); e[n][3] = exp2_fast(-((u3 * u3) * q.z));
+            } else {
+                e[n][0] = e[n][1] = e[n][2] = e[n][3] = 0.0f;
+            }
+        }
+        for (int il = r0; il < rows; il += rpar) {
+            const long p = base + (long)il * R + j;
+            float4 tg4 = make_float4(0.f, 0.f, 0.f, 0.f), dm4 = tg4;
+            if constexpr (LOSS) {                      // requested first: they are what the kernel waits for
+                tg4 = *reinterpret_cast<const float4*>(L.target + p);
+                dm4 = *reinterpret_cast<const float4*>(L.dmaps + p);
+            }
+            const float4 a03 = *reinterpret_cast<const float4*>(&sA[il][0]);      // broadcast reads
+            float4 a47 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (NMAX > 4) a47 = *reinterpret_cast<const float4*>(&sA[il][4]);
+            const float av[FEW_MAX_RAYS] = {a03.x, a03.y, a03.z, a03.w, a47.x, a47.y, a47.z, a47.w};
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int n = 0; n < NMAX; ++n) {
+                if (n < N) {                           // (uniform; rays past N hold stale factors: never read)
+                    acc.x = __builtin_fmaf(av[n], e[n][0], acc.x);
+                    acc.y = __builtin_fmaf(av[n], e[n][1], acc.y);
+                    acc.z = __builtin_fmaf(av[n], e[n][2], acc.z);
+                    acc.w = __builtin_fmaf(av[n], e[n][3], acc.w);
+                }
+            }
+            *reinterpret_cast<float4*>(image + p) = acc;
+            if constexpr (LOSS) {
+                const float pv[4] = {acc.x, acc.y, acc.z, acc.w}, tv[4] = {tg4.x, tg4.y, tg4.z, tg4.w};
+                const float dv[4] = {dm4.x, dm4.y, dm4.z, dm4.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float d = pv[k] / sc - tv[k] / sc;       // as the reference divides (:438-441)
+                    const float ad = fabsf(d);
+                    sq = __builtin_fmaf(d, d, sq);
+                    ab += ad;
+                    ds = __builtin_fmaf(ad, dv[k], ds);
+                }
             }
         }
     }
@@ -1085,6 +1134,19 @@ render_fwd_few(int N, int R, const float* __restrict__ helios, const float* __re
             o[0] = sq; o[1] = ab; o[2] = ds;
         }
     }
+}
+
+template <bool LOSS>
+static void launch_few(int B, int N, int R, const float* helios, const float* sun, const float* action, const float* trig,
+                       long trig_b_stride, const float* xs, const float* ys, const PlaneK& P, float* actual, float* refl,
+                       float* rays, float* image, const StepLossArgs& L, hipStream_t st) {
+    const dim3 grid((R + FEW_ROWS - 1) / FEW_ROWS, B), block(256);
+#define HELIO_FEW_FWD(NM) hipLaunchKernelGGL((render_fwd_few<LOSS, NM>), grid, block, 0, st, N, R, helios, sun, action, trig, trig_b_stride, xs, ys, P, actual, refl, rays, image, L)
+    if (N <= 1) HELIO_FEW_FWD(1);
+    else if (N <= 2) HELIO_FEW_FWD(2);
+    else if (N <= 4) HELIO_FEW_FWD(4);
+    else HELIO_FEW_FWD(8);
+#undef HELIO_FEW_FWD
 }
 
 // the streaming kernel's preconditions
@@ -1105,8 +1167,13 @@ bool render_is_fused(int B, int N, int R) {
     // traces the rays of its sun itself, so longer sums go to the geometry + splat pair
     // a handful of rays per image: one streaming launch at any size (render_fwd_few, or the block kernel
     // when its alignment preconditions do not hold)
+    // … and only while the re-tracing stays small: every 32×32 block traces all N rays of its sun, B·N·⌈R/32⌉² traces in
+    // all against the B·N of the geometry kernel.  tools/rule_regret.py (profiles/r04_c_rule_regret_before.txt): from
+    // ≈300 k traces the two launches win — B = 500, N = 96, R = 128: 35.8 against 24.3 µs; B = 256, N = 200, R = 128:
+    // 36.1 / 27.3; B = 60, N = 200, R = 256: 34.4 / 27.8; at 200 k (B = 256, N = 50, R = 128) the single launch still does
     const long t128 = (long)B * ((R + 127) / 128) * ((R + 127) / 128);
-    return N <= FEW_MAX_RAYS || (N <= 256 && t128 < 512);
+    const long nb = (R + 31) / 32;
+    return N <= FEW_MAX_RAYS || (N <= 256 && t128 < 512 && (long)B * N * nb * nb <= (1l << 18));
 }
 
 // waves per 32×32 block of the fused kernel (the heliostats are split between them; 64·KG >= N): as
@@ -1130,6 +1197,12 @@ extern "C" int helio_diag_fused_kg(int B, int N, int R) { return helio::fused_kg
 namespace helio {
 #endif
 
+#ifdef HELIO_STAMPS
+#define HELIO_DIAG_SLOT_BIT (::g_diag_slot << 17)
+#else
+#define HELIO_DIAG_SLOT_BIT 0
+#endif
+
 template <int KG, bool LOSS>
 static void launch_fused(int B, int N, int R, const float* helios, const float* sun, const float* action,
                          const float* trig, long trig_b_stride, const helio_plane* plane, const float* xs,
@@ -1140,7 +1213,7 @@ static void launch_fused(int B, int N, int R, const float* helios, const float* 
     late.P = to_k(plane);
     late.actual = actual; late.refl = refl; late.rays = rays; late.image = image;
     hipLaunchKernelGGL((render_fwd_fused_small<KG, LOSS>), dim3(nb, nb + (LOSS ? 1 : 0), B), dim3(64 * KG), 0, st, N,
-                       R | (trig_b_stride != 0 ? 1 << 16 : 0), helios, sun, action, trig, xs, ys, late, L);
+                       R | (trig_b_stride != 0 ? 1 << 16 : 0) | HELIO_DIAG_SLOT_BIT, helios, sun, action, trig, xs, ys, late, L);
 }
 
 // form: 0 = by problem size; 1, 2, 4 = the block kernel with that many waves per block (64·KG >= N);
@@ -1160,8 +1233,7 @@ bool launch_render_fused(int B, int N, int R, const float* helios, const float* 
     const StepLossArgs none{};
     switch (resolve_fused_form(form, B, N, R, few_ok(N, R, ys, image, nullptr))) {
     case 8:
-        hipLaunchKernelGGL(render_fwd_few<false>, dim3((R + FEW_ROWS - 1) / FEW_ROWS, B), dim3(256), 0, st, N, R, helios, sun,
-                           action, trig, trig_b_stride, xs, ys, to_k(plane), actual, refl, rays, image, none);
+        launch_few<false>(B, N, R, helios, sun, action, trig, trig_b_stride, xs, ys, to_k(plane), actual, refl, rays, image, none, st);
         return true;
     case 4: launch_fused<4, false>(B, N, R, helios, sun, action, trig, trig_b_stride, plane, xs, ys, actual, refl, rays, image, none, st); return true;
     case 2: launch_fused<2, false>(B, N, R, helios, sun, action, trig, trig_b_stride, plane, xs, ys, actual, refl, rays, image, none, st); return true;
@@ -1199,8 +1271,7 @@ bool launch_env_step_fused(int B, int N, int R, const float* helios, const float
     case 8: {
         const int bands = (R + FEW_ROWS - 1) / FEW_ROWS;
         L.part_ray = workspace + 3l * B * bands;
-        hipLaunchKernelGGL(render_fwd_few<true>, dim3(bands, B), dim3(256), 0, st, N, R, helios, sun, action, trig,
-                           trig_b_stride, xs, ys, to_k(plane), actual, refl, rays, image, L);
+        launch_few<true>(B, N, R, helios, sun, action, trig, trig_b_stride, xs, ys, to_k(plane), actual, refl, rays, image, L, st);
         launch_step_losses_final(B, N, R, bands, B, mask_ratio, L.part_img, L.part_ray, out, mae, keep, notify, ticket, st);
         return true;
     }

@@ -68,7 +68,7 @@ class HelioField:
         device="cpu",
         max_batch_size: int = 25,
     ) -> None:
-        object.__setattr__(self, "_ready", False)          # the receiver records are built once, at the end
+        self._rec = None              # (plane record, xs, ys): made from the receiver's attributes on first use
         self.device = torch.device(device)
         self.max_batch_size = int(max_batch_size)
 
@@ -103,8 +103,7 @@ class HelioField:
         self._fast_render = None      # ops.render_context once resolved (False: compiled binding absent)
         self._render_ctx, self._ctx_key, self._ops = None, None, None
         self._fast = None             # the render context of the previous fast call (see __setattr__)
-        self._ready = True
-        self._rebuild_receiver()
+        self._receiver()              # (a constructor argument the kernels cannot stand for is refused here)
         self.reset_errors()
         self.initial_action = None
 
@@ -123,21 +122,21 @@ class HelioField:
         for name in self._TRANSIENT:
             state[name] = None
         state["_trig_cache"] = {}
-        state["_plane"] = None
+        state["_rec"] = None              # (rebuilt from the attributes on first use)
         return state
 
     def __setstate__(self, state):
         self.__dict__.update(state)
-        self._rebuild_receiver()
 
     # -------------------------------------------------------------- the receiver, as live as the reference's
     # The reference reads target_position, target_normal, plane_u, plane_v, target_width, target_height, resolution and
     # sigma_scale from the instance at EVERY render (:387-401), so a script that assigns one of them between renders
     # sees it take effect.  Here they feed three native-side records — the plane (origin, normal, the orthonormal
     # frame u, v, w = u × v of the separable footprint, sigma_scale), the pixel coordinates of :129-130 and the
-    # target of calculate_ideal_normals — which every assignment rebuilds (and with them the compiled contexts:
-    # they are keyed on the records' identity); an in-place write to one of the four tensors is caught by its
-    # version counter at the next render.
+    # target of calculate_ideal_normals.  An assignment only stores the value and drops the records (as the reference
+    # only stores it: two attributes that must change together, plane_u and plane_v, can be assigned one after the
+    # other); the NEXT use rebuilds them — new objects, so every compiled context keyed on them is rebuilt too — and an
+    # in-place write to one of the four tensors is caught by its version counter at that point as well.
     def _vector_attr(name, doc):        # noqa: N805 — class-body helper
         slot = "_" + name
 
@@ -148,7 +147,8 @@ class HelioField:
             t = torch.as_tensor(value, dtype=torch.float32, device=self.device)
             if t.shape != (3,):
                 raise ValueError(f"HelioField.{name} must have shape (3,), got {tuple(t.shape)}")
-            self._assign_receiver(slot, t)
+            self.__dict__[slot] = t
+            self._rec = None              # (through __setattr__: the memoised context goes too)
         return property(get, set_, doc=doc)
 
     def _scalar_attr(name, cast, doc):  # noqa: N805
@@ -158,12 +158,13 @@ class HelioField:
             return self.__dict__[slot]
 
         def set_(self, value):
-            self._assign_receiver(slot, cast(value))
+            self.__dict__[slot] = cast(value)
+            self._rec = None
         return property(get, set_, doc=doc)
 
     target_position = _vector_attr("target_position", "centre of the receiver (:184-186); read at every render (:387)")
     target_normal = _vector_attr("target_normal", "receiver normal, as assigned — the render divides by its norm again (:60)")
-    plane_u = _vector_attr("plane_u", "image dim-0 axis on the receiver (:206); must stay orthonormal with plane_v")
+    plane_u = _vector_attr("plane_u", "image dim-0 axis on the receiver (:206); must be orthonormal with plane_v when rendered")
     plane_v = _vector_attr("plane_v", "image dim-1 axis on the receiver (:207-213)")
     target_width = _scalar_attr("target_width", float, "receiver extent along plane_u [m] (:187)")
     target_height = _scalar_attr("target_height", float, "receiver extent along plane_v [m] (:187)")
@@ -171,27 +172,16 @@ class HelioField:
     sigma_scale = _scalar_attr("sigma_scale", float, "footprint sigma per metre of path (:198, read at :400)")
     del _vector_attr, _scalar_attr
 
-    def _assign_receiver(self, slot, value) -> None:
-        d = self.__dict__
-        had, old = slot in d, d.get(slot)
-        d[slot] = value
-        self._fast = None
-        if d.get("_ready"):
-            try:
-                self._rebuild_receiver()
-            except ValueError:                   # a refused value is not kept
-                if had:
-                    d[slot] = old
-                else:
-                    del d[slot]
-                raise
-
     def _receiver_versions(self):
         d = self.__dict__
         return tuple(d[k]._version for k in ("_target_position", "_target_normal", "_plane_u", "_plane_v"))
 
-    def _rebuild_receiver(self) -> None:
-        """The native-side records of the receiver from the current attribute values."""
+    def _receiver(self):
+        """→ (plane record, xs, ys) of the receiver's CURRENT attribute values: the records of the last call while
+        nothing was assigned or written in place since, else new ones."""
+        rec = self._rec
+        if rec is not None and self._receiver_seen == self._receiver_versions():
+            return rec
         d = self.__dict__
         tp, tn, u, v = (d[k].detach().cpu() for k in ("_target_position", "_target_normal", "_plane_u", "_plane_v"))
         # the footprint is evaluated in its separable form, |P_ij − x|² = (xs_i + a)² + (ys_j + b)² + c² (DESIGN §2),
@@ -201,26 +191,33 @@ class HelioField:
         if not (abs(uu - 1.0) <= 1e-5 and abs(vv - 1.0) <= 1e-5 and abs(uv) <= 1e-5):
             raise ValueError("HelioField: plane_u / plane_v must be orthonormal (|u|² = %.6g, |v|² = %.6g, u·v = %.3g): the HIP "
                              "footprint kernels evaluate the reference's Gaussian in its separable form" % (uu, vv, uv))
-        w = torch.linalg.cross(u.double(), v.double()).float()
-        vectors = (tuple(tp.tolist()), tuple(tn.tolist()), tuple(u.tolist()), tuple(v.tolist()), tuple(w.tolist()))
-        self._plane_vectors = vectors
-        self._plane = native.Plane(*vectors, self._sigma_scale)
-        self._target_xyz = vectors[0]
         R = self._resolution
         if R < 1:
             raise ValueError(f"HelioField.resolution must be >= 1, got {R}")
-        xs_key = (self._target_width, self._target_height, R)
-        if d.get("_xs_key") != xs_key:                        # (sigma_scale or a vector alone leaves the pixel grid as it is)
-            self._xs = torch.linspace(-self._target_width / 2, self._target_width / 2, R).to(self.device)
-            self._ys = torch.linspace(-self._target_height / 2, self._target_height / 2, R).to(self.device)
-            self._xs_key = xs_key
+        w = torch.linalg.cross(u.double(), v.double()).float()
+        vectors = (tuple(tp.tolist()), tuple(tn.tolist()), tuple(u.tolist()), tuple(v.tolist()), tuple(w.tolist()))
+        plane = native.Plane(*vectors, self._sigma_scale)
+        xs_key = (self._target_width, self._target_height, R, self.device)
+        grid = d.get("_grid")
+        if grid is None or grid[0] != xs_key:                 # (sigma_scale or a vector alone leaves the pixel grid as it is)
+            grid = (xs_key, torch.linspace(-self._target_width / 2, self._target_width / 2, R).to(self.device),
+                    torch.linspace(-self._target_height / 2, self._target_height / 2, R).to(self.device))
+            self._grid = grid
+        self._target_xyz = vectors[0]
         self._receiver_seen = self._receiver_versions()
+        self._rec = rec = (plane, grid[1], grid[2])
+        return rec
 
-    def _receiver(self):
-        """→ (plane record, xs, ys), rebuilt first if one of the receiver's tensors was written in place."""
-        if self._receiver_seen != self._receiver_versions():
-            self._rebuild_receiver()
-        return self._plane, self._xs, self._ys
+    def _override_record(self, i, value) -> None:
+        rec = list(self._receiver())
+        rec[i] = value
+        self._rec = tuple(rec)            # (stays until the next assignment to a receiver attribute)
+
+    # the records by name (tests and tools read them — and substitute one, e.g. a misaligned coordinate table; the
+    # render paths take all three from one _receiver() call)
+    _plane = property(lambda self: self._receiver()[0], lambda self, v: self._override_record(0, v))
+    _xs = property(lambda self: self._receiver()[1], lambda self, v: self._override_record(1, v))
+    _ys = property(lambda self: self._receiver()[2], lambda self, v: self._override_record(2, v))
 
     @property
     def device_trig(self) -> bool:
@@ -319,6 +316,7 @@ class HelioField:
     def calculate_ideal_normals(self, sun_position) -> torch.Tensor:
         """Normals that send every heliostat's reflection to the target centre (:256-278)."""
         sun = torch.as_tensor(sun_position, dtype=torch.float32, device=self.device)
+        self._receiver()                                  # (target_position as it is NOW, :263 / :274)
         if sun.dim() == 1:
             return _get_ops().ideal_normals(self.heliostat_positions, sun.view(1, 3).contiguous(),
                                             self._target_xyz)[0]

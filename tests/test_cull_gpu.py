@@ -460,3 +460,24 @@ def test_fuzz_of_every_list_taking_kernel_against_its_dense_self():
     run = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_cull.py"), "30", "11"], capture_output=True, text=True,
                          timeout=600)
     assert run.returncode == 0 and "30 cases, 0 differences" in run.stdout, run.stdout[-3000:] + run.stderr[-2000:]
+
+
+@pytest.mark.parametrize("N,B,R,sigma,err", [(700, 3, 260, 0.01, 90.0), (300, 2, 512, 0.02, 40.0), (257, 2, 132, 0.01, 180.0),
+                                             (1000, 5, 288, 0.05, 90.0)])
+def test_double_buffered_backward_tile_gives_the_single_buffered_bits(N, B, R, sigma, err, monkeypatch):
+    """splat_bwd_mfma_both<…, DB> (round 4: the two LDS tables twice, 32-deep chunks, the next chunk's factors produced in
+    the shadow of this chunk's MFMAs, one barrier per chunk) walks the contracted axis in the order of the single-buffered
+    body: the moments are the same bits — dense and with the lists, with a ragged last chunk (R % 32 != 0) and rows past the
+    image in the last c tile."""
+    from doodle_amd import native
+    ops = native.get_ops()
+    f, suns, act, rays = field_and_rays(N, B, R, sigma, err, seed=N + R, span=30.0)
+    G = torch.randn(B, R, R, device=DEV, generator=torch.Generator(device=DEV).manual_seed(R))
+    out = {}
+    for db in ("1", "0"):
+        monkeypatch.setenv("HELIO_BWD_DB", db)
+        out[db] = (ops.splat_bwd(rays, f._xs, f._ys, G, variant=2, cull=False), splat_bwd_with_list(rays, f._xs, f._ys, G, 2)[0])
+    torch.cuda.synchronize()
+    assert same_bits(out["1"][0], out["0"][0]) and same_bits(out["1"][1], out["0"][1])
+    assert same_bits(out["1"][0], out["1"][1])                      # (and the lists change no bit of either)
+    assert torch.isfinite(out["1"][0]).all() and out["1"][0].abs().max().item() > 0

@@ -48,7 +48,7 @@ def test_library_exports_every_declared_symbol():
 def test_comm_library_exports_every_declared_symbol():
     from doodle_amd import comm
     header = open(os.path.join(ROOT, "include", "helio_comm.h")).read()
-    declared = set(re.findall(r"\b(helio_comm_[a-z_0-9]+)\s*\(", header))
+    declared = set(re.findall(r"\b(helio_(?:comm|p2p)_[a-z_0-9]+)\s*\(", header))
     assert declared == set(comm.COMM_EXPORTS), declared ^ set(comm.COMM_EXPORTS)
     lib = comm.load_comm_library()
     for name in declared:
@@ -475,8 +475,11 @@ def test_receiver_attributes_are_live(monkeypatch):
     got = f.render(sun, act, None)[0]
     assert got.shape == (5, 24, 24) and torch.equal(got, want)
     assert torch.equal(f.calculate_ideal_normals(sun), fresh(target_position=tp2).calculate_ideal_normals(sun))
+    u0 = f.plane_u
+    f.plane_u = torch.tensor([2.0, 0.0, 0.0])                         # stored, as in the reference; refused when rendered
     with pytest.raises(ValueError, match="orthonormal"):
-        f.plane_u = torch.tensor([2.0, 0.0, 0.0])
+        f.render(sun, act, None)
+    f.plane_u = u0
     with pytest.raises(ValueError, match="shape"):
         f.target_normal = torch.zeros(4)
     # a copy / pickle rebuilds the records from the attributes

@@ -13,7 +13,7 @@ from test_gpu_more import make_case
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
-FRESH_ERRORS_BAR = 2e-4     # max|Δ| / max|ref|; 2x the measured worst (profiles/r04_b_grad_devs.txt)
+FRESH_ERRORS_BAR = 7e-7     # max|Δ| / max|ref|; 2x the measured worst (3.1e-7, profiles/r04_b_grad_devs.txt)
 
 
 @pytest.mark.parametrize("err", [90.0, 180.0])

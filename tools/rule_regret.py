@@ -7,6 +7,9 @@ R=128; run_experiments.py:31-56 is N=1, B=500) one helio_render_fwd / helio_rend
 of three loops) with variant 0 and with every variant that exists at that size.  regret = t(auto) / t(best) - 1.
 The split-bf16 kernels (forward 7 / 8, backward 5) are opt-in, never chosen by the rules, and do not count as "best".
 Inputs: err 40 mrad, sigma_scale 0.02 — every ray lands on the image, so no list shortens anybody's work.
+Times are DEVICE times: HIP events around an eager loop where a call takes longer than the host needs to issue it, a
+HIP-graph replay of 20 back-to-back calls below that.  What the host pays per call (one launch or two) is not in them;
+the last section times config 3's forward + backward through the Python surface for the two backward forms it concerns.
 
 usage: rule_regret.py [quick] [out.txt]
 """
@@ -31,6 +34,7 @@ def grid(quick):
     g = [(B, N, R) for R in (64, 128, 256, 512) for N in (50, 200, 1000, 5000) for B in (4, 32, 256)
          if B * N * R * R <= 3e11]
     g += [(B, N, R) for R in (100, 128, 256) for N in (1, 8, 50, 96, 200) for B in (1, 4, 25, 60, 500)]
+    g += [(B, N, R) for R in (128, 256) for N in (2, 4, 16, 32) for B in (4, 60, 500)]      # around the few-ray rules
     seen, out = set(), []
     for p in g:
         if p not in seen:
@@ -40,13 +44,42 @@ def grid(quick):
 
 
 def timed(fn, flops):
+    """Device time per call (s), or None where the variant does not exist.  Calls shorter than ≈100 µs are timed as a
+    HIP-graph replay of 20 back-to-back calls (least of five replays): an eager Python loop cannot issue faster than
+    ≈6 µs per call, which is ALL a loop of the small sizes would show, for every variant alike."""
     iters = max(5, min(200, int(1e11 / max(flops, 1.0))))
     try:
         fn()
         torch.cuda.synchronize()
     except RuntimeError:
         return None                                   # this variant does not exist at this size
-    return time_kernel(fn, iters, warm=3, repeats=3)
+    t = time_kernel(fn, iters, warm=3, repeats=3)
+    if t > 100e-6:
+        return t
+    K = 20
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            fn()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(K):
+            fn()
+    best = None
+    for _ in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        dt = e0.elapsed_time(e1) * 1e-3 / K
+        best = dt if best is None else min(best, dt)
+    del g
+    return best
 
 
 def main():
@@ -79,9 +112,15 @@ def main():
                     tf[v] = None
                     continue
                 tf[v] = timed(lambda: ops.render_fwd(hp, suns_d, normals, trig, stride, pl, xs, ys, rays=rays, variant=v), flops)
+            # (the rules' choice once more, LAST: the first timing of a size runs on clocks that dropped while the host
+            # built the field — 8–13 % at the 150 µs sizes; the lesser of the two counts)
+            v = 0
+            tf[0] = min(tf[0], timed(lambda: ops.render_fwd(hp, suns_d, normals, trig, stride, pl, xs, ys, rays=rays, variant=v), flops))
             ops.render_fwd(hp, suns_d, normals, trig, stride, pl, xs, ys, rays=rays)
             for v in (0,) + BWD + BWD_OPT_IN:
                 tb[v] = timed(lambda: ops.render_bwd(hp, suns_d, normals, trig, stride, pl, rays, xs, ys, G, None, None, variant=v), 2 * flops)
+            v = 0
+            tb[0] = min(tb[0], timed(lambda: ops.render_bwd(hp, suns_d, normals, trig, stride, pl, rays, xs, ys, G, None, None, variant=v), 2 * flops))
         bf = min((v for v in FWD if tf[v] is not None), key=lambda v: tf[v])
         bb = min((v for v in BWD if tb[v] is not None), key=lambda v: tb[v])
         rf, rb = tf[0] / tf[bf] - 1.0, tb[0] / tb[bb] - 1.0
@@ -99,9 +138,41 @@ def main():
         emit(f"  {which} B={B} N={N} R={R}: auto (= v{c}) {t0 * 1e6:.1f} us, best v{best} {tbest * 1e6:.1f} us, regret {reg * 100:.1f}%   [{every}]")
     worst = max(r[8] for r in rows)
     emit(f"max regret {worst * 100:.1f}% over {len(rows)} (size, direction) pairs")
+    emit("")
+    emit("config 3 (N=50, B=25, R=128) through the Python surface — HelioField.render_value_and_grad, wall clock per call, "
+         "best of 5 loops of 2000 — with the backward by rule and forced:")
+    import time
+    w = synthetic.CONFIGS["cfg2"]
+    helios, suns, errs, noise = synthetic.make_inputs(w, 0)
+    f = build_field(w, helios, errs, dev)
+    suns_d = suns.to(dev)
+    act = make_action(f, suns_d, noise)
+    G = torch.randn(w.B, w.R, w.R, device=dev)
+    H = torch.ones(w.B, w.N, 3, device=dev)
+    for v in (0, 8, 10, 11):
+        ops.bwd_variant = v
+        try:
+            for _ in range(500):
+                f.render_value_and_grad(suns_d, act, G, H)
+            torch.cuda.synchronize()
+            best = None
+            for _ in range(5):
+                t0 = time.perf_counter()
+                for _ in range(2000):
+                    f.render_value_and_grad(suns_d, act, G, H)
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t0) / 2000
+                best = dt if best is None else min(best, dt)
+        finally:
+            ops.bwd_variant = 0
+        emit(f"  bwd variant {v:2d}{' (= v' + str(ops.render_bwd_choice(w.B, w.N, w.R)) + ')' if v == 0 else '':8s}: {best * 1e6:6.2f} us per forward + backward")
     if outs:
         with open(outs[0], "w") as fh:
             fh.write("\n".join(lines) + "\n")
+        import json
+        with open(os.path.splitext(outs[0])[0] + ".json", "w") as fh:      # every variant's time, for deriving rules offline
+            json.dump([{"B": r[0], "N": r[1], "R": r[2], "dir": r[3], "auto": r[4], "us": {str(v): round(t * 1e6, 2) for v, t in r[9].items()}}
+                       for r in rows], fh)
 
 
 if __name__ == "__main__":
