@@ -272,8 +272,24 @@ def value_sweep(dev, w, steps, seeds=(0, 1, 2), sigmas=(0.01, 0.1)):
     """the headline loop — K bare ``field.render`` calls + fence, after a burst preheat — for seeds
     0..2 at the training sigma_scale (0.01) and at the README default (0.1): frames/s per seed, median, spread."""
     import gc
+    # This sweep runs late in the process, behind legs that left tens of GB in torch's caching allocator and (the graph
+    # leg) side streams: round 3's line showed the SAME workload at 4.17 M here against 5.48 M as `value`.
+    # tools/headline_drift.py replays the headline sample after each thing the process does in between, one at a time
+    # (profiles/r04_d_headline_drift.txt): a large cached pool costs the launch-bound loop ≈2.2 µs per step (5.7 → 3.8 M
+    # frames/s after 20 GB allocated and freed; back to 5.6 M after empty_cache()), a live second stream that has run work
+    # ≈2.0 µs (→ 3.9 M; back once it is released); a second field, a graph capture, config-4-sized launches, HelioEnv and
+    # its pinned record, the autograd engine's thread, the affinity widened and narrowed: nothing.  So: collect what the
+    # earlier legs dropped and hand the cached blocks back before sampling.
+    gc.collect()
+    reserved0 = torch.cuda.memory_reserved(dev)
+    torch.cuda.empty_cache()
     out = {"steps": steps, "what": "frames/s of K field.render calls + synchronize (the timed region of `value`), one fresh "
-                                   "field per (seed, sigma_scale); spread = (max - min) / median"}
+                                   "field per (seed, sigma_scale); spread = (max - min) / median",
+           "allocator": {"reserved_GB_left_by_the_earlier_legs": round(reserved0 / 2**30, 2),
+                         "reserved_GB_after_empty_cache": round(torch.cuda.memory_reserved(dev) / 2**30, 2),
+                         "why": "a large cached pool in torch's allocator (and a live side stream) costs this launch-bound loop "
+                                "≈2 µs per step — profiles/r04_d_headline_drift.txt; round 3 sampled with the pool full "
+                                "(seed 0 here = the workload of `value`: 4.17 M then against 5.48 M)"}}
     for sg in sigmas:
         vals = []
         for seed in seeds:

@@ -15,6 +15,7 @@
 // bit-reproducible.
 #include <hip/hip_runtime.h>
 #include <cstdlib>
+#include <type_traits>
 #include "helio.h"
 #include "step_loss_math.h"
 #include "geometry_bwd_ray.h"
@@ -439,6 +440,17 @@ splat_bwd_mfma_body_db(int B, int N, int R, const float* __restrict__ rays, cons
     const float fshift = (PASS == 0 ? q.x : q.y) * sk;
     const float fcc = PASS == 0 ? q.w * q.z : 0.0f;
     const int foff = KC * LDG + pk0 * LD + pr;                      // this thread's first factor, inside a pair of tables
+    // the two rays this lane's EPILOGUE belongs to (column lr of ray blocks 0 and 1 of the wave), requested now: fetched
+    // after the loop they are two dependent misses (list entry, then ray) in front of every workgroup's last microseconds
+    int en[2];
+    float4 eh[2];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+        const int p = n0 + wn + 32 * nb + lr;
+        en[nb] = p < L ? (lidx ? lidx[p] : p) : N;
+        eh[nb] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (en[nb] < N) eh[nb] = reinterpret_cast<const float4*>(rays)[(long)b * N + en[nb]];
+    }
 
     // loader role for the grad-image slab Gm[k][c]: 8 dwords per thread and chunk (layouts as in the body above)
     float gv[NV];
@@ -508,56 +520,64 @@ splat_bwd_mfma_body_db(int B, int N, int R, const float* __restrict__ rays, cons
     __syncthreads();
 
     const int goff = lh * LDG + wc + lr, foff_c = KC * LDG + lh * LD + wn + lr;      // consumer operands inside a pair
-    for (int k0 = 0; k0 < R; k0 += KC) {
+    // One chunk: 16 k-pairs of 4 MFMAs out of the pair of tables `cur`; the operands of k-pair kp + 1 are requested
+    // BEFORE the MFMAs of k-pair kp are issued (the LDS round trip then runs beside them: the first form of this loop
+    // waited for every pair of reads in front of its four MFMAs and lost 10 % to it), and with MORE the next chunk is
+    // produced into the other pair of tables in eight pieces, one behind every second k-pair's MFMAs.
+    auto chunk = [&](auto more_c, int k0) {
+        constexpr bool MORE = decltype(more_c)::value;
         const int cur = (k0 / KC) & 1;
-        float* __restrict__ bufc = smem + cur * BUF;
         float* __restrict__ bufn = smem + (cur ^ 1) * BUF;
-        lds_cf* pg = (lds_cf*)bufc + goff;
-        lds_cf* pf = (lds_cf*)bufc + foff_c;
-        const bool more = k0 + KC < R;                              // (uniform) a chunk to produce beside this one's MFMAs
-        // eight segments: two k-pairs (8 MFMAs) and a share of the next chunk's production each
+        lds_cf* pg = (lds_cf*)smem + cur * BUF + goff;
+        lds_cf* pf = (lds_cf*)smem + cur * BUF + foff_c;
+        float g0 = pg[0], g1 = pg[32], f0 = pf[0], f1 = pf[32];
 #pragma unroll
-        for (int seg = 0; seg < 8; ++seg) {
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int kp = 2 * seg + h;
-                const float g0 = pg[kp * 2 * LDG], g1 = pg[kp * 2 * LDG + 32];
-                const float f0 = pf[kp * 2 * LD], f1 = pf[kp * 2 * LD + 32];
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(g0, f0, acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(g0, f1, acc[1], 0, 0, 0);
-                acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(g1, f0, acc[2], 0, 0, 0);
-                acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(g1, f1, acc[3], 0, 0, 0);
+        for (int kp = 0; kp < KC / 2; ++kp) {
+            float g0n = 0.f, g1n = 0.f, f0n = 0.f, f1n = 0.f;
+            if (kp + 1 < KC / 2) {
+                g0n = pg[(kp + 1) * 2 * LDG]; g1n = pg[(kp + 1) * 2 * LDG + 32];
+                f0n = pf[(kp + 1) * 2 * LD]; f1n = pf[(kp + 1) * 2 * LD + 32];
             }
-            if (more) {
-                if (seg == 0) store_slab(bufn);                     // chunk c + 1's slab (fetched a chunk ago)
-                if (seg == 1) load_slab(k0 + 2 * KC);               // chunk c + 2's: in flight for a whole chunk
+            __builtin_amdgcn_sched_barrier(0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(g0, f0, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(g0, f1, acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(g1, f0, acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(g1, f1, acc[3], 0, 0, 0);
+            if constexpr (MORE) {
+                if ((kp & 1) == 1) {
+                    const int seg = kp >> 1;
+                    if (seg == 0) store_slab(bufn);                 // chunk c + 1's slab (fetched a chunk ago)
+                    if (seg == 1) load_slab(k0 + 2 * KC);           // chunk c + 2's: in flight for a whole chunk
 #pragma unroll
-                for (int jj = 0; jj < KPT / 8; ++jj) {
-                    const int j = seg * (KPT / 8) + jj;
-                    factor(bufn, k0 + KC, j, kc[j]);
+                    for (int jj = 0; jj < KPT / 8; ++jj) {
+                        const int j = seg * (KPT / 8) + jj;
+                        factor(bufn, k0 + KC, j, kc[j]);
+                    }
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
+            g0 = g0n; g1 = g1n; f0 = f0n; f1 = f1n;
         }
-        if (more) {
+        if constexpr (MORE) {
 #pragma unroll
             for (int j = 0; j < KPT; ++j) kc[j] = kcoord[min(k0 + 2 * KC + pk0 + j, R - 1)];
         }
         __syncthreads();                                            // pair cur consumed by everybody, pair cur^1 complete
-    }
+    };
+    int k0 = 0;
+    for (; k0 + KC < R; k0 += KC) chunk(std::true_type{}, k0);
+    chunk(std::false_type{}, k0);
 
     // epilogue: as in the body above
     const int JB = (R + 63) / 64;
     const int cblock = (c0 + wc) / 64;
     if (c0 + wc >= R) return;
     const int lane2 = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    const int lr2 = lane2 & 31, lh2 = lane2 >> 5;
+    const int lh2 = lane2 >> 5;
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
-        const int p = n0 + wn + 32 * nb + lr2;
-        const int n = p < L ? (lidx ? lidx[p] : p) : N;
-        float4 h = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (n < N) h = reinterpret_cast<const float4*>(rays)[(long)b * N + n];
+        const int n = en[nb];
+        const float4 h = eh[nb];
         const float hshift = PASS == 0 ? h.y : h.x;
         const float hcc = PASS == 0 ? 0.0f : h.w;
         const f32x2 sh = {hshift, hshift}, cc2 = {hcc, hcc}, nk = {-h.z, -h.z};
@@ -968,20 +988,25 @@ render_bwd_fused_small(int B, int N, int R, const float* __restrict__ rays, cons
     st3(g_action + 3 * m, geometry_bwd_ray(in, m, n, B, N, P, true, M0, Mx, My, Mxx, Myy, g_actual != nullptr, helios, action, RL));
 }
 
-// The sizes the single-launch backward serves.  Measured at config 3 (rocprofv3): 12.1 µs, the same GPU time
-// as the two launches it replaces (6.6 + 4.0 + the boundary) — its 16 waves share ONE CU's matrix pipe
-// (4 per SIMD, 8192 MFMA cycles each SIMD) where the small kernel spreads them over four CUs, which eats
-// what the saved boundary and the saved round trip of the moments give — but one launch less for the host
-// (render_value_and_grad 20.7 → 17.2 µs).  So it is chosen only where the two-launch form cannot spread
-// either: at most 64 workgroups (B · ⌈N/32⌉), an image of at most four 64-wide c blocks, the small MFMA
-// kernel's regime (not the few-ray one).  HELIO_BWD_FUSED=0 switches the choice off; variant 8 forces it.
+// The sizes the single-launch backward serves (variant 8 forces it; HELIO_BWD_FUSED=0 switches the choice off).
 bool render_bwd_is_fused(int B, int N, int R) {
     static const bool off = [] { const char* e = getenv("HELIO_BWD_FUSED"); return e && e[0] == '0'; }();
-    // (R > 128: round 3 let images of up to 256 pixels in while N < 96 — its CT = 4 form cuts the contracted axis between
-    // two waves only, and tools/rule_regret.py showed it 2.3x behind the two launches there: B = 4, N = 50, R = 256,
-    // 34.6 against ≈15 µs)
-    if (off || splat_bwd_is_few(B, N, R) || R > 128) return false;
-    return (long)B * ((N + 31) / 32) <= 64;
+    if (off || splat_bwd_is_few(B, N, R) || R > 256) return false;
+    // Round 4, from tools/rule_regret.py (device times as HIP-graph replays; profiles/r04_c_rule_regret.txt).  wg = the
+    // launch's workgroups, one per 32 rays of a sun, 16 waves each.
+    const long wg = (long)B * ((N + 31) / 32);
+    // (a) at most 64 of them, R <= 128 — the latency-bound corner, config 3 in it: ON THE DEVICE the two launches are
+    //     the shorter (≈9 against ≈12 µs: the 16 waves of a workgroup share one CU's matrix pipe), but a forward +
+    //     backward through the Python surface is issue-bound there and one launch less is 17–19.5 against 22–24 µs per
+    //     call (config 3, same table): the rule follows the wall clock.  HELIO_BWD_FUSED=0 for graph replays.
+    if (R <= 128 && wg <= 64) return true;
+    // (b) enough workgroups to fill the chip and few ray blocks per sun: no round trip of the moments, one launch —
+    //     B = 256, N = 50, R = 128: 25.0 against 29.5 µs; B = 32, N = 200, R = 128: 13.2 / 16.1; B = 500, N = 32, R = 256:
+    //     71.4 / 79.0.  Between (a) and (b) — 64 < wg < 160 — the two launches win (B = 60, N = 50, R = 128: 11.4 / 13.1),
+    //     and so they do with 64-pixel images (B = 256, N = 50, R = 64: 12.3 / 15.9) and with many ray blocks.
+    if (R > 64 && R <= 128) return wg >= 160 && (N <= 64 || wg <= 512);
+    if (R > 128) return N <= 64 && wg >= 256;
+    return false;
 }
 
 // ideal == nullptr: the render's backward alone; else with the adjoint of HelioEnv.step's two ray losses
@@ -1014,13 +1039,15 @@ static int bwd_small_ks(int B, int N, int R) {
 }
 
 // ray blocks per wave of the small backward kernel (1, 2 or 4); HELIO_BWD_NRB forces one — tuning runs only
-static int bwd_small_nrb(int N, int ks) {
+static int bwd_small_nrb(int B, int N, int R, int ks) {
     static const int forced = [] { const char* e = getenv("HELIO_BWD_NRB"); return e ? atoi(e) : 0; }();
     if (forced == 1 || forced == 2 || forced == 4) return forced;
     // tools/sweep_bwd_nrb.py: two ray blocks per wave are 3–10 % ahead from N = 300 (B = 25: 36.5 → 35.3 µs at
     // N = 1000, R = 128; 110.9 → 101.8 at R = 256), behind below (N = 100: 7.2 → 8.3 µs); four never pay
     // (344 registers: one wave per SIMD).  Same sums per ray: the bits do not change.
-    return (N >= 300 && ks == 4) ? 2 : 1;
+    // … and only while halving the workgroups leaves the chip full (round 4: B = 4, N = 1000, R = 64 — 256 workgroups
+    // with one ray block each — 8.5 against 9.8 µs; B = 4, N = 5000, R = 64: 13.7 / 15.1)
+    return (N >= 300 && ks == 4 && 2l * B * ((R + 63) / 64) * ((N + 31) / 32) >= 2048) ? 2 : 1;
 }
 
 template <int PASS, bool VEC, int WC>
@@ -1542,11 +1569,13 @@ static void launch_bwd_few(int B, int N, int R, const float* rays, const float* 
 // where the few-ray kernel wins (tools/sweep_bwd.py, MI355X): its time grows with B·N·R², the
 // MFMA kernels' with the number of 64-ray tiles
 bool splat_bwd_is_few(int B, int N) { return N <= 8 || (N <= 16 && B <= 64) || (N <= 32 && B <= 8); }
-// … and, knowing the image size, the rule the backward uses (round 4, tools/rule_regret.py): with 3..32 rays per image
-// and few pixels in all the small MFMA kernel's latency is the shorter one — N = 8, R = 128, B <= 60: 11.7 against
-// 8.8–9.4 µs; from ≈2 M pixels (B = 60, R = 256) the streaming kernel is level or ahead.  One or two rays: always.
+// … and, knowing the image size, the rule the render's backward uses (round 4, tools/rule_regret.py,
+// profiles/r04_c_rule_regret.txt): with 3..8 rays per image and few pixels in all the small MFMA kernel's latency is the
+// shorter one — N = 8, R = 128, B <= 60: 11.7 against 8.8–9.4 µs; from ≈2 M pixels (B = 60, R = 256) the streaming kernel
+// is level or ahead.  One or two rays: always.  (The two-argument form stays the env step's: its few-ray path also
+// forms the image cotangent on the fly.)
 bool splat_bwd_is_few(int B, int N, int R) {
-    return splat_bwd_is_few(B, N) && (N <= 2 || (long)B * R * R >= (1l << 21));
+    return N <= 8 && (N <= 2 || (long)B * R * R >= (1l << 21));       // (9..32 rays: never ahead in the table — B = 60, N = 16, R = 256: 20.7 against 16.7 µs)
 }
 
 // backward through the image losses with the cotangent formed on the fly (few rays only)
@@ -1582,6 +1611,9 @@ static int splat_bwd_choice(int B, int N, int R) {
     if (tiles >= 512) return 2;
     const long rounds = (2 * tiles + 255) / 256;
     const double fill = (double)(2 * tiles) / (256.0 * rounds) * N / (256.0 * ray_tiles);
+    // (two rounds of which the second is less than half full — B = 4, N = 5000, R = 512: 320 workgroups — go to the
+    // small-tile kernel whatever the fill says: 259 against 314–321 µs, tools/rule_regret.py)
+    if (rounds == 2 && 2 * tiles < 384) return 3;
     return fill >= 0.58 ? 2 : 3;
 }
 
@@ -1589,7 +1621,13 @@ static int splat_bwd_choice(int B, int N, int R) {
 // N = 600 with workgroups enough (tools/sweep_bwd_nrb.py)
 static bool small_whole_k(int B, int N, int R) {
     static const int ks_exp = [] { const char* e = getenv("HELIO_BWD_KSX"); return e ? atoi(e) : 0; }();     // tuning runs
-    return ks_exp == 0 && N >= 600 && 2l * ((R + 63) / 64) * ((N + 255) / 256) * B >= 256;
+    // round 4 (tools/rule_regret.py): what counts is how full the 256-ray groups are — N = 200 (78 %) gains like N = 1000
+    // (B = 256, N = 200, R = 64: 21.7 against 28.2 µs; B = 60, N = 200, R = 256: 59.7 / 65.6), N = 300 (59 %) loses — and
+    // that there are waves enough to hide its unstaged grad-image loads: 400 workgroups where the contracted axis is
+    // long (B = 4, N = 1000, R = 512, 256 workgroups: 72.5 against 63.7 µs), 256 where it is 64
+    const long groups = (N + 255) / 256, wgs = 2l * ((R + 63) / 64) * groups * B;
+    const bool full = N >= 600 || 4l * N >= 3l * 256 * groups;
+    return ks_exp == 0 && full && wgs >= (R <= 64 ? 256 : 400);
 }
 
 // The forms of the small-tile kernel that differ in their BITS are the ways its contracted axis is cut: 9 = not at
@@ -1671,7 +1709,7 @@ int launch_splat_bwd(int B, int N, int R, const float* rays, const float* xs, co
         // ONE ray block per wave whatever the size (tests, tuning)
         const int ct = (R + 63) / 64, nt = (N + 31) / 32;
         const int ks = (variant == 7 || variant == 11) ? 8 : 4;
-        const int nrb = variant >= 9 ? bwd_small_nrb(N, ks) : 1;
+        const int nrb = variant >= 9 ? bwd_small_nrb(B, N, R, ks) : 1;
         static const int ks_exp_env = [] { const char* e = getenv("HELIO_BWD_KSX"); return e ? atoi(e) : 0; }();     // tuning runs
         const int ks_exp = by_rule ? ks_exp_env : 0;
         const bool v3 = variant >= 9;

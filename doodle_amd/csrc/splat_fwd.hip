@@ -1004,23 +1004,32 @@ namespace helio {
 // from the pixels in registers, and band 0 also does the per-ray side work (outputs, the two ray losses,
 // the `aux` row).  Partials: [B, bands, 3] / [B, 2], reduced by step_losses_final in fixed order.  Needs
 // R % 4 == 0 and 16-byte aligned images; anything else takes the block kernel.
-constexpr int FEW_ROWS = 32, FEW_MAX_RAYS = 8;
+constexpr int FEW_ROWS = 32, FEW_MAX_ROWS = 128, FEW_MAX_RAYS = 8;
+// rows per band: a thread's 4·N column-factor exponentials are paid once per band, so narrow images get taller bands
+// (R = 128, N = 8, 32 rows: one exponential per pixel quad and ray again — 0.52 of the HBM rate; 128 rows: a quarter
+// of that) — as long as the grid keeps ≈2048 workgroups (B = 500, R = 128 stays at 32 rows: 2000 short workgroups hide
+// each other's trace and barriers, 500 tall ones would not)
+static int few_band_rows(int B, int R) {
+    int rows = FEW_MAX_ROWS;
+    while (rows > FEW_ROWS && ((long)rows * (R >> 2) > 16 * 256 || (long)B * ((R + rows - 1) / rows) < 2048)) rows >>= 1;
+    return rows;
+}
 
 // NMAX: 1, 2, 4 or 8 >= N — the column factors are NMAX·4 registers, and with them the kernel fits 8 waves per SIMD
 // (its workgroups are short: a band of 32 rows; what hides a workgroup's trace and its two barriers is the other seven)
 template <bool LOSS, int NMAX>
 __global__ void __launch_bounds__(256, 2)
-render_fwd_few(int N, int R, const float* __restrict__ helios, const float* __restrict__ sun,
+render_fwd_few(int N, int R, int band_rows, const float* __restrict__ helios, const float* __restrict__ sun,
                const float* __restrict__ action, const float* __restrict__ trig, long trig_b_stride,
                const float* __restrict__ xs, const float* __restrict__ ys, PlaneK P,
                float* __restrict__ actual, float* __restrict__ refl, float* __restrict__ rays,
                float* __restrict__ image, StepLossArgs L) {
     __shared__ float4 sRay[FEW_MAX_RAYS];              // (a, b, k2, c2)
-    __shared__ __attribute__((aligned(16))) float sA[FEW_ROWS][FEW_MAX_RAYS];       // row factors of the band: A_n[i0 + il]
+    __shared__ __attribute__((aligned(16))) float sA[FEW_MAX_ROWS][FEW_MAX_RAYS];   // row factors of the band: A_n[i0 + il]
     __shared__ float sLoss[2 * FEW_MAX_RAYS];
     __shared__ float scratch[4];
     const int band = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
-    const int i0 = band * FEW_ROWS, rows = min(FEW_ROWS, R - i0);
+    const int i0 = band * band_rows, rows = min(band_rows, R - i0);
     if (tid < N) {
         const int n = tid;
         const long m = (long)b * N + n;
@@ -1048,9 +1057,11 @@ render_fwd_few(int N, int R, const float* __restrict__ helios, const float* __re
             }
         }
     }
-    // (requested while the rays are traced: the row coordinate of this thread's row factor)
-    const int fn = tid & (FEW_MAX_RAYS - 1), fil = tid >> 3;               // FEW_ROWS · FEW_MAX_RAYS = 256 threads
-    const float xrow = xs[min(i0 + fil, R - 1)];
+    // (requested while the rays are traced: the row coordinates of this thread's row factors — rows fil, fil + 32, …)
+    const int fn = tid & (FEW_MAX_RAYS - 1), fil = tid >> 3;               // 32 rows × FEW_MAX_RAYS = 256 threads
+    float xrow[FEW_MAX_ROWS / FEW_ROWS];
+#pragma unroll
+    for (int k = 0; k < FEW_MAX_ROWS / FEW_ROWS; ++k) xrow[k] = xs[min(i0 + fil + FEW_ROWS * k, R - 1)];
     __syncthreads();
     if constexpr (LOSS) {
         if (band == 0 && tid == 0) {
@@ -1062,8 +1073,13 @@ render_fwd_few(int N, int R, const float* __restrict__ helios, const float* __re
     }
     if (fn < N) {
         const float4 q = sRay[fn];
-        const float t = xrow + q.x;
-        sA[fil][fn] = exp2_fast(-(__builtin_fmaf(t, t, q.w) * q.z));
+#pragma unroll
+        for (int k = 0; k < FEW_MAX_ROWS / FEW_ROWS; ++k) {
+            if (FEW_ROWS * k < rows) {                 // (uniform)
+                const float t = xrow[k] + q.x;
+                sA[fil + FEW_ROWS * k][fn] = exp2_fast(-(__builtin_fmaf(t, t, q.w) * q.z));
+            }
+        }
     }
     const int qpr = R >> 2;                            // 16-byte quads per row
     // thread ↔ (column quad, row phase): rpar rows of the band are walked side by side when a row is shorter than
@@ -1140,8 +1156,9 @@ template <bool LOSS>
 static void launch_few(int B, int N, int R, const float* helios, const float* sun, const float* action, const float* trig,
                        long trig_b_stride, const float* xs, const float* ys, const PlaneK& P, float* actual, float* refl,
                        float* rays, float* image, const StepLossArgs& L, hipStream_t st) {
-    const dim3 grid((R + FEW_ROWS - 1) / FEW_ROWS, B), block(256);
-#define HELIO_FEW_FWD(NM) hipLaunchKernelGGL((render_fwd_few<LOSS, NM>), grid, block, 0, st, N, R, helios, sun, action, trig, trig_b_stride, xs, ys, P, actual, refl, rays, image, L)
+    const int band_rows = few_band_rows(B, R);
+    const dim3 grid((R + band_rows - 1) / band_rows, B), block(256);
+#define HELIO_FEW_FWD(NM) hipLaunchKernelGGL((render_fwd_few<LOSS, NM>), grid, block, 0, st, N, R, band_rows, helios, sun, action, trig, trig_b_stride, xs, ys, P, actual, refl, rays, image, L)
     if (N <= 1) HELIO_FEW_FWD(1);
     else if (N <= 2) HELIO_FEW_FWD(2);
     else if (N <= 4) HELIO_FEW_FWD(4);
@@ -1157,7 +1174,9 @@ static bool few_ok(int N, int R, const float* ys, const float* image, const Step
 // and where it wins: always for one or two rays; for up to 8 once the images are large enough to be
 // bound by HBM rather than by launch latency (tools/bench_fused.py: N = 8, B = 64, R = 64 takes 4.4 µs in
 // the block kernel and 5.3 µs here — 40 exponentials per pixel quad)
-static bool few_wins(int B, int N, int R) { return N <= 2 || (long)B * R * R >= (1l << 21); }
+// (round 4, tools/rule_regret.py as graph replays: below ≈0.5 M pixels even one or two rays are 0.3–0.7 µs quicker in the
+// block kernel — B = 4, N = 2, R = 256: 3.6 against 4.3 µs — whose single barrier is the shorter latency chain)
+static bool few_wins(int B, int N, int R) { return (long)B * R * R >= (N <= 2 ? (1l << 19) : (1l << 21)); }
 
 // true when launch_render_fwd() would take the single-launch path
 bool render_is_fused(int B, int N, int R) {
@@ -1269,7 +1288,7 @@ bool launch_env_step_fused(int B, int N, int R, const float* helios, const float
     L.g = make_geom(tp, tn, W, H, exponential_risk);
     switch (resolve_fused_form(form, B, N, R, few_ok(N, R, ys, image, &L))) {
     case 8: {
-        const int bands = (R + FEW_ROWS - 1) / FEW_ROWS;
+        const int band_rows = few_band_rows(B, R), bands = (R + band_rows - 1) / band_rows;      // (launch_few's grid)
         L.part_ray = workspace + 3l * B * bands;
         launch_few<true>(B, N, R, helios, sun, action, trig, trig_b_stride, xs, ys, to_k(plane), actual, refl, rays, image, L, st);
         launch_step_losses_final(B, N, R, bands, B, mask_ratio, L.part_img, L.part_ray, out, mae, keep, notify, ticket, st);

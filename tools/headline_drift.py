@@ -49,7 +49,21 @@ def sample(f, s, a, what):
         finally:
             gc.enable()
     med, best = statistics.median(ts), min(ts)
-    emit(f"{what:<62s} median {25 * K / med / 1e6:5.2f} M frames/s ({med / K * 1e6:5.2f} us/step)   best {25 * K / best / 1e6:5.2f} M")
+    # … and where the time goes: the DEVICE period of the same call in a long back-to-back loop (HIP events, 3000 calls:
+    # the GPU never waits for the host there) and the host's own cost of issuing it (wall clock of 3000 calls, no fence)
+    with torch.no_grad():
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        e0.record()
+        for _ in range(3000):
+            f.render(s, a, None)
+        e1.record()
+        issue = (time.perf_counter() - t0) / 3000
+        torch.cuda.synchronize()
+        period = e0.elapsed_time(e1) * 1e-3 / 3000
+    emit(f"{what:<62s} median {25 * K / med / 1e6:5.2f} M frames/s ({med / K * 1e6:5.2f} us/step)   best {25 * K / best / 1e6:5.2f} M"
+         f"   | long loop: device period {period * 1e6:5.2f} us, host issue {issue * 1e6:5.2f} us per call")
 
 w, f, s, a = make()
 sample(f, s, a, "fresh process, first field")
