@@ -272,24 +272,31 @@ def value_sweep(dev, w, steps, seeds=(0, 1, 2), sigmas=(0.01, 0.1)):
     """the headline loop — K bare ``field.render`` calls + fence, after a burst preheat — for seeds
     0..2 at the training sigma_scale (0.01) and at the README default (0.1): frames/s per seed, median, spread."""
     import gc
-    # This sweep runs late in the process, behind legs that left tens of GB in torch's caching allocator and (the graph
-    # leg) side streams: round 3's line showed the SAME workload at 4.17 M here against 5.48 M as `value`.
-    # tools/headline_drift.py replays the headline sample after each thing the process does in between, one at a time
-    # (profiles/r04_d_headline_drift.txt): a large cached pool costs the launch-bound loop ≈2.2 µs per step (5.7 → 3.8 M
-    # frames/s after 20 GB allocated and freed; back to 5.6 M after empty_cache()), a live second stream that has run work
-    # ≈2.0 µs (→ 3.9 M; back once it is released); a second field, a graph capture, config-4-sized launches, HelioEnv and
-    # its pinned record, the autograd engine's thread, the affinity widened and narrowed: nothing.  So: collect what the
-    # earlier legs dropped and hand the cached blocks back before sampling.
+    # This sweep runs late in the process; round 3's line showed the SAME workload at 4.17 M here against 5.48 M as
+    # `value`.  tools/headline_drift.py replays the headline sample after each thing the process does in between, one at
+    # a time, on two boxes (profiles/r04_d_headline_drift.txt, r04_f_headline_drift.txt): the loop has TWO MODES — 4.35 µs
+    # per step (5.7 M frames/s; device period of a long loop 3.72 µs) and 5.3–6.5 µs (3.8–4.7 M; device period 4.1–4.2 µs,
+    # i.e. the dispatch itself is slower, not the host's issue) — and drops into the slow one at DIFFERENT points in the
+    # two runs (once when a side stream had run, and again after 20 GB had been allocated and freed; once after
+    # config-4-sized launches, then for every later sample) and comes back by itself or — every time — when the threads'
+    # affinity is reset (widened to the NUMA node and bound to the CCD again).  None of the listed state is the cause
+    # (allocator pool, streams, graphs, a second field, HelioEnv, the autograd thread: each neutral in one of the runs);
+    # it is where threads and queue lines sit after a phase that moved them (tools/core_sweep.py: the CCD the runtime's
+    # helper threads live on is 25 % faster than its neighbours).  So: re-bind before sampling, and say so.
     gc.collect()
     reserved0 = torch.cuda.memory_reserved(dev)
     torch.cuda.empty_cache()
+    from doodle_amd import affinity
+    affinity.widen_to_node(dev.index or 0)
+    rebound = affinity.bind_to_gpu_ccd(dev.index or 0)
     out = {"steps": steps, "what": "frames/s of K field.render calls + synchronize (the timed region of `value`), one fresh "
                                    "field per (seed, sigma_scale); spread = (max - min) / median",
-           "allocator": {"reserved_GB_left_by_the_earlier_legs": round(reserved0 / 2**30, 2),
-                         "reserved_GB_after_empty_cache": round(torch.cuda.memory_reserved(dev) / 2**30, 2),
-                         "why": "a large cached pool in torch's allocator (and a live side stream) costs this launch-bound loop "
-                                "≈2 µs per step — profiles/r04_d_headline_drift.txt; round 3 sampled with the pool full "
-                                "(seed 0 here = the workload of `value`: 4.17 M then against 5.48 M)"}}
+           "before_sampling": {"threads_rebound_to": rebound["l3_group"] if rebound else None,
+                               "allocator_GB_reserved_then_released": round(reserved0 / 2**30, 2),
+                               "why": "the launch-bound loop has two modes (4.35 / 5.3–6.5 µs per step) and a phase that moves "
+                                      "threads can leave it in the slow one until the affinity is reset — "
+                                      "profiles/r04_d_headline_drift.txt, r04_f_headline_drift.txt; round 3 sampled without "
+                                      "resetting it (seed 0 here = the workload of `value`: 4.17 M then against 5.48 M)"}}
     for sg in sigmas:
         vals = []
         for seed in seeds:

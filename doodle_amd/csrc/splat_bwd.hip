@@ -163,7 +163,7 @@ __device__ __forceinline__ void
 splat_bwd_mfma_body(int B, int N, int R, const float* __restrict__ rays, const float* __restrict__ xs,
                     const float* __restrict__ ys, const float* __restrict__ gimg, float* __restrict__ moments,
                     const int* __restrict__ live_counts, const int* __restrict__ live_idx, const int* __restrict__ live_total,
-                    const int2* __restrict__ live_map, int live_ct) {
+                    const int2* __restrict__ live_map, int live_ct, int tile_rays = CULL_BWD_TILE) {
     static_assert(!(VEC && PASS == 1), "16-byte staging is pass 0's");
     // Row pitch of the two LDS tables.  Pass 1 writes the slab transposed (lanes ↔ k at stride LD):
     // an odd pitch keeps that conflict-free.  Pass 0 writes it along c and stages it 16 bytes at a time
@@ -205,7 +205,7 @@ splat_bwd_mfma_body(int B, int N, int R, const float* __restrict__ rays, const f
         b = live_ct > 1 ? e.x / c_tiles : e.x;
         bx = e.y * c_tiles + (live_ct > 1 ? e.x % c_tiles : (int)(w % per));
     }
-    const int c0 = (bx % c_tiles) * TC, n0 = (bx / c_tiles) * CULL_BWD_TILE;     // (tiles are numbered in 256 rays whatever WR)
+    const int c0 = (bx % c_tiles) * TC, n0 = (bx / c_tiles) * tile_rays;     // (tiles are numbered in 256 rays whatever WR — except in the HELIO_BWD_WR2 experiment)
     const int L = live_counts ? live_counts[lst] : N;
     const int* __restrict__ lidx = live_counts ? live_idx + (long)lst * N : nullptr;
     const int wc = (wave / WR) * 64, wn = (wave % WR) * 64;
@@ -384,7 +384,7 @@ splat_bwd_mfma_body(int B, int N, int R, const float* __restrict__ rays, const f
     }
 }
 
-// ---- the same tile with the two LDS tables DOUBLE-BUFFERED (round 4) ---------------------------------------------
+// ---- the same tile with the two LDS tables DOUBLE-BUFFERED (round 4; opt-in, HELIO_BWD_DB=1: it did NOT pay) -------
 // The body above alternates two phases per 64-deep chunk, separated by barriers: every wave stores its share of the slab
 // and computes its share of the factor table (16 exponentials and their fused multiply-adds per thread: VALU), then
 // every wave issues its 128 MFMAs.  In the first phase the matrix pipe of all four SIMDs idles — PMC (round 2): pipe busy
@@ -392,6 +392,12 @@ splat_bwd_mfma_body(int B, int N, int R, const float* __restrict__ rays, const f
 // the MFMAs of chunk c out of one pair of tables it produces chunk c + 1 into the other — one factor after every eight
 // MFMAs, in the shadow of the pipe — and ONE barrier per chunk hands the pairs over.  Same operands, same order of the
 // contracted axis, same epilogue: the moments are the bits of the single-buffered body.
+// MEASURED (config 4, one box, profiles/r04_e_bwd_db.txt): dense 8.29 ms single-buffered; this body 9.15 ms in its first
+// form (every pair of operand reads waited for in front of its four MFMAs), 8.71 ms with the operands of k-pair kp + 1
+// requested before the MFMAs of kp and the epilogue's rays fetched at kernel start (114–118 VGPRs, no spill) — 5 % BEHIND:
+// the producer's vector instructions are not free beside this chip's 16-pass f32 MFMAs (they take the SIMD's issue slots
+// whichever wave they come from), so interleaving them moves the producer phase's cycles into the MFMA phase instead of
+// hiding them, and the per-chunk pointer arithmetic and branches come on top.  The single-buffered body stays the default.
 template <int PASS, bool VEC, int WC>
 __device__ __forceinline__ void
 splat_bwd_mfma_body_db(int B, int N, int R, const float* __restrict__ rays, const float* __restrict__ xs,
@@ -629,11 +635,11 @@ __global__ void __launch_bounds__(64 * WC * WR, WC == 4 ? 4 : 2)
 splat_bwd_mfma_both(int B, int N, int R, const float* __restrict__ rays, const float* __restrict__ xs,
                     const float* __restrict__ ys, const float* __restrict__ gimg, float* __restrict__ moments,
                     const int* __restrict__ live_counts, const int* __restrict__ live_idx, const int* __restrict__ live_total,
-                    const int2* __restrict__ live_map, int live_ct, long set_lists, long map_stride) {
+                    const int2* __restrict__ live_map, int live_ct, long set_lists, long map_stride, int tile_rays) {
     static_assert(!DB || WR == 4, "the double-buffered body is the 256-ray tile's");
     if (blockIdx.z == 0) {
         if constexpr (DB) splat_bwd_mfma_body_db<0, VEC, WC>(B, N, R, rays, xs, ys, gimg, moments, live_counts, live_idx, live_total, live_map, live_ct);
-        else splat_bwd_mfma_body<0, VEC, WC, WR>(B, N, R, rays, xs, ys, gimg, moments, live_counts, live_idx, live_total, live_map, live_ct);
+        else splat_bwd_mfma_body<0, VEC, WC, WR>(B, N, R, rays, xs, ys, gimg, moments, live_counts, live_idx, live_total, live_map, live_ct, tile_rays);
     } else {
         const bool own = live_counts && live_ct > 1;
         const int* lc = own ? live_counts + set_lists : live_counts;
@@ -641,7 +647,7 @@ splat_bwd_mfma_both(int B, int N, int R, const float* __restrict__ rays, const f
         const int* lt = own ? live_total + 1 : live_total;
         const int2* lm = own ? live_map + map_stride : live_map;
         if constexpr (DB) splat_bwd_mfma_body_db<1, false, WC>(B, N, R, rays, xs, ys, gimg, moments, lc, li, lt, lm, live_ct);
-        else splat_bwd_mfma_body<1, false, WC, WR>(B, N, R, rays, xs, ys, gimg, moments, lc, li, lt, lm, live_ct);
+        else splat_bwd_mfma_body<1, false, WC, WR>(B, N, R, rays, xs, ys, gimg, moments, lc, li, lt, lm, live_ct, tile_rays);
     }
 }
 
@@ -1081,12 +1087,16 @@ static void launch_bwd_mfma_both_v(int B, int N, int R, const float* rays, const
     const int ct = (R + TC - 1) / TC, nt = (N + 255) / 256;
     if (WR == 4) {
         hipLaunchKernelGGL((splat_bwd_mfma_both<VEC, WC, WR, DB>), dim3(ct * nt, B, 2), dim3(64 * WC * WR), lds, st, B, N, R, rays, xs, ys, gimg,
-                           moments, c.counts, c.idx, c.total, c.map, c.ct, c.set_lists, c.set_items);
+                           moments, c.counts, c.idx, c.total, c.map, c.ct, c.set_lists, c.set_items, CULL_BWD_TILE);
+    } else if (!c.counts) {
+        // (HELIO_BWD_WR2 experiment: the 128-ray form over EVERY tile of a dense launch, tiles numbered in 128 rays)
+        hipLaunchKernelGGL((splat_bwd_mfma_both<VEC, WC, WR, DB>), dim3(ct * ((N + 127) / 128), B, 2), dim3(64 * WC * WR), lds, st, B, N, R, rays, xs, ys, gimg,
+                           moments, nullptr, nullptr, nullptr, nullptr, 1, 0l, 0l, 128);
     } else {
         // the short last tiles: at most one per list (and c tile, where a list serves all of an image's c tiles)
         const long items = c.set_lists * (c.ct > 1 ? 1 : ct);
         hipLaunchKernelGGL((splat_bwd_mfma_both<VEC, WC, WR, DB>), dim3((unsigned)items, 1, 2), dim3(64 * WC * WR), lds, st, B, N, R, rays, xs, ys,
-                           gimg, moments, c.counts, c.idx, c.tail_total, c.tail_map, c.ct, c.set_lists, c.set_lists);
+                           gimg, moments, c.counts, c.idx, c.tail_total, c.tail_map, c.ct, c.set_lists, c.set_lists, CULL_BWD_TILE);
     }
 }
 
@@ -1120,10 +1130,14 @@ static void launch_bwd_mfma_both(int B, int N, int R, const float* rays, const f
         // at pass 1's register count
         if (vec) launch_bwd_mfma_both_v<true, 2, 4>(B, N, R, rays, xs, ys, gimg, moments, st, cull);
         else launch_bwd_mfma_both_v<false, 2, 4>(B, N, R, rays, xs, ys, gimg, moments, st, cull);
+    } else if (vec && !cull.counts && [] { const char* e = getenv("HELIO_BWD_WR2"); return e && e[0] == '1'; }()) {
+        launch_bwd_mfma_both_v<true, 4, 2>(B, N, R, rays, xs, ys, gimg, moments, st, cull);       // experiment: 128-ray tiles, two workgroups per CU
     } else if (vec) {
-        // HELIO_BWD_DB=0: the single-buffered body (A/B runs; the same bits)
+        // HELIO_BWD_DB=1: the double-buffered body — the same bits, measured SLOWER at config 4 (dense 8.71 against 8.29 ms,
+        // with the lists 5.28 / 5.08; profiles/r04_e_bwd_db.txt) and therefore not the default: kept as the record of the
+        // experiment and for the test that holds the two bodies to the same bits
         const char* e = getenv("HELIO_BWD_DB");        // (read per call — these launches are milliseconds — so that a test can compare the two bodies in one process)
-        const bool db = !(e && e[0] == '0');
+        const bool db = e && e[0] == '1';
         if (db) launch_bwd_mfma_both_v<true, 4, 4, true>(B, N, R, rays, xs, ys, gimg, moments, st, cull);
         else launch_bwd_mfma_both_v<true, 4, 4>(B, N, R, rays, xs, ys, gimg, moments, st, cull);
         if (cull.tail_map) launch_bwd_mfma_both_v<true, 4, 2>(B, N, R, rays, xs, ys, gimg, moments, st, cull);

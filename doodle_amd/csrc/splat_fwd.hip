@@ -1176,7 +1176,13 @@ static bool few_ok(int N, int R, const float* ys, const float* image, const Step
 // the block kernel and 5.3 µs here — 40 exponentials per pixel quad)
 // (round 4, tools/rule_regret.py as graph replays: below ≈0.5 M pixels even one or two rays are 0.3–0.7 µs quicker in the
 // block kernel — B = 4, N = 2, R = 256: 3.6 against 4.3 µs — whose single barrier is the shorter latency chain)
-static bool few_wins(int B, int N, int R) { return (long)B * R * R >= (N <= 2 ? (1l << 19) : (1l << 21)); }
+// Final form, from the second table (profiles/r04_c_rule_regret.txt): one or two rays — from 64 bands of 32 rows (B = 25,
+// R = 100: 3.9 against 4.3 µs; B = 4, R = 256, 32 bands: 4.1 / 3.6); up to four — from 2 M pixels; up to eight — from 8 M
+// (B = 500, N = 8, R = 128, 8.2 M: 13.0 against 11.8 µs for geometry + the 64² register kernel; R = 256, 33 M: level).
+static bool few_wins(int B, int N, int R) {
+    if (N <= 2) return (long)B * ((R + FEW_ROWS - 1) / FEW_ROWS) >= 64;
+    return (long)B * R * R >= (N <= 4 ? (1l << 21) : (1l << 23));
+}
 
 // true when launch_render_fwd() would take the single-launch path
 bool render_is_fused(int B, int N, int R) {
@@ -1189,10 +1195,11 @@ bool render_is_fused(int B, int N, int R) {
     // … and only while the re-tracing stays small: every 32×32 block traces all N rays of its sun, B·N·⌈R/32⌉² traces in
     // all against the B·N of the geometry kernel.  tools/rule_regret.py (profiles/r04_c_rule_regret_before.txt): from
     // ≈300 k traces the two launches win — B = 500, N = 96, R = 128: 35.8 against 24.3 µs; B = 256, N = 200, R = 128:
-    // 36.1 / 27.3; B = 60, N = 200, R = 256: 34.4 / 27.8; at 200 k (B = 256, N = 50, R = 128) the single launch still does
+    // 36.1 / 27.3; B = 60, N = 200, R = 256: 34.4 / 27.8; at 256 k (B = 500, N = 32, R = 128) still by 11 %: 16.8 / 15.2; at
+    // 205 k (B = 256, N = 50, R = 128) the single launch is level or ahead
     const long t128 = (long)B * ((R + 127) / 128) * ((R + 127) / 128);
     const long nb = (R + 31) / 32;
-    return N <= FEW_MAX_RAYS || (N <= 256 && t128 < 512 && (long)B * N * nb * nb <= (1l << 18));
+    return N <= FEW_MAX_RAYS || (N <= 256 && t128 < 512 && (long)B * N * nb * nb <= 225000);
 }
 
 // waves per 32×32 block of the fused kernel (the heliostats are split between them; 64·KG >= N): as

@@ -38,7 +38,7 @@ def launch_stubs() -> str:
         # the size rules the host layer consults are part of what is under test: restate them
         rules = {
             "splat_bwd_blocks": "return (a0 + 63) / 64;",
-            "render_is_fused": "{ const long t = (long)a0 * ((a2 + 127) / 128) * ((a2 + 127) / 128); const long nb = (a2 + 31) / 32; return a1 <= 8 || (a1 <= 256 && t < 512 && (long)a0 * a1 * nb * nb <= (1l << 18)); }",
+            "render_is_fused": "{ const long t = (long)a0 * ((a2 + 127) / 128) * ((a2 + 127) / 128); const long nb = (a2 + 31) / 32; return a1 <= 8 || (a1 <= 256 && t < 512 && (long)a0 * a1 * nb * nb <= 225000); }",
             "step_losses_chunks": "return 4;",
             "step_losses_ray_wgs": "return 4;",
             "step_losses_max_mask_batch": "return 4096;",

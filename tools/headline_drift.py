@@ -9,7 +9,13 @@ the two readings, one at a time, so that the step that moves the figure shows:
   replay / 20 GB allocated and freed through the caching allocator (+ empty_cache) / the config-4 forward (large
   launches, device scratch) / HelioEnv construction and steps (its streams, its pinned completion record) /
   the affinity widened to the NUMA node and narrowed again.
-usage: headline_drift.py [out.txt]"""
+usage: headline_drift.py [out.txt]
+
+FOUND (two runs, two boxes: profiles/r04_d_headline_drift.txt, r04_f_headline_drift.txt): the loop has two modes — 4.35 µs
+per step and 5.3–6.5 µs (device period of a long loop 3.72 against 4.1–4.2 µs: the dispatch is slower, not the host's issue)
+— and none of the listed state decides between them: the slow mode set in at different points in the two runs (with a side
+stream and with 20 GB cached in one; after config-4-sized launches in the other, where the stream and the pool were neutral)
+and ended by itself or when the threads' affinity was reset.  bench.py's late sweep now resets it before sampling."""
 import os, sys, time, gc, statistics
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
