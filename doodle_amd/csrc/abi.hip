@@ -25,6 +25,7 @@ long splat_fwd_scratch_required(int, int, int, int);
 long splat_bwd_scratch_bytes(int, int, int, int);
 int splat_bwd_blocks(int);
 bool render_is_fused(int, int, int);
+bool render_is_fused_plain(int, int, int);
 int render_fwd_choice(int, int, int);
 void launch_distance_maps(int, int, const float*, float, int*, float*, int*, float*, hipStream_t);
 int step_losses_chunks(int);
@@ -146,7 +147,7 @@ int helio_render_fwd(int B, int N, int R, const float* helios_d, const float* su
         return fail(HELIO_E_INVALID, "render_fwd: trig/rays/image must be 16-byte aligned");
     if (!scratch_ok(scratch_d, scratch_bytes)) return fail(HELIO_E_INVALID, "render_fwd: scratch must be 256-byte aligned");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (((variant == 0 || variant == 2) && helio::render_is_fused(B, N, R)) || fused_form(variant)) {
+    if (((variant == 0 || variant == 2) && helio::render_is_fused_plain(B, N, R)) || fused_form(variant)) {
         if (!helio::launch_render_fused(B, N, R, helios_d, sun_d, action_d, trig_d, trig_b_stride, plane, xs_d, ys_d,
                                         actual_d, refl_d, rays_d, image_d, fused_form(variant), st))
             return fail(HELIO_E_INVALID, "render_fwd: variant %d does not exist for B=%d N=%d R=%d", variant, B, N, R);
@@ -170,18 +171,18 @@ int helio_render_bwd_choice(int B, int N, int R) {
 }
 
 int helio_render_fwd_launches(int B, int N, int R) {
-    return (sizes_ok(B, N) && R >= 1 && helio::render_is_fused(B, N, R)) ? 1 : 2;
+    return (sizes_ok(B, N) && R >= 1 && helio::render_is_fused_plain(B, N, R)) ? 1 : 2;
 }
 
 long helio_fwd_scratch_bytes(int B, int N, int R, int variant) {
     if (!sizes_ok(B, N) || R < 1 || R > 16384) return 0;
-    if (((variant == 0 || variant == 2) && helio::render_is_fused(B, N, R)) || fused_form(variant)) return 0;
+    if (((variant == 0 || variant == 2) && helio::render_is_fused_plain(B, N, R)) || fused_form(variant)) return 0;
     return helio::splat_fwd_scratch_bytes(B, N, R, variant);
 }
 
 long helio_fwd_scratch_required(int B, int N, int R, int variant) {
     if (!sizes_ok(B, N) || R < 1 || R > 16384) return 0;
-    if (((variant == 0 || variant == 2) && helio::render_is_fused(B, N, R)) || fused_form(variant)) return 0;
+    if (((variant == 0 || variant == 2) && helio::render_is_fused_plain(B, N, R)) || fused_form(variant)) return 0;
     return helio::splat_fwd_scratch_required(B, N, R, variant);
 }
 

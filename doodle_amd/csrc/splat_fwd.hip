@@ -1202,6 +1202,18 @@ bool render_is_fused(int B, int N, int R) {
     return N <= FEW_MAX_RAYS || (N <= 256 && t128 < 512 && (long)B * N * nb * nb <= 225000);
 }
 
+// … for the render ALONE (helio_render_fwd; the env step keeps the rule above: its fused forms also spare the loss block a
+// pass over the image).  A handful of rays no longer means one launch at any size: where the streaming kernel does not
+// win (few_wins) the block kernel must earn its place like everybody — and with more than 4096 blocks it does not, however
+// few rays each traces: B = 500, N = 8, R = 100: 12.6 against 10.6 µs for geometry + the 128² register kernel; N = 16,
+// R = 128: 14.0 / 13.2 (third table, profiles/r04_c_rule_regret.txt)
+bool render_is_fused_plain(int B, int N, int R) {
+    if (N <= FEW_MAX_RAYS && few_wins(B, N, R)) return true;
+    const long t128 = (long)B * ((R + 127) / 128) * ((R + 127) / 128);
+    const long nb = (R + 31) / 32;
+    return N <= 256 && t128 < 512 && (long)B * N * nb * nb <= 225000 && (long)B * nb * nb <= 4096;
+}
+
 // waves per 32×32 block of the fused kernel (the heliostats are split between them; 64·KG >= N): as
 // many as keep the chip's 1024 SIMDs at about one wave each and leave every wave a few k-pairs.
 // HELIO_FUSED_KG (1, 2 or 4) forces one form where N allows it — tuning runs only
@@ -1615,7 +1627,7 @@ static int splat_fwd_choice(int B, int N, int R) {
 // GPU — passes the choice of the WHOLE batch with every piece and gets the rows of the unsharded render
 // bit for bit.  (The few-ray form assumes 16-byte aligned images, as torch's allocations are.)
 int render_fwd_choice(int B, int N, int R) {
-    if (render_is_fused(B, N, R)) {
+    if (render_is_fused_plain(B, N, R)) {
         const int f = resolve_fused_form(0, B, N, R, N <= FEW_MAX_RAYS && (R & 3) == 0);
         return f == 8 ? 13 : f == 4 ? 12 : f == 2 ? 11 : 10;
     }

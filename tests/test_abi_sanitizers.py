@@ -39,6 +39,7 @@ def launch_stubs() -> str:
         rules = {
             "splat_bwd_blocks": "return (a0 + 63) / 64;",
             "render_is_fused": "{ const long t = (long)a0 * ((a2 + 127) / 128) * ((a2 + 127) / 128); const long nb = (a2 + 31) / 32; return a1 <= 8 || (a1 <= 256 && t < 512 && (long)a0 * a1 * nb * nb <= 225000); }",
+            "render_is_fused_plain": "{ const long t = (long)a0 * ((a2 + 127) / 128) * ((a2 + 127) / 128); const long nb = (a2 + 31) / 32; return (a1 <= 8 && (long)a0 * a2 * a2 >= (1l << 21)) || (a1 <= 256 && t < 512 && (long)a0 * a1 * nb * nb <= 225000 && (long)a0 * nb * nb <= 4096); }",
             "step_losses_chunks": "return 4;",
             "step_losses_ray_wgs": "return 4;",
             "step_losses_max_mask_batch": "return 4096;",
