@@ -179,7 +179,10 @@ splat_bwd_mfma_body(int B, int N, int R, const float* __restrict__ rays, const f
     // a list's last tile is half empty on average, and lists are short (≈1100 rays at config 4: cull.h)
     // (the 128-ray form stages 32 k at a time: the same 16 slab values per thread as the 256-ray form, 50 KB of LDS and —
     // held to 128 registers by its launch bounds — two workgroups per CU, each in the other's producer phase)
-    constexpr int KC = WR == 2 ? 32 : 64, T = 64 * WR, TC = 64 * WC, NT = 64 * WC * WR, KPT = KC / WC, NV = KC * TC / NT;
+    // (WR = 1, round 4: 64-ray tiles for fields of 33–128 heliostats on large or many images — 4 waves, 16 k at a time
+    // (16 slab values per thread: 32 spilled), 21 KB of LDS, three workgroups per CU by their registers; the slab is
+    // staged four times as often per MFMA as in the 256-ray tile)
+    constexpr int KC = WR == 1 ? 16 : (WR == 2 ? 32 : 64), T = 64 * WR, TC = 64 * WC, NT = 64 * WC * WR, KPT = KC / WC, NV = KC * TC / NT;
     constexpr int LDG = PASS == 0 ? TC + 4 : TC + 1, LD = PASS == 0 ? T + 4 : T + 1;
     extern __shared__ __attribute__((aligned(16))) float smem[];   // sG[KC][LDG] sF[KC][LD] ccoord[TC]
     float* __restrict__ sCc = smem + KC * (LDG + LD);
@@ -631,7 +634,7 @@ splat_bwd_mfma(int B, int N, int R, const float* __restrict__ rays, const float*
 template <bool VEC, int WC, int WR, bool DB = false>
 // (launch bounds — 256-wide tiles: four waves a SIMD, one 16-wave workgroup or two 8-wave ones per CU; 128-wide: two, one
 // 8-wave workgroup with its 101 KB of LDS)
-__global__ void __launch_bounds__(64 * WC * WR, WC == 4 ? 4 : 2)
+__global__ void __launch_bounds__(64 * WC * WR, WR == 1 ? 3 : (WC == 4 ? 4 : 2))
 splat_bwd_mfma_both(int B, int N, int R, const float* __restrict__ rays, const float* __restrict__ xs,
                     const float* __restrict__ ys, const float* __restrict__ gimg, float* __restrict__ moments,
                     const int* __restrict__ live_counts, const int* __restrict__ live_idx, const int* __restrict__ live_total,
@@ -938,6 +941,21 @@ splat_bwd_mfma_small(int N, int R, const float* __restrict__ rays, const float* 
 bool splat_bwd_is_few(int B, int N);
 bool splat_bwd_is_few(int B, int N, int R);
 
+// Where the LDS-tile kernel runs in 64-RAY tiles (variant 12, round 4: splat_bwd_mfma_both<…, WR = 1>, 4 waves, 16 k per
+// chunk, three workgroups per CU): fields of 33–192 heliostats — one to three tiles that are 52–100 % full where a 256-ray
+// tile would be 13–75 % — on images and batches large enough to give it a few hundred workgroups.  tools/check_v12.py
+// (profiles/r04_k_bwd_tile64.txt), helio_render_bwd per call: B = 256, N = 50, R = 512: 279 → 165 µs; B = 500, N = 128,
+// R = 512: 1058 → 631; B = 256, N = 128, R = 256: 150 → 92; B = 500, N = 50, R = 128: 52 → 38.  It loses with four tiles
+// (N = 200: the 256-ray tile is 78 % full and stages its slab a quarter as often) and with few workgroups (B = 60,
+// N = 50, R = 256: 32 against 22 µs for the small-tile kernel), more of them being needed where the contracted axis is
+// short (R <= 128: a workgroup is eight 16-deep chunks).  Same bits as variant 2: a ray's chain over the contracted axis
+// does not know how many rays share its tile.
+static bool bwd_tile64(int B, int N, int R) {
+    if (N <= 32 || N > 192 || R <= 64) return false;
+    const long wgs = 2l * ((R + (R <= 128 ? 127 : 255)) / (R <= 128 ? 128 : 256)) * ((N + 63) / 64) * B;
+    return wgs >= (R <= 128 ? 800 : 240);
+}
+
 template <int CT>
 __global__ void __launch_bounds__(1024)
 render_bwd_fused_small(int B, int N, int R, const float* __restrict__ rays, const float* __restrict__ xs,
@@ -997,7 +1015,7 @@ render_bwd_fused_small(int B, int N, int R, const float* __restrict__ rays, cons
 // The sizes the single-launch backward serves (variant 8 forces it; HELIO_BWD_FUSED=0 switches the choice off).
 bool render_bwd_is_fused(int B, int N, int R) {
     static const bool off = [] { const char* e = getenv("HELIO_BWD_FUSED"); return e && e[0] == '0'; }();
-    if (off || splat_bwd_is_few(B, N, R) || R > 256) return false;
+    if (off || splat_bwd_is_few(B, N, R) || R > 256 || bwd_tile64(B, N, R)) return false;
     // Round 4, from tools/rule_regret.py (device times as HIP-graph replays; profiles/r04_c_rule_regret.txt).  wg = the
     // launch's workgroups, one per 32 rays of a sun, 16 waves each.
     const long wg = (long)B * ((N + 31) / 32);
@@ -1076,7 +1094,7 @@ static void launch_bwd_mfma_v(int B, int N, int R, const float* rays, const floa
 template <bool VEC, int WC, int WR, bool DB = false>
 static void launch_bwd_mfma_both_v(int B, int N, int R, const float* rays, const float* xs, const float* ys,
                                    const float* gimg, float* moments, hipStream_t st, CullBwd c) {
-    constexpr int TC = 64 * WC, T = 64 * WR, KC = (WR == 2 || DB) ? 32 : 64;
+    constexpr int TC = 64 * WC, T = 64 * WR, KC = WR == 1 ? 16 : ((WR == 2 || DB) ? 32 : 64);
     const size_t lds = ((DB ? 2 : 1) * KC * ((TC + 4) + (T + 4)) + TC + 64) * sizeof(float);      // pass 0's pitches: the larger of the two
     static bool configured = false;
     if (!configured) {
@@ -1089,9 +1107,10 @@ static void launch_bwd_mfma_both_v(int B, int N, int R, const float* rays, const
         hipLaunchKernelGGL((splat_bwd_mfma_both<VEC, WC, WR, DB>), dim3(ct * nt, B, 2), dim3(64 * WC * WR), lds, st, B, N, R, rays, xs, ys, gimg,
                            moments, c.counts, c.idx, c.total, c.map, c.ct, c.set_lists, c.set_items, CULL_BWD_TILE);
     } else if (!c.counts) {
-        // (HELIO_BWD_WR2 experiment: the 128-ray form over EVERY tile of a dense launch, tiles numbered in 128 rays)
-        hipLaunchKernelGGL((splat_bwd_mfma_both<VEC, WC, WR, DB>), dim3(ct * ((N + 127) / 128), B, 2), dim3(64 * WC * WR), lds, st, B, N, R, rays, xs, ys, gimg,
-                           moments, nullptr, nullptr, nullptr, nullptr, 1, 0l, 0l, 128);
+        // dense launches of the narrow forms, tiles numbered in T rays: WR = 1 (variant 12) — and the HELIO_BWD_WR2
+        // experiment, the 128-ray form over EVERY tile
+        hipLaunchKernelGGL((splat_bwd_mfma_both<VEC, WC, WR, DB>), dim3(ct * ((N + T - 1) / T), B, 2), dim3(64 * WC * WR), lds, st, B, N, R, rays, xs, ys, gimg,
+                           moments, nullptr, nullptr, nullptr, nullptr, 1, 0l, 0l, T);
     } else {
         // the short last tiles: at most one per list (and c tile, where a list serves all of an image's c tiles)
         const long items = c.set_lists * (c.ct > 1 ? 1 : ct);
@@ -1608,10 +1627,12 @@ void launch_splat_bwd_fused_loss_raw(int B, int N, int R, const float* rays, con
 int splat_bwd_blocks(int R) { return (R + BW_JT - 1) / BW_JT; }
 
 // variant: 0 = by problem size, 1 = VALU kernel, 2 = MFMA kernels (256-tiles), 3 = MFMA small tiles,
-// 4 = few-ray streaming kernel, 5 = split-bf16 MFMA kernels (opt-in), 6 / 7 = the small kernel with 4 / 8 waves
+// 4 = few-ray streaming kernel, 5 = split-bf16 MFMA kernels (opt-in), 6 / 7 = the small kernel with 4 / 8 waves,
+// 9 / 10 / 11 = its forms by the cut of the contracted axis, 12 = the LDS-tile kernel in 64-ray tiles
 // the kernel family variant 0 stands for at this size
 static int splat_bwd_choice(int B, int N, int R) {
     if (splat_bwd_is_few(B, N, R)) return 4;
+    if (bwd_tile64(B, N, R)) return 12;
     // tools/sweep_bwd.py, tools/sweep_bwd_mid.py: the LDS-tile kernels (256 rays × 256 c, or × 128 c for images of at
     // most 128 pixels across) against the small-tile kernel; below 65 pixels even the narrow tile is half padding and
     // the small-tile kernel is its equal.  Both passes of the LDS-tile kernels are ONE launch of 2·tiles workgroups, one
@@ -1754,6 +1775,15 @@ int launch_splat_bwd(int B, int N, int R, const float* rays, const float* xs, co
             hipLaunchKernelGGL(splat_bwd_mfma_small<8>, dim3(ct * nt, B, 2), dim3(512), 0, st, N, R, rays, xs, ys, gimg, moments, nullptr, nullptr);
         else
             hipLaunchKernelGGL(splat_bwd_mfma_small<4>, dim3(ct * nt, B, 2), dim3(256), 0, st, N, R, rays, xs, ys, gimg, moments, nullptr, nullptr);
+        return HELIO_OK;
+    }
+    if (variant == 12) {       // (round 4) the LDS-tile kernel in 64-ray tiles (256- or 128-wide c tiles), dense
+        const bool vec = (R & 3) == 0;
+        if (R <= 128) {
+            if (vec) launch_bwd_mfma_both_v<true, 2, 1>(B, N, R, rays, xs, ys, gimg, moments, st, CullBwd{});
+            else launch_bwd_mfma_both_v<false, 2, 1>(B, N, R, rays, xs, ys, gimg, moments, st, CullBwd{});
+        } else if (vec) launch_bwd_mfma_both_v<true, 4, 1>(B, N, R, rays, xs, ys, gimg, moments, st, CullBwd{});
+        else launch_bwd_mfma_both_v<false, 4, 1>(B, N, R, rays, xs, ys, gimg, moments, st, CullBwd{});
         return HELIO_OK;
     }
     if (variant == 2) {

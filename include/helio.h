@@ -182,7 +182,7 @@ int helio_render_fwd_choice(int B, int N, int R);
 
 /*
  * The same for the backward: the variant that helio_render_bwd's variant 0 resolves to at (B, N, R) — 8 (the
- * single-launch form), 4, 2, or 9 / 10 / 11 (the small-tile kernel with its contracted axis whole / cut between
+ * single-launch form), 4, 2, 12, or 9 / 10 / 11 (the small-tile kernel with its contracted axis whole / cut between
  * four / eight waves); 0 for invalid sizes.  A ray's moments are sums over ITS image only, in an order fixed by the
  * variant, N and R, so a shard that passes the whole batch's choice gets the unsharded gradient's rows bit for
  * bit (the lists of helio_bwd_scratch_bytes and the workgroup shapes still follow the shard's own size: they
@@ -210,7 +210,8 @@ int helio_splat_bwd_blocks(int R);
  * bf16 pieces, six partial products per product on the bf16 matrix pipe, f32 accumulation);
  * 6 / 7 = the small-tile kernel forced to 4 / 8 waves per workgroup and one ray block per wave (tests, tuning);
  * 9 / 10 / 11 = the forms 3 chooses between by size: contracted axis whole / cut between four / eight waves
- * (helio_render_bwd_choice).
+ * (helio_render_bwd_choice); 12 = the LDS-tile kernels of 2 in 64-ray tiles (same bits as 2; what 0 chooses for fields
+ * of 33..192 heliostats once images and batch give it a few hundred workgroups).
  */
 int helio_splat_bwd(int B, int N, int R,
                     const float *rays_d, const float *xs_d, const float *ys_d,

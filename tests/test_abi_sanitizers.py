@@ -50,7 +50,7 @@ def launch_stubs() -> str:
             "splat_fwd_scratch_bytes": "return (a1 >= 192 && (a3 == 5 || a3 == 0)) ? 4096 : 0;",
             "splat_fwd_scratch_required": "return (a3 >= 14 && a3 <= 17) ? 8192 : 0;",
             "splat_bwd_scratch_bytes": "return (a1 > 256 && (a3 == 2 || a3 == 0)) ? 4096 : 0;",
-            "render_bwd_is_fused": "{ const bool few = a1 <= 8 && (a1 <= 2 || (long)a0 * a2 * a2 >= (1l << 21)); const long wg = (long)a0 * ((a1 + 31) / 32); if (few || a2 > 256) return false; if (a2 <= 128 && wg <= 64) return true; if (a2 > 64 && a2 <= 128) return wg >= 160 && (a1 <= 64 || wg <= 512); if (a2 > 128) return a1 <= 64 && wg >= 256; return false; }",
+            "render_bwd_is_fused": "{ if (a1 > 32 && a1 <= 192 && a2 > 64 && 2l * ((a2 + (a2 <= 128 ? 127 : 255)) / (a2 <= 128 ? 128 : 256)) * ((a1 + 63) / 64) * a0 >= (a2 <= 128 ? 800 : 240)) return false; const bool few = a1 <= 8 && (a1 <= 2 || (long)a0 * a2 * a2 >= (1l << 21)); const long wg = (long)a0 * ((a1 + 31) / 32); if (few || a2 > 256) return false; if (a2 <= 128 && wg <= 64) return true; if (a2 > 64 && a2 <= 128) return wg >= 160 && (a1 <= 64 || wg <= 512); if (a2 > 128) return a1 <= 64 && wg >= 256; return false; }",
         }
         args = [a.strip() for a in m.group(3).split(",")] if m.group(3).strip() else []
         named = ", ".join(f"{a} a{k}" for k, a in enumerate(args))

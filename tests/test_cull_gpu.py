@@ -481,3 +481,28 @@ def test_double_buffered_backward_tile_gives_the_single_buffered_bits(N, B, R, s
     assert same_bits(out["1"][0], out["0"][0]) and same_bits(out["1"][1], out["0"][1])
     assert same_bits(out["1"][0], out["1"][1])                      # (and the lists change no bit of either)
     assert torch.isfinite(out["1"][0]).all() and out["1"][0].abs().max().item() > 0
+
+
+@pytest.mark.parametrize("N,B,R", [(50, 7, 260), (96, 3, 512), (130, 4, 300), (192, 2, 132), (64, 5, 128), (40, 9, 100),
+                                   (33, 2, 129)])
+def test_64_ray_tiles_give_the_256_ray_tiles_bits(N, B, R):
+    """Backward variant 12 (round 4: splat_bwd_mfma_both<…, WR = 1>, the LDS-tile kernel in 64-ray tiles — what the rules
+    choose for fields of 33–192 heliostats on large or many images) against variant 2: a ray's chain over the contracted
+    axis does not know how many rays share its tile — the same bits, with 256- and 128-wide c tiles, 16-byte and dword
+    staging (R % 4 != 0), ragged last tiles and chunks."""
+    from doodle_amd import native
+    ops = native.get_ops()
+    f, suns, act, rays = field_and_rays(N, B, R, 0.02, 40.0, seed=N + R, span=20.0)
+    G = torch.randn(B, R, R, device=DEV, generator=torch.Generator(device=DEV).manual_seed(N))
+    a = ops.splat_bwd(rays, f._xs, f._ys, G, variant=12, cull=False)
+    b = ops.splat_bwd(rays, f._xs, f._ys, G, variant=2, cull=False)
+    torch.cuda.synchronize()
+    assert same_bits(a, b) and torch.isfinite(a).all() and a.abs().max().item() > 0
+
+
+def test_the_rules_take_the_64_ray_tiles_where_they_were_measured_ahead():
+    from doodle_amd import native
+    ops = native.get_ops()
+    assert [ops.render_bwd_choice(*s) for s in ((256, 50, 512), (500, 128, 512), (256, 128, 256), (500, 50, 128), (60, 192, 256))] == [12] * 5
+    # … and not with four tiles, few workgroups, a field of one ray block, or 64-pixel images
+    assert 12 not in [ops.render_bwd_choice(*s) for s in ((256, 200, 256), (60, 50, 256), (256, 50, 128), (500, 16, 256), (500, 50, 64))]

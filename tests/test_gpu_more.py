@@ -65,8 +65,9 @@ def test_odd_sizes_against_oracle(N, B, R, normal):
         assert np.array_equal(actual.detach().cpu().numpy(), actual_o.detach().numpy())
         assert np.array_equal(refl.detach().cpu().numpy(), refl_o.detach().numpy())
         np.testing.assert_allclose(img.detach().cpu().numpy(), img_o.detach().numpy(), rtol=1e-5, atol=1e-8)
-    # every backward kernel (8: moments + geometry adjoint in one launch; 9 / 10 / 11: the forms of the small-tile kernel)
-    for bwd_variant in (1, 2, 3, 4, 5, 6, 7, 9, 10, 11) + ((8,) if R <= 256 else ()):
+    # every backward kernel (8: moments + geometry adjoint in one launch; 9 / 10 / 11: the forms of the small-tile kernel;
+    # 12: the LDS-tile kernel in 64-ray tiles)
+    for bwd_variant in (1, 2, 3, 4, 5, 6, 7, 9, 10, 11, 12) + ((8,) if R <= 256 else ()):
         native.get_ops().bwd_variant = bwd_variant
         try:
             (grad,) = torch.autograd.grad((img * G.to(DEV)).sum() + (actual * H.to(DEV)).sum(), a_dev, retain_graph=True)

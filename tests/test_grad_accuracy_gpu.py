@@ -30,7 +30,7 @@ def _render_truth(name):
     return gf.render_truth(golden(name))
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12])
 @pytest.mark.parametrize("name", render_fixture_names())
 def test_render_gradient_is_as_accurate_as_the_reference(name, variant):
     g = golden(name)

@@ -80,7 +80,7 @@ def test_ray_parameters_match_reference_intersections(name):
     assert np.array_equal(rays[:, 2] > 0, mask > 0)
 
 
-@pytest.mark.parametrize("bwd_variant", [1, 2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("bwd_variant", [1, 2, 3, 4, 5, 6, 7, 8, 12])
 @pytest.mark.parametrize("name", NAMES)
 def test_backward_matches_reference_autograd(name, bwd_variant, monkeypatch):
     from doodle_amd import native

@@ -27,7 +27,7 @@ ops = native.get_ops()
 WALL_SIZES = {(25, 50, 128), (1, 50, 128), (4, 8, 128), (60, 32, 128), (4, 200, 100), (25, 8, 100)}
 FWD = (1, 3, 4, 5, 6, 9, 10, 11, 12, 13, 14, 15, 16, 17)
 FWD_OPT_IN = (7, 8)
-BWD = (1, 2, 4, 6, 7, 8, 9, 10, 11)
+BWD = (1, 2, 4, 6, 7, 8, 9, 10, 11, 12)
 BWD_OPT_IN = (5,)
 
 
