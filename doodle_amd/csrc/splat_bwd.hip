@@ -950,10 +950,31 @@ bool splat_bwd_is_few(int B, int N, int R);
 // N = 50, R = 256: 32 against 22 µs for the small-tile kernel), more of them being needed where the contracted axis is
 // short (R <= 128: a workgroup is eight 16-deep chunks).  Same bits as variant 2: a ray's chain over the contracted axis
 // does not know how many rays share its tile.
+// Larger fields (second table, tools/check_v12.py wide → profiles/r04_m_bwd_tile64_wide.txt, and the rule table with variant 12
+// in it): the 64-ray tiles also win wherever the 256-ray tiles (a) pad the field — N = 260 is two of them, 49 % empty, or
+// one and a 128-ray last tile where the lists split the tails — or (b) leave the chip partly idle: B = 4, N = 5000,
+// R = 512 is 320 workgroups for 256 CUs, a second round a quarter full (260 → 202 µs); B = 500, N = 260…640, R = 128:
+// 212…316 → 125…246 µs; B = 128, N = 300, R = 256: 162 → 111.  A model of both kernels' time in ray SLOTS per image —
+// the 256-ray tiles' with their tail form, the 64-ray tiles' × 1.05 (their slab is staged four times as often) — each
+// divided by how full its last round of workgroups leaves the chip (256 resp. 768 at a time; a partly filled round
+// counted at 30 % of what it leaves idle) lands within 3 % of the better kernel in 236 of 242 measured sizes, the worst miss 11 %
+// (B = 32, N = 5000, R = 128: the model sees two equal kernels, the 64-ray tiles are ahead).  They need more
+// workgroups where the contracted axis is short (R <= 128: 1280; else 384).
 static bool bwd_tile64(int B, int N, int R) {
-    if (N <= 32 || N > 192 || R <= 64) return false;
-    const long wgs = 2l * ((R + (R <= 128 ? 127 : 255)) / (R <= 128 ? 128 : 256)) * ((N + 63) / 64) * B;
-    return wgs >= (R <= 128 ? 800 : 240);
+    if (N <= 32 || R <= 64) return false;
+    const int ct = (R + (R <= 128 ? 127 : 255)) / (R <= 128 ? 128 : 256);
+    const long wg64 = 2l * ct * ((N + 63) / 64) * B, wg256 = 2l * ct * ((N + 255) / 256) * B;
+    if (N <= 192) return wg64 >= (R <= 128 ? 800 : 240);
+    if (wg64 < (R <= 128 ? 1280 : 384)) return false;
+    const bool tails = R > 128 && 2l * B * ct >= 512;            // bwd_split_tails: a last tile of at most 128 rays in the 128-ray form
+    const int rem = N % 256;
+    const double s256 = tails ? 256.0 * (N / 256) + (rem == 0 ? 0.0 : rem <= 128 ? 134.0 : 256.0) : 256.0 * ((N + 255) / 256);
+    const double s64 = 64.0 * ((N + 63) / 64) * 1.05;
+    auto fill = [](long wgs, long at_a_time) {
+        const double rounds = (double)wgs / at_a_time, whole = (double)((wgs + at_a_time - 1) / at_a_time);
+        return 1.0 - 0.3 * (1.0 - rounds / whole);
+    };
+    return s64 / fill(wg64, 768) < s256 / fill(wg256, 256);
 }
 
 template <int CT>
@@ -1144,6 +1165,11 @@ static void launch_bwd_mfma_both(int B, int N, int R, const float* rays, const f
     if (two_launches) {
         launch_bwd_mfma<0>(B, N, R, rays, xs, ys, gimg, moments, st, cull);
         launch_bwd_mfma<1>(B, N, R, rays, xs, ys, gimg, moments, st, cull);
+    } else if (R <= 128 && !cull.counts && [] { const char* e = getenv("HELIO_BWD_WR2"); return e && e[0] == '1'; }()) {
+        // experiment (round 4): 128 c × 128 rays, 4 waves, 34 KB of LDS — several workgroups per CU, each in another's
+        // producer phase — over EVERY tile of a dense launch
+        if (vec) launch_bwd_mfma_both_v<true, 2, 2>(B, N, R, rays, xs, ys, gimg, moments, st, cull);
+        else launch_bwd_mfma_both_v<false, 2, 2>(B, N, R, rays, xs, ys, gimg, moments, st, cull);
     } else if (R <= 128) {
         // 128-wide c tiles: one 8-wave workgroup per CU either way (101 KB of LDS), so pass 0 loses nothing by running
         // at pass 1's register count

@@ -468,6 +468,9 @@ static bool launch_ksplit(int B, int N, int R, const float* rays, const float* x
 //     per-pixel operand reads (lanes ↔ rows) are both bank-conflict free.
 //   consumer phase — 32 k-pairs × 4 MFMAs per wave, fully unrolled; operands are ds_read_b32
 //     from four base registers + 16-bit immediates (no VALU instruction in the loop).
+#ifndef HELIO_FWD_LAST_GROUP
+#define HELIO_FWD_LAST_GROUP 16        // rays per group of the consumer loop (A/B builds: 8, 16, 64 = no groups)
+#endif
 template <int W, bool TWO_LEVEL>
 __global__ void __launch_bounds__(64 * W * W)
 splat_fwd_mfma_tile(int B, int Nall, int R, const float* __restrict__ rays, const float* __restrict__ xs,
@@ -595,14 +598,27 @@ splat_fwd_mfma_tile(int B, int Nall, int R, const float* __restrict__ rays, cons
             }
         }
         __syncthreads();
+        // the short last chunk: its padded rays have A = 0 exactly and add +0 to sums that are never negative, so the
+        // k-pairs made of padding alone are left out — GRP rays at a time, a scalar compare and branch between the groups
+        // of the unrolled chunk — and the bits stay.  Measured (tools/ab_fwd_last.sh, profiles/r04_m_fwd_last_chunk.txt; GRP =
+        // 64, i.e. every chunk whole as before round 4 / 8 / 16): config 4 (N = 2000: 16 rays in its last chunk) dense
+        // 3926 / 3857 / 3826 µs, with the lists (half a chunk saved per list) 1986 / 1941 / 1938; B = 256, N = 200, R = 512:
+        // 281 / 236 / 241; B = 500, N = 200, R = 256: 147 / 126 / 126.  The groups cost a whole chunk nothing (the operand
+        // reads of a group are issued together at its head; the other waves of the SIMD cover them).
+        constexpr int GRP = HELIO_FWD_LAST_GROUP;
+        const int steps = __builtin_amdgcn_readfirstlane(min(NC / GRP, (N - n0 + GRP - 1) / GRP));
 #pragma unroll
-        for (int kp = 0; kp < NC / 2; ++kp) {
-            const float a0 = pa[kp * 2 * LD], a1 = pa1[kp * 2 * LD];
-            const float e0 = pe[kp * 2 * LD], e1 = pe1[kp * 2 * LD];
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, e0, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, e1, acc[1], 0, 0, 0);
-            acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, e0, acc[2], 0, 0, 0);
-            acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, e1, acc[3], 0, 0, 0);
+        for (int s8 = 0; s8 < NC / GRP; ++s8) {
+            if (s8 > 0 && s8 >= steps) break;
+#pragma unroll
+            for (int kp = GRP / 2 * s8; kp < GRP / 2 * (s8 + 1); ++kp) {
+                const float a0 = pa[kp * 2 * LD], a1 = pa1[kp * 2 * LD];
+                const float e0 = pe[kp * 2 * LD], e1 = pe1[kp * 2 * LD];
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, e0, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, e1, acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, e0, acc[2], 0, 0, 0);
+                acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, e1, acc[3], 0, 0, 0);
+            }
         }
         if (TWO_LEVEL) {
 #pragma unroll

@@ -484,7 +484,7 @@ def test_double_buffered_backward_tile_gives_the_single_buffered_bits(N, B, R, s
 
 
 @pytest.mark.parametrize("N,B,R", [(50, 7, 260), (96, 3, 512), (130, 4, 300), (192, 2, 132), (64, 5, 128), (40, 9, 100),
-                                   (33, 2, 129)])
+                                   (33, 2, 129), (300, 3, 128), (577, 2, 256), (1000, 2, 130)])
 def test_64_ray_tiles_give_the_256_ray_tiles_bits(N, B, R):
     """Backward variant 12 (round 4: splat_bwd_mfma_both<…, WR = 1>, the LDS-tile kernel in 64-ray tiles — what the rules
     choose for fields of 33–192 heliostats on large or many images) against variant 2: a ray's chain over the contracted
@@ -506,3 +506,28 @@ def test_the_rules_take_the_64_ray_tiles_where_they_were_measured_ahead():
     assert [ops.render_bwd_choice(*s) for s in ((256, 50, 512), (500, 128, 512), (256, 128, 256), (500, 50, 128), (60, 192, 256))] == [12] * 5
     # … and not with four tiles, few workgroups, a field of one ray block, or 64-pixel images
     assert 12 not in [ops.render_bwd_choice(*s) for s in ((256, 200, 256), (60, 50, 256), (256, 50, 128), (500, 16, 256), (500, 50, 64))]
+    # larger fields: where the 256-ray tiles pad the field or leave the chip partly idle (profiles/r04_m_bwd_tile64_wide.txt) …
+    assert [ops.render_bwd_choice(*s) for s in ((500, 300, 128), (128, 300, 256), (4, 5000, 512), (32, 576, 512), (500, 640, 128))] == [12] * 5
+    # … not where they fit (one and a half tiles with the 128-ray tail form, one exact round of workgroups, the configs of the bench)
+    assert 12 not in [ops.render_bwd_choice(*s) for s in ((500, 384, 256), (32, 448, 512), (32, 300, 128), (256, 1000, 256), (512, 2000, 512),
+                                                           (512, 5000, 256))]
+
+
+@pytest.mark.parametrize("variant", [4, 5])
+@pytest.mark.parametrize("N", [1, 7, 8, 9, 57, 64, 65, 72, 200, 449])
+def test_the_short_last_chunk_of_the_table_kernels_gives_the_full_chunk_s_bits(N, variant):
+    """The LDS-table forward kernels (variants 4, 5 and the split forms 14–17, one template) leave out the k-pairs of the
+    last 64-ray chunk that are padding alone, 8 rays at a time (round 4).  The same launch with the rays padded BY THE
+    CALLER to a whole chunk — with rays whose row factor is exactly zero, as the kernel's own padding — runs the full
+    chunk: the images are the same bits."""
+    from doodle_amd import native
+    ops = native.get_ops()
+    B, R = 3, 256
+    f, suns, act, rays = field_and_rays(N, B, R, 0.02, 40.0, seed=N, span=20.0)
+    padded = torch.zeros(B, (N + 63) // 64 * 64, 4, device=DEV)
+    padded[..., 2], padded[..., 3] = 1.0, 1e30
+    padded[:, :N] = rays
+    a = ops.splat_fwd(rays, f._xs, f._ys, variant=variant, cull=False)
+    b = ops.splat_fwd(padded.contiguous(), f._xs, f._ys, variant=variant, cull=False)
+    torch.cuda.synchronize()
+    assert same_bits(a, b) and torch.isfinite(a).all() and a.max().item() > 0
