@@ -59,7 +59,7 @@ __device__ __forceinline__ bool cull_dead_strict(const float4 ray, const CullBox
 // forward:  int counts[T] | int order[T] | float4 lists[T][P]          T = B·tiles²·S, tile = TE×TE pixels;
 //           S = 1, P = N normally; with the heliostat sum split across workgroups (splat_fwd.hip, "split"),
 //           S parts of P consecutive rays each and one list per (image, tile, part)
-// backward: int counts[T] | int idx[T][N] | int total[sets], tail_total[sets] (256 bytes) | int2 map[T·⌈N/256⌉] |
+// backward: int counts[T] | int idx[T][N] | int total[sets], tail_total[sets] (256 bytes) | int2 map[T·⌈N/tile_rays⌉] |
 //           int2 tail_map[T]     T = sets·B·CT lists:
 //           CT = 1: one list per image, shared by the two passes (sets = 1); CT > 1: one list per (pass, image,
 //           c tile) of the LDS-tile kernels (sets = 2), list = (pass·B + b)·CT + tile.  tail_map: the LAST tile of a
@@ -71,11 +71,11 @@ inline long cull_fwd_bytes(int B, int N, int R, int TE, int S = 1, int P = 0) {
     const long t = (R + TE - 1) / TE, T = (long)B * t * t * S;
     return 2 * cull_pad256(4 * T) + 16 * T * (S > 1 ? P : N);
 }
-constexpr int CULL_BWD_TILE = 256;           // rays per tile of splat_bwd_mfma
+constexpr int CULL_BWD_TILE = 256;           // rays per tile of splat_bwd_mfma (64 in its 64-ray form: the map counts tiles of `tile_rays`)
 constexpr int CULL_BWD_MAX_CT = 8;           // c tiles per image that get lists of their own (R ≤ 2048)
 inline long cull_bwd_lists(int B, int CT) { return (long)B * CT * (CT > 1 ? 2 : 1); }
-inline long cull_bwd_bytes(int B, int N, int CT = 1) {
-    const long nt = (N + CULL_BWD_TILE - 1) / CULL_BWD_TILE, T = cull_bwd_lists(B, CT);
+inline long cull_bwd_bytes(int B, int N, int CT = 1, int tile_rays = CULL_BWD_TILE) {
+    const long nt = (N + tile_rays - 1) / tile_rays, T = cull_bwd_lists(B, CT);
     return cull_pad256(4 * T) + cull_pad256(4 * T * N) + 256 + 8 * T * nt + 8 * T;
 }
 
@@ -94,9 +94,9 @@ struct CullBwd {
 // launchers (cull.hip)
 CullFwd launch_cull_fwd(int B, int N, int R, int TE, int S, int P, bool with_order, const float* rays, const float* xs,
                         const float* ys, void* scratch, hipStream_t st);
-// TC: width of a c tile in pixels, CT = ⌈R/TC⌉ or 1
+// TC: width of a c tile in pixels, CT = ⌈R/TC⌉ or 1; tile_rays: rays per item of the map (256; 64 for the 64-ray tiles, no tails)
 CullBwd launch_cull_bwd(int B, int N, int R, int JB, int TC, int CT, bool with_map, bool split_tails, const float* rays, const float* xs,
-                        const float* ys, float* moments, void* scratch, hipStream_t st);
+                        const float* ys, float* moments, void* scratch, hipStream_t st, int tile_rays = CULL_BWD_TILE);
 bool cull_enabled();
 
 }  // namespace helio

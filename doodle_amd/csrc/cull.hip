@@ -189,7 +189,7 @@ cull_order_fwd_kernel(int T, int N, const int* __restrict__ counts, int* __restr
 // many.  With split_tails the last tile of a list goes to tail_map[] instead when it holds at most 128 rays.
 // grid (sets): one workgroup per set of `lists` lists.
 __global__ void __launch_bounds__(ORDER_THREADS)
-cull_map_bwd_kernel(int lists, int nt, int split_tails, const int* __restrict__ counts, int* __restrict__ total_out,
+cull_map_bwd_kernel(int lists, int nt, int split_tails, int tile_rays, const int* __restrict__ counts, int* __restrict__ total_out,
                     int2* __restrict__ map, int* __restrict__ tail_total_out, int2* __restrict__ tail_map) {
     __shared__ int sw[ORDER_WAVES];
     counts += (long)blockIdx.x * lists;
@@ -199,8 +199,8 @@ cull_map_bwd_kernel(int lists, int nt, int split_tails, const int* __restrict__ 
     for (int l0 = 0; l0 < lists; l0 += ORDER_THREADS) {
         const int l = l0 + (int)threadIdx.x;
         const int c = l < lists ? counts[l] : 0;
-        const int t = (c + CULL_BWD_TILE - 1) / CULL_BWD_TILE;
-        const int tail = split_tails && t > 0 && c - (t - 1) * CULL_BWD_TILE <= CULL_BWD_TILE / 2;
+        const int t = (c + tile_rays - 1) / tile_rays;
+        const int tail = split_tails && t > 0 && c - (t - 1) * tile_rays <= tile_rays / 2;
         const int tf = t - tail;
         int total;
         const int start = running + block_scan_incl(tf, sw, total) - tf;
@@ -236,9 +236,9 @@ CullFwd launch_cull_fwd(int B, int N, int R, int TE, int S, int P, bool with_ord
 }
 
 CullBwd launch_cull_bwd(int B, int N, int R, int JB, int TC, int CT, bool with_map, bool split_tails, const float* rays, const float* xs,
-                        const float* ys, float* moments, void* scratch, hipStream_t st) {
+                        const float* ys, float* moments, void* scratch, hipStream_t st, int tile_rays) {
     const int sets = CT > 1 ? 2 : 1;
-    const long T = cull_bwd_lists(B, CT), nt = (N + CULL_BWD_TILE - 1) / CULL_BWD_TILE;
+    const long T = cull_bwd_lists(B, CT), nt = (N + tile_rays - 1) / tile_rays;
     char* base = static_cast<char*>(scratch);
     int* counts = reinterpret_cast<int*>(base);
     int* idx = reinterpret_cast<int*>(base + cull_pad256(4 * T));
@@ -256,7 +256,7 @@ CullBwd launch_cull_bwd(int B, int N, int R, int JB, int TC, int CT, bool with_m
     int* tail_total = total + 8;
     int2* tail_map = map + T * nt;
     if (with_map)
-        hipLaunchKernelGGL(cull_map_bwd_kernel, dim3(sets), dim3(ORDER_THREADS), 0, st, (int)(T / sets), (int)nt, (int)split_tails, counts,
+        hipLaunchKernelGGL(cull_map_bwd_kernel, dim3(sets), dim3(ORDER_THREADS), 0, st, (int)(T / sets), (int)nt, (int)split_tails, tile_rays, counts,
                            total, map, tail_total, tail_map);
     const bool tails = with_map && split_tails;
     return CullBwd{counts, idx, total, map, tails ? tail_total : nullptr, tails ? tail_map : nullptr, CT, T / sets, T / sets * nt, N};

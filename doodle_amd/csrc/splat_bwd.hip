@@ -950,16 +950,30 @@ bool splat_bwd_is_few(int B, int N, int R);
 // N = 50, R = 256: 32 against 22 µs for the small-tile kernel), more of them being needed where the contracted axis is
 // short (R <= 128: a workgroup is eight 16-deep chunks).  Same bits as variant 2: a ray's chain over the contracted axis
 // does not know how many rays share its tile.
-// Larger fields (second table, tools/check_v12.py wide → profiles/r04_m_bwd_tile64_wide.txt, and the rule table with variant 12
-// in it): the 64-ray tiles also win wherever the 256-ray tiles (a) pad the field — N = 260 is two of them, 49 % empty, or
-// one and a 128-ray last tile where the lists split the tails — or (b) leave the chip partly idle: B = 4, N = 5000,
-// R = 512 is 320 workgroups for 256 CUs, a second round a quarter full (260 → 202 µs); B = 500, N = 260…640, R = 128:
-// 212…316 → 125…246 µs; B = 128, N = 300, R = 256: 162 → 111.  A model of both kernels' time in ray SLOTS per image —
-// the 256-ray tiles' with their tail form, the 64-ray tiles' × 1.05 (their slab is staged four times as often) — each
-// divided by how full its last round of workgroups leaves the chip (256 resp. 768 at a time; a partly filled round
-// counted at 30 % of what it leaves idle) lands within 3 % of the better kernel in 236 of 242 measured sizes, the worst miss 11 %
-// (B = 32, N = 5000, R = 128: the model sees two equal kernels, the 64-ray tiles are ahead).  They need more
-// workgroups where the contracted axis is short (R <= 128: 1280; else 384).
+// Larger fields (tools/check_v12.py wide → profiles/r04_m_bwd_tile64_wide.txt, r04_o_bwd_tile64_wide_err90.txt / _err40.txt, and
+// the rule table with variant 12 in it): the 64-ray tiles also win wherever the 256-ray tiles (a) pad the field — N = 260
+// is two of them, 49 % empty, or one and a 128-ray last tile where the lists split the tails — or (b) leave the chip
+// partly idle: B = 4, N = 5000, R = 512 is 320 workgroups for 256 CUs, a second round a quarter full (260 → 202 µs);
+// B = 500, N = 260…640, R = 128: 212…316 → 125…246 µs; B = 128, N = 300, R = 256: 162 → 111.  From N = 257 they walk the
+// same lists as the 256-ray tiles (the work map in tiles of 64): at err 90 mrad / σs 0.01 B = 128, N = 260, R = 512:
+// 425 → 252 µs; B = 500, N = 520, R = 256: 509 → 468.  The rule is a model of both kernels' time in ray SLOTS per image —
+// the 256-ray tiles' with their tail form against the 64-ray tiles' — each divided by how full its last round of
+// workgroups leaves the chip (256 resp. 768 at a time; a partly filled round counted at 30 % of what it leaves idle).
+// Without lists the slots are the field's, padded to whole tiles (a slot of the 64-ray tiles 5 % dearer: their slab is
+// staged four times as often).  With lists — which both tilings walk where they pay — the length of a list is not known
+// when the kernel is chosen: the EXPECTED padding is what counts, half a last tile (32 rays against 96 with the
+// 128-ray tail form, 128 without), the 64-ray slot 8 % dearer: the fine tiles up to N ≈ 770 resp. 1170, the
+// 256-ray tiles beyond (configs 4 and 5 stay with them: 2–4 % ahead there).  Against three measured tables (every ray
+// live, rules of that moment; every ray live / err 90 mrad, σs 0.01 with lists on both sides: 242 + 62 + 62 sizes) the worst
+// misses are 11 %, 8 % and 19 % — the last where the LIVE rays of a 260-heliostat field fit one 256-ray tile, which no
+// rule made before the lists exist can know.  More workgroups are needed where the contracted axis is short
+// (R <= 128: 1280; else 384).
+// (the 64-ray tiles take lists where they are more than one round of the chip — three workgroups per CU — and the
+// footprint work carries the three launches in front: ≈20 µs, 5–17 % of a call with every ray live)
+static bool tile64_lists_pay(int B, int N, int R) {
+    const int ct = (R + (R <= 128 ? 127 : 255)) / (R <= 128 ? 128 : 256);
+    return N > 256 && 2l * ct * ((N + 63) / 64) * B > 768 && (long)B * N * R * R >= (1l << 31);
+}
 static bool bwd_tile64(int B, int N, int R) {
     if (N <= 32 || R <= 64) return false;
     const int ct = (R + (R <= 128 ? 127 : 255)) / (R <= 128 ? 128 : 256);
@@ -968,8 +982,10 @@ static bool bwd_tile64(int B, int N, int R) {
     if (wg64 < (R <= 128 ? 1280 : 384)) return false;
     const bool tails = R > 128 && 2l * B * ct >= 512;            // bwd_split_tails: a last tile of at most 128 rays in the 128-ray form
     const int rem = N % 256;
-    const double s256 = tails ? 256.0 * (N / 256) + (rem == 0 ? 0.0 : rem <= 128 ? 134.0 : 256.0) : 256.0 * ((N + 255) / 256);
-    const double s64 = 64.0 * ((N + 63) / 64) * 1.05;
+    const bool lists = tile64_lists_pay(B, N, R);
+    const double s256 = lists ? N + (tails ? 96.0 : 128.0)
+                              : tails ? 256.0 * (N / 256) + (rem == 0 ? 0.0 : rem <= 128 ? 134.0 : 256.0) : 256.0 * ((N + 255) / 256);
+    const double s64 = lists ? (N + 32.0) * 1.08 : 64.0 * ((N + 63) / 64) * 1.05;
     auto fill = [](long wgs, long at_a_time) {
         const double rounds = (double)wgs / at_a_time, whole = (double)((wgs + at_a_time - 1) / at_a_time);
         return 1.0 - 0.3 * (1.0 - rounds / whole);
@@ -1127,6 +1143,10 @@ static void launch_bwd_mfma_both_v(int B, int N, int R, const float* rays, const
     if (WR == 4) {
         hipLaunchKernelGGL((splat_bwd_mfma_both<VEC, WC, WR, DB>), dim3(ct * nt, B, 2), dim3(64 * WC * WR), lds, st, B, N, R, rays, xs, ys, gimg,
                            moments, c.counts, c.idx, c.total, c.map, c.ct, c.set_lists, c.set_items, CULL_BWD_TILE);
+    } else if (WR == 1 && c.counts) {
+        // the 64-ray tiles over lists: the map (cull.hip) counts tiles of 64 rays, no tail form
+        hipLaunchKernelGGL((splat_bwd_mfma_both<VEC, WC, WR, DB>), dim3(ct * ((N + T - 1) / T), B, 2), dim3(64 * WC * WR), lds, st, B, N, R, rays, xs, ys, gimg,
+                           moments, c.counts, c.idx, c.total, c.map, c.ct, c.set_lists, c.set_items, T);
     } else if (!c.counts) {
         // dense launches of the narrow forms, tiles numbered in T rays: WR = 1 (variant 12) — and the HELIO_BWD_WR2
         // experiment, the 128-ray form over EVERY tile
@@ -1724,7 +1744,7 @@ static int resolve_bwd(int variant, int B, int N, int R) {
 static bool cull_bwd_possible(int variant, int B, int N, int R) {
     variant = resolve_bwd(variant, B, N, R);
     if (!cull_enabled() || N <= 256) return false;
-    return variant == 2 || variant == 9;
+    return variant == 2 || variant == 9 || variant == 12;
 }
 // … and it PAYS (what the size query answers: a caller that sizes its scratch by the query hands none otherwise)
 static bool cull_bwd_wanted(int variant, int B, int N, int R) {
@@ -1732,6 +1752,8 @@ static bool cull_bwd_wanted(int variant, int B, int N, int R) {
     if (!cull_bwd_possible(variant, B, N, R)) return false;
     const long ray_tiles = (N + 255) / 256;
     if (variant == 2) return 2l * B * ((R + (R <= 128 ? 127 : 255)) / (R <= 128 ? 128 : 256)) * ray_tiles > 256;   // (both passes are one launch)
+    // the 64-ray tiles: three workgroups per CU, and footprint work enough beside the three launches in front
+    if (variant == 12) return tile64_lists_pay(B, N, R);
     // (both passes in one launch; two 4-wave workgroups fit a CU; and enough footprint work for the ≈15 µs of the
     // launches in front to be small beside it — grid A/B at err 90 / σs 0.01: B = 32, N = 5000, R = 64, 45 µs dense:
     // 54 µs with lists; B = 4, N = 5000, R = 256, 85 µs: 72 µs; B = 256, N = 5000, R = 64, 325 µs: 271 µs)
@@ -1744,11 +1766,11 @@ static bool cull_bwd_wanted(int variant, int B, int N, int R) {
 static int cull_bwd_ct(int variant, int B, int N, int R) {
     variant = resolve_bwd(variant, B, N, R);
     const int c_tiles = (R + 255) / 256;
-    return variant == 2 && R > 128 && c_tiles > 1 && c_tiles <= CULL_BWD_MAX_CT ? c_tiles : 1;
+    return (variant == 2 || variant == 12) && R > 128 && c_tiles > 1 && c_tiles <= CULL_BWD_MAX_CT ? c_tiles : 1;
 }
 
 long splat_bwd_scratch_bytes(int B, int N, int R, int variant) {
-    return cull_bwd_wanted(variant, B, N, R) ? cull_bwd_bytes(B, N, cull_bwd_ct(variant, B, N, R)) : 0;
+    return cull_bwd_wanted(variant, B, N, R) ? cull_bwd_bytes(B, N, cull_bwd_ct(variant, B, N, R), resolve_bwd(variant, B, N, R) == 12 ? 64 : CULL_BWD_TILE) : 0;
 }
 
 int launch_splat_bwd(int B, int N, int R, const float* rays, const float* xs, const float* ys,
@@ -1803,13 +1825,20 @@ int launch_splat_bwd(int B, int N, int R, const float* rays, const float* xs, co
             hipLaunchKernelGGL(splat_bwd_mfma_small<4>, dim3(ct * nt, B, 2), dim3(256), 0, st, N, R, rays, xs, ys, gimg, moments, nullptr, nullptr);
         return HELIO_OK;
     }
-    if (variant == 12) {       // (round 4) the LDS-tile kernel in 64-ray tiles (256- or 128-wide c tiles), dense
+    if (variant == 12) {       // (round 4) the LDS-tile kernel in 64-ray tiles (256- or 128-wide c tiles); lists as variant 2's, their map in 64-ray tiles
+        CullBwd cull{};
+        if (scratch && cull_bwd_possible(12, B, N, R)) {
+            int ct = cull_bwd_ct(12, B, N, R);
+            if (scratch_bytes < cull_bwd_bytes(B, N, ct, 64)) ct = 1;
+            if (scratch_bytes >= cull_bwd_bytes(B, N, ct, 64))
+                cull = launch_cull_bwd(B, N, R, splat_bwd_blocks(R), R <= 128 ? 128 : 256, ct, /*with_map=*/true, false, rays, xs, ys, moments, scratch, st, 64);
+        }
         const bool vec = (R & 3) == 0;
         if (R <= 128) {
-            if (vec) launch_bwd_mfma_both_v<true, 2, 1>(B, N, R, rays, xs, ys, gimg, moments, st, CullBwd{});
-            else launch_bwd_mfma_both_v<false, 2, 1>(B, N, R, rays, xs, ys, gimg, moments, st, CullBwd{});
-        } else if (vec) launch_bwd_mfma_both_v<true, 4, 1>(B, N, R, rays, xs, ys, gimg, moments, st, CullBwd{});
-        else launch_bwd_mfma_both_v<false, 4, 1>(B, N, R, rays, xs, ys, gimg, moments, st, CullBwd{});
+            if (vec) launch_bwd_mfma_both_v<true, 2, 1>(B, N, R, rays, xs, ys, gimg, moments, st, cull);
+            else launch_bwd_mfma_both_v<false, 2, 1>(B, N, R, rays, xs, ys, gimg, moments, st, cull);
+        } else if (vec) launch_bwd_mfma_both_v<true, 4, 1>(B, N, R, rays, xs, ys, gimg, moments, st, cull);
+        else launch_bwd_mfma_both_v<false, 4, 1>(B, N, R, rays, xs, ys, gimg, moments, st, cull);
         return HELIO_OK;
     }
     if (variant == 2) {

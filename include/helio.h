@@ -210,8 +210,9 @@ int helio_splat_bwd_blocks(int R);
  * bf16 pieces, six partial products per product on the bf16 matrix pipe, f32 accumulation);
  * 6 / 7 = the small-tile kernel forced to 4 / 8 waves per workgroup and one ray block per wave (tests, tuning);
  * 9 / 10 / 11 = the forms 3 chooses between by size: contracted axis whole / cut between four / eight waves
- * (helio_render_bwd_choice); 12 = the LDS-tile kernels of 2 in 64-ray tiles (same bits as 2; what 0 chooses for fields
- * of 33..192 heliostats once images and batch give it a few hundred workgroups).
+ * (helio_render_bwd_choice); 12 = the LDS-tile kernels of 2 in 64-ray tiles (same bits as 2, lists as 2's; what 0 chooses
+ * for fields of 33..192 heliostats once images and batch give it a few hundred workgroups, and for larger fields where
+ * 256-ray tiles would pad the field or leave the chip partly idle).
  */
 int helio_splat_bwd(int B, int N, int R,
                     const float *rays_d, const float *xs_d, const float *ys_d,

@@ -48,14 +48,15 @@ def bwd_lists_per_image(R, variant):
     """Lists per image and pass (csrc/cull.h): the LDS-tile kernels get one per 256-wide c tile where an image is
     2..8 of them wide, one per image otherwise."""
     ct = -(-R // 256)
-    return ct if variant == 2 and R > 128 and 2 <= ct <= 8 else 1
+    return ct if variant in (2, 12) and R > 128 and 2 <= ct <= 8 else 1
 
 
 def bwd_scratch_need(B, N, R, variant, per_image=False):
     pad = lambda n: (n + 255) // 256 * 256      # noqa: E731  counts | idx | totals | map | tail map (csrc/cull.h)
     ct = 1 if per_image else bwd_lists_per_image(R, variant)
     T = B * ct * (2 if ct > 1 else 1)
-    return pad(4 * T) + pad(4 * T * N) + 256 + 8 * T * ((N + 255) // 256) + 8 * T, T
+    tile = 64 if variant == 12 else 256          # rays per item of the work map: variant 12 walks its lists in 64-ray tiles
+    return pad(4 * T) + pad(4 * T * N) + 256 + 8 * T * ((N + tile - 1) // tile) + 8 * T, T
 
 
 def splat_bwd_with_list(rays, xs, ys, G, variant, per_image=False):
@@ -198,6 +199,13 @@ def test_culled_backward_moments_equal_the_dense_ones_bit_for_bit(N, B, R, sigma
         assert int(counts.sum()) == counts.numel() * N
     for variant in (1, 3, 4, 5, 6, 7):
         assert ops.lib.helio_bwd_scratch_bytes(B, N, R, variant) == 0
+    # the 64-ray tiles (variant 12) over the same lists, their map in tiles of 64: the same bits again
+    culled12, counts12, need12 = splat_bwd_with_list(rays, f._xs, f._ys, G, 12)
+    assert ops.lib.helio_bwd_scratch_bytes(B, N, R, 12) in (0, need12) and ops.lib.helio_bwd_scratch_bytes(500, 520, 256, 12) > 0
+    assert same_bits(culled12, dense) and torch.equal(counts12, counts)
+    if bwd_lists_per_image(R, 12) > 1:
+        fallback12, _, _ = splat_bwd_with_list(rays, f._xs, f._ys, G, 12, per_image=True)
+        assert same_bits(fallback12, dense)
 
 
 def test_render_autograd_and_env_step_are_unchanged_by_the_culling():
@@ -450,7 +458,7 @@ def test_small_tile_backward_with_lists_equals_the_dense_one_bit_for_bit(N, B, R
 
 def test_fuzz_of_every_list_taking_kernel_against_its_dense_self():
     """tools/fuzz_cull.py: random shapes (odd sizes included), fields (sigma 0.002…0.1, err 0…400 mrad, tilted
-    receivers, spans 10…100 m) and cotangent scales; forward variants 3, 4, 5, 9, 14–17 and backward variants 2, 3
+    receivers, spans 10…100 m) and cotangent scales; forward variants 3, 4, 5, 9, 14–17 and backward variants 2, 3, 12
     with their lists against themselves without — any differing bit fails.  (300 cases were run once by hand:
     profiles/r03_e_fuzz_cull.txt; 30 here.)"""
     import os
@@ -507,10 +515,11 @@ def test_the_rules_take_the_64_ray_tiles_where_they_were_measured_ahead():
     # … and not with four tiles, few workgroups, a field of one ray block, or 64-pixel images
     assert 12 not in [ops.render_bwd_choice(*s) for s in ((256, 200, 256), (60, 50, 256), (256, 50, 128), (500, 16, 256), (500, 50, 64))]
     # larger fields: where the 256-ray tiles pad the field or leave the chip partly idle (profiles/r04_m_bwd_tile64_wide.txt) …
-    assert [ops.render_bwd_choice(*s) for s in ((500, 300, 128), (128, 300, 256), (4, 5000, 512), (32, 576, 512), (500, 640, 128))] == [12] * 5
-    # … not where they fit (one and a half tiles with the 128-ray tail form, one exact round of workgroups, the configs of the bench)
-    assert 12 not in [ops.render_bwd_choice(*s) for s in ((500, 384, 256), (32, 448, 512), (32, 300, 128), (256, 1000, 256), (512, 2000, 512),
-                                                           (512, 5000, 256))]
+    assert [ops.render_bwd_choice(*s) for s in ((500, 300, 128), (128, 300, 256), (4, 5000, 512), (32, 576, 512), (500, 640, 128),
+                                                (500, 384, 256))] == [12] * 6
+    # … not where they fit (one exact round of workgroups, too few workgroups, long lists — the configs of the bench)
+    assert 12 not in [ops.render_bwd_choice(*s) for s in ((32, 448, 512), (32, 300, 128), (256, 1000, 256), (512, 2000, 512), (512, 5000, 256),
+                                                           (4096, 5000, 256))]
 
 
 @pytest.mark.parametrize("variant", [4, 5])

@@ -86,7 +86,10 @@ def test_abi_rejects_bad_arguments_without_launching():
     # the small-tile kernel: lists only with footprint work enough to carry the launches in front of it
     assert lib.helio_bwd_scratch_bytes(32, 5000, 64, 0) == 0 and lib.helio_bwd_scratch_bytes(256, 5000, 64, 0) > 0
     # the LDS-tile kernels (both passes one launch): lists where that launch is more than one round of the chip
-    assert lib.helio_bwd_scratch_bytes(4, 5000, 256, 0) == 0 and lib.helio_bwd_scratch_bytes(4, 5000, 512, 0) > 0
+    assert lib.helio_bwd_scratch_bytes(4, 5000, 256, 0) == 0 and lib.helio_bwd_scratch_bytes(16, 5000, 512, 0) > 0
+    # … the 64-ray tiles (B = 4, N = 5000, R = 512 by the rules): lists per (pass, c tile), their map in tiles of 64 rays
+    assert lib.helio_render_bwd_choice(4, 5000, 512) == 12
+    assert lib.helio_bwd_scratch_bytes(4, 5000, 512, 0) == 256 + 4 * 16 * 5000 + 256 + 8 * 16 * 79 + 8 * 16
     assert lib.helio_bwd_scratch_bytes(512, 2000, 512, 5) == 0 and lib.helio_bwd_scratch_bytes(512, 200, 512, 0) == 0
     assert lib.helio_notify_wait(None, 1, 0.0) == -1 and lib.helio_notify_destroy(None) == 0
 
@@ -404,19 +407,20 @@ def test_library_switches_change_the_size_rules_they_name():
 
 def test_scratch_size_queries_are_consistent_over_random_sizes():
     """helio_*_scratch_bytes are host code: over random sizes they are never negative, the required part never exceeds
-    the whole, the backward size is 0 or exactly one of the two layouts of csrc/cull.h (one list per image; one per
-    (pass, 256-wide c tile) where an image is 2..8 tiles wide), and forcing a variant that takes no lists gives 0."""
+    the whole, the backward size is 0 or exactly one of the layouts of csrc/cull.h (one list per image; one per
+    (pass, 256-wide c tile) where an image is 2..8 tiles wide; either with its work map in tiles of 256 rays or — where the
+    rules take the 64-ray tiles — of 64), and forcing a variant that takes no lists gives 0."""
     import random
     from doodle_amd import native
     lib = native.load_library()
     rng = random.Random(7)
     pad = lambda n: (n + 255) // 256 * 256  # noqa: E731
 
-    def bwd_layout(B, N, lists_per_image, sets):
+    def bwd_layout(B, N, lists_per_image, sets, tile=256):
         T = B * lists_per_image * sets
-        return pad(4 * T) + pad(4 * T * N) + 256 + 8 * T * ((N + 255) // 256) + 8 * T
+        return pad(4 * T) + pad(4 * T * N) + 256 + 8 * T * ((N + tile - 1) // tile) + 8 * T
 
-    seen_lists = seen_ctile = 0
+    seen_lists = seen_ctile = seen_tile64 = 0
     for _ in range(3000):
         B = rng.choice([1, 2, 4, 7, 25, 32, 100, 256, 512, 4096])
         N = rng.choice([1, 50, 96, 200, 257, 300, 1000, 1024, 2000, 5000, 20000])
@@ -425,16 +429,18 @@ def test_scratch_size_queries_are_consistent_over_random_sizes():
         assert 0 <= req <= fwd and bwd >= 0 and fwd % 16 == 0
         if bwd:
             ct = -(-R // 256)
-            per_image, per_ctile = bwd_layout(B, N, 1, 1), bwd_layout(B, N, ct, 2)
+            tile = 64 if lib.helio_render_bwd_choice(B, N, R) == 12 else 256
+            per_image, per_ctile = bwd_layout(B, N, 1, 1, tile), bwd_layout(B, N, ct, 2, tile)
             assert bwd == per_image or (R > 128 and 2 <= ct <= 8 and bwd == per_ctile), (B, N, R, bwd)
             seen_lists += 1
             seen_ctile += bwd == per_ctile and ct > 1
+            seen_tile64 += tile == 64
             assert N > 256
         for v in (1, 4, 5, 6, 7, 8):
             assert lib.helio_bwd_scratch_bytes(B, N, R, v) == 0
         for v in (1, 6, 7, 8, 10, 11, 12, 13):
             assert lib.helio_fwd_scratch_bytes(B, N, R, v) == 0
-    assert seen_lists > 100 and seen_ctile > 20
+    assert seen_lists > 100 and seen_ctile > 20 and seen_tile64 > 5
 
 
 def test_receiver_attributes_are_live(monkeypatch):

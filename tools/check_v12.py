@@ -13,7 +13,7 @@ ops = native.get_ops()
 WIDE = len(sys.argv) > 1 and sys.argv[1] == "wide"        # fields just past one or two 256-ray tiles; column v8 is then variant 9
 SIGMA, ERR = (float(sys.argv[-2]), float(sys.argv[-1])) if len(sys.argv) > 2 else (0.02, 40.0)     # e.g. 0.01 90: the reference's defaults, where the lists bite
 print(f"# sigma_scale {SIGMA}, error_scale_mrad {ERR}")
-print(f"{'B':>4} {'N':>4} {'R':>4} | {'auto':>9} {'=v':>3} | {'v12':>9} {'v2':>9} {'v10':>9} {'v8':>9} | v12 == v2 bits")
+print(f"{'B':>4} {'N':>4} {'R':>4} | {'auto':>9} {'=v':>3} | {'v12':>9} {'v2':>9} {'v10':>9} {'v8':>9} | {'v12 dense':>9} {'v2 dense':>9} | v12 == v2 bits")
 OTHER = 9 if WIDE else 8
 for R in ((128, 256, 512) if WIDE else (100, 128, 256, 512)):
     for N in ((260, 300, 320, 384, 448, 520, 576, 640) if WIDE else (40, 50, 64, 96, 128, 200) if R <= 128 else (33, 160, 192)):
@@ -39,8 +39,12 @@ for R in ((128, 256, 512) if WIDE else (100, 128, 256, 512)):
                         res[v] = time_kernel(lambda: ops.render_bwd(hp, suns_d, normals, trig, stride, pl, rays, xs, ys, G, None, None, variant=v), 20, warm=3, repeats=3)
                     except RuntimeError:
                         res[v] = float("nan")
+                ops.cull = False                      # no scratch: the dense kernels
+                for v in (12, 2):
+                    res[f"{v}d"] = time_kernel(lambda: ops.render_bwd(hp, suns_d, normals, trig, stride, pl, rays, xs, ys, G, None, None, variant=v), 20, warm=3, repeats=3)
+                ops.cull = True
                 same = torch.equal(ops.splat_bwd(rays, xs, ys, G, variant=12, cull=False).view(torch.int32),
                                    ops.splat_bwd(rays, xs, ys, G, variant=2, cull=False).view(torch.int32))
-            print(f"{B:4d} {N:4d} {R:4d} | {res[0] * 1e6:9.1f} {ops.render_bwd_choice(B, N, R):3d} | {res[12] * 1e6:9.1f} {res[2] * 1e6:9.1f} {res[10] * 1e6:9.1f} {res[OTHER] * 1e6:9.1f} | {same}", flush=True)
+            print(f"{B:4d} {N:4d} {R:4d} | {res[0] * 1e6:9.1f} {ops.render_bwd_choice(B, N, R):3d} | {res[12] * 1e6:9.1f} {res[2] * 1e6:9.1f} {res[10] * 1e6:9.1f} {res[OTHER] * 1e6:9.1f} | {res['12d'] * 1e6:9.1f} {res['2d'] * 1e6:9.1f} | {same}", flush=True)
             del f, G, rays
             torch.cuda.empty_cache()

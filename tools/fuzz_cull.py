@@ -48,13 +48,14 @@ for case in range(cases):
             bad += 1
             print("DIFFERS forward variant", v, what, (dense - culled).abs().max().item(), flush=True)
     G = torch.randn(B, R, R, device=dev) * rng.choice([1e-6, 1.0, 1e6])
-    for v in (2, 3):
+    for v in (2, 3, 12):
         dense = ops.splat_bwd(rays, f._xs, f._ys, G, variant=v, cull=False)
         ct = -(-R // 256)
-        sizes = [(1, 1)] + ([(ct, 2)] if v == 2 and R > 128 and 2 <= ct <= 8 else [])     # one list per image; per (pass, c tile)
+        sizes = [(1, 1)] + ([(ct, 2)] if v in (2, 12) and R > 128 and 2 <= ct <= 8 else [])     # one list per image; per (pass, c tile)
+        tile = 64 if v == 12 else 256       # rays per item of the work map
         for lists_per_image, sets in sizes:
             T = B * lists_per_image * sets
-            need = pad(4 * T) + pad(4 * T * N) + 256 + 8 * T * ((N + 255) // 256) + 8 * T
+            need = pad(4 * T) + pad(4 * T * N) + 256 + 8 * T * ((N + tile - 1) // tile) + 8 * T
             scratch = torch.full((need,), 0x55, dtype=torch.uint8, device=dev)
             mom = torch.full_like(dense, float("nan"))
             rc = lib.helio_splat_bwd(B, N, R, rays.data_ptr(), f._xs.data_ptr(), f._ys.data_ptr(), G.data_ptr(), mom.data_ptr(), v,
