@@ -11,7 +11,7 @@ Times are DEVICE times: HIP events around an eager loop where a call takes longe
 HIP-graph replay of 20 back-to-back calls below that.  What the host pays per call (one launch or two) is not in them;
 the last section times config 3's forward + backward through the Python surface for the two backward forms it concerns.
 
-usage: rule_regret.py [quick] [out.txt]
+usage: rule_regret.py [quick] [err90] [out.txt]      (err90: err 90 mrad, sigma_scale 0.01 instead — the lists bite)
 """
 import os
 import sys
@@ -85,17 +85,20 @@ def timed(fn, flops):
 
 def main():
     quick = "quick" in sys.argv[1:]
-    outs = [a for a in sys.argv[1:] if a != "quick"]
+    culled = "err90" in sys.argv[1:]           # the reference's default error scale and sigma: the lists shorten the list-taking kernels' work
+    sigma, err = (0.01, 90.0) if culled else (0.02, 40.0)
+    outs = [a for a in sys.argv[1:] if a not in ("quick", "err90")]
     lines, rows, wall_jobs = [], [], []
 
     def emit(s):
         print(s, flush=True)
         lines.append(s)
 
+    emit(f"# err {err} mrad, sigma_scale {sigma}")
     emit(f"{'B':>4} {'N':>5} {'R':>4} | {'fwd auto':>9} {'=v':>3} {'best':>9} {'v':>3} {'regret':>7} | "
          f"{'bwd auto':>9} {'=v':>3} {'best':>9} {'v':>3} {'regret':>7}")
     for B, N, R in grid(quick):
-        w = synthetic.Workload("s", N=N, B=B, R=R, sigma_scale=0.02, error_scale_mrad=40.0, span=30.0 if N > 100 else 10.0)
+        w = synthetic.Workload("s", N=N, B=B, R=R, sigma_scale=sigma, error_scale_mrad=err, span=30.0 if N > 100 else 10.0)
         helios, suns, errs, noise = synthetic.make_inputs(w, 0)
         f = build_field(w, helios, errs, dev)
         suns_d = suns.to(dev)
