@@ -1623,17 +1623,31 @@ static int splat_fwd_choice(int B, int N, int R) {
     // the 256 CUs and the heliostat sum is long enough to amortise its 64-ray chunks; the 128²
     // register-operand kernel once ITS tiles fill the chip; below that, 32² blocks with the heliostat sum
     // split over the waves of a workgroup where it is long, else 64² tiles.
-    if (N >= 200 && R > 128 && t256 >= 192) return 5;
-    // between 24 and 192 such tiles — tens of images of a large field — the 256² kernel with the heliostat sum
-    // split across workgroups (variants 14..16, below): as many parts as fill the chip, while a part keeps at
-    // least 7 of the kernel's 64-ray chunks.  tools/sweep_split.py (profiles/r03_c_sweep_split.txt): B = 32,
-    // N = 5000, R = 256: 256 → 215 µs (k-split blocks before); B = 64: 464 → 371 µs (128² register tiles
-    // before); B = 16, N = 5000, R = 512: 458 → 357 µs.  HELIO_SPLIT=0 switches the choice off.
+    // (round 4) … from TWO rounds of the chip: 512 tiles.  Below that a partly filled round idles (B = 384, N = 5000, R = 256: 2416 µs
+    // against 1923 with the sum split in two) and — at the reference's default error scale, where the lists bite — the
+    // lists do not balance: every workgroup starts at once and the launch lasts as long as its longest list (B = 256,
+    // N = 5000, R = 256 at err 90 mrad / σs 0.01: 1050 µs, live fraction 0.60, against 822 for the 128² tiles, 0.50).
+    if (N >= 200 && R > 128 && t256 >= 512) return 5;
+    // between 24 and 512 such tiles — tens to hundreds of images of a large field — the 256² kernel with the heliostat sum
+    // split across workgroups (variants 14..17, below): as many parts as give 512 workgroups, while a part keeps at
+    // least 7 of the kernel's 64-ray chunks (16 where the unsplit kernel is the alternative).  tools/sweep_split.py
+    // (profiles/r03_c_sweep_split.txt): B = 32, N = 5000, R = 256: 256 → 215 µs (k-split blocks before); B = 64: 464 → 371 µs
+    // (128² register tiles before); B = 16, N = 5000, R = 512: 458 → 357 µs.  Round 4, both regimes side by side
+    // (tools/rule_regret.py sizes=… with and without err90, profiles/r04_x_split_both_regimes.txt): parts × tiles ≥ 512
+    // instead of ≥ 192 costs 2–7 % with every ray live and gains 12–22 % at err 90 (B = 128, N = 5000, R = 256: 565 → 463 µs;
+    // B = 32, N = 5000, R = 512: 470 → 386); where parts that short are not to be had and the 128² tiles fill the chip,
+    // those (B = 32, N = 1000, R = 512 at err 90: 126 → 101 µs).  HELIO_SPLIT=0 switches the choice off.
     static const bool no_split = [] { const char* e = getenv("HELIO_SPLIT"); return e && e[0] == '0'; }();
-    if (!no_split && R > 128 && t256 >= 24) {
-        const int S = t256 >= 96 ? 2 : t256 >= 48 ? 4 : 8;
-        if (N / S >= 448) return S == 2 ? 14 : S == 4 ? 15 : 16;
+    if (!no_split && R > 128 && t256 >= 24 && t256 < 512) {
+        int want = 2;
+        while (t256 * want < 512 && want < 16) want *= 2;
+        const int min_part = t256 >= 192 ? 1000 : 448;
+        int S = want;
+        while (S >= 2 && N / S < min_part) S /= 2;
+        if (S >= 2 && (S == want || t128 < 192 || R <= 64))
+            return S == 2 ? 14 : S == 4 ? 15 : S == 8 ? 16 : 17;
     }
+    if (N >= 200 && R > 128 && t256 >= 192) return 5;
     if (t128 >= 192 && R > 64) return 3;
     return ksplit_parts(B, N, R) ? 9 : 6;
 }

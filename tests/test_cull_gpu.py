@@ -540,3 +540,6 @@ def test_the_short_last_chunk_of_the_table_kernels_gives_the_full_chunk_s_bits(N
     b = ops.splat_fwd(padded.contiguous(), f._xs, f._ys, variant=variant, cull=False)
     torch.cuda.synchronize()
     assert same_bits(a, b) and torch.isfinite(a).all() and a.max().item() > 0
+    # the two table kernels sum an image's rays in the same order, pair by pair, whatever their tile and chunk (256² tiles of
+    # 64-ray chunks; 128² tiles of 32-ray chunks since round 4): one image, bit for bit
+    assert same_bits(a, ops.splat_fwd(rays, f._xs, f._ys, variant=9 - variant, cull=False))

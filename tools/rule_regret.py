@@ -11,7 +11,7 @@ Times are DEVICE times: HIP events around an eager loop where a call takes longe
 HIP-graph replay of 20 back-to-back calls below that.  What the host pays per call (one launch or two) is not in them;
 the last section times config 3's forward + backward through the Python surface for the two backward forms it concerns.
 
-usage: rule_regret.py [quick] [err90] [out.txt]      (err90: err 90 mrad, sigma_scale 0.01 instead — the lists bite)
+usage: rule_regret.py [quick] [err90] [sizes=B,N,R;B,N,R…] [out.txt]      (err90: err 90 mrad, sigma_scale 0.01 instead — the lists bite)
 """
 import os
 import sys
@@ -87,7 +87,8 @@ def main():
     quick = "quick" in sys.argv[1:]
     culled = "err90" in sys.argv[1:]           # the reference's default error scale and sigma: the lists shorten the list-taking kernels' work
     sigma, err = (0.01, 90.0) if culled else (0.02, 40.0)
-    outs = [a for a in sys.argv[1:] if a not in ("quick", "err90")]
+    custom = [a for a in sys.argv[1:] if a.startswith("sizes=")]       # sizes=B,N,R;B,N,R…: these sizes instead of the grid
+    outs = [a for a in sys.argv[1:] if a not in ("quick", "err90") and not a.startswith("sizes=")]
     lines, rows, wall_jobs = [], [], []
 
     def emit(s):
@@ -97,7 +98,8 @@ def main():
     emit(f"# err {err} mrad, sigma_scale {sigma}")
     emit(f"{'B':>4} {'N':>5} {'R':>4} | {'fwd auto':>9} {'=v':>3} {'best':>9} {'v':>3} {'regret':>7} | "
          f"{'bwd auto':>9} {'=v':>3} {'best':>9} {'v':>3} {'regret':>7}")
-    for B, N, R in grid(quick):
+    sizes = [tuple(int(x) for x in t.split(",")) for t in custom[0][6:].split(";")] if custom else grid(quick)
+    for B, N, R in sizes:
         w = synthetic.Workload("s", N=N, B=B, R=R, sigma_scale=sigma, error_scale_mrad=err, span=30.0 if N > 100 else 10.0)
         helios, suns, errs, noise = synthetic.make_inputs(w, 0)
         f = build_field(w, helios, errs, dev)
