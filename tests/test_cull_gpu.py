@@ -359,8 +359,9 @@ def test_split_heliostat_sum_variants(N, B, R, sigma, err):
     from test_gpu_more import make_case
     ops = native.get_ops()
     # what the size rule hands them: tens of images of a large field
-    assert [ops.render_choice(b, 5000, 256) for b in (16, 32, 64, 128, 256)] == [9, 16, 15, 14, 5]
-    assert ops.render_choice(16, 2000, 512) == 15 and ops.render_choice(32, 2000, 256) == 9
+    # (round 4: as many parts as give 512 workgroups — the lists of fewer do not balance —, the unsplit kernel from 512 tiles)
+    assert [ops.render_choice(b, 5000, 256) for b in (16, 32, 64, 128, 256, 512)] == [9, 16, 16, 15, 14, 5]
+    assert ops.render_choice(32, 2000, 512) == 15 and ops.render_choice(32, 2000, 256) == 9 and ops.render_choice(32, 1000, 256) == 9
     f, sc, suns, errs, act = make_case(N, B, R, sigma=sigma, err=err, seed=N + R + 3, span=30.0)
     s_dev = suns.to(DEV)
     normals = act.to(DEV).reshape(B, N, 3).contiguous()
