@@ -443,6 +443,43 @@ def test_scratch_size_queries_are_consistent_over_random_sizes():
     assert seen_lists > 100 and seen_ctile > 20 and seen_tile64 > 5
 
 
+def test_the_size_rules_keep_their_own_conditions_over_random_sizes():
+    """helio_render_fwd_choice / helio_render_bwd_choice are host code.  Over random sizes: a split heliostat sum (forward
+    14..17) only between 24 and 511 tiles of 256², its parts never shorter than 448 rays and never fewer than round 3's
+    rule gave (2 / 4 / 8 from 96 / 48 / 24 tiles); the unsplit 256² kernel (5) only from 192 tiles and 200 rays; the 64-ray
+    backward tiles (12) only for fields of more than 32 heliostats on images wider than 64 pixels with a few hundred
+    workgroups; the bench's configurations stay where they are measured; invalid sizes give 0."""
+    import random
+    from doodle_amd import native
+    lib = native.load_library()
+    rng = random.Random(11)
+    seen = {v: 0 for v in (5, 12, 14, 15, 16, 17)}
+    for _ in range(4000):
+        B = rng.choice([1, 2, 4, 7, 16, 25, 32, 48, 64, 100, 128, 256, 384, 500, 512, 1024, 4096])
+        N = rng.choice([1, 8, 33, 50, 96, 200, 257, 300, 448, 500, 1000, 1024, 2000, 5000, 20000])
+        R = rng.choice([16, 64, 65, 100, 128, 129, 256, 257, 512, 1000, 2048])
+        f, b = lib.helio_render_fwd_choice(B, N, R), lib.helio_render_bwd_choice(B, N, R)
+        assert f in (3, 5, 6, 9, 10, 11, 12, 13, 14, 15, 16, 17) and b in (2, 4, 8, 9, 10, 11, 12), (B, N, R, f, b)
+        t256 = B * (-(-R // 256)) ** 2
+        if 14 <= f <= 17:
+            S = 2 << (f - 14)
+            assert R > 128 and 24 <= t256 < 512 and N // S >= 448 and S >= (2 if t256 >= 96 else 4 if t256 >= 48 else 8), (B, N, R, f)
+            assert lib.helio_fwd_scratch_required(B, N, R, 0) > 0
+        if f == 5:
+            assert R > 128 and N >= 200 and t256 >= 192, (B, N, R)
+        if b == 12:
+            ct = -(-R // (128 if R <= 128 else 256))
+            assert N > 32 and R > 64 and 2 * ct * (-(-N // 64)) * B >= 240, (B, N, R)
+        for v in (f, b):
+            if v in seen:
+                seen[v] += 1
+    assert all(n > 10 for n in seen.values()), seen
+    assert lib.helio_render_fwd_choice(512, 2000, 512) == 5 and lib.helio_render_fwd_choice(4096, 5000, 256) == 5
+    assert lib.helio_render_fwd_choice(512, 5000, 256) == 5 and lib.helio_render_fwd_choice(25, 50, 128) in (10, 11, 12)
+    assert lib.helio_render_bwd_choice(512, 2000, 512) == 2 and lib.helio_render_bwd_choice(512, 5000, 256) == 2
+    assert lib.helio_render_fwd_choice(0, 50, 128) == 0 and lib.helio_render_bwd_choice(25, 0, 128) == 0 and lib.helio_render_bwd_choice(25, 50, 0) == 0
+
+
 def test_receiver_attributes_are_live(monkeypatch):
     """The reference reads target_position / target_normal / plane_u / plane_v / target_width / target_height /
     resolution / sigma_scale from the instance at every render (newenv_rl_test_multi_error.py:387-401).  Host logic on
