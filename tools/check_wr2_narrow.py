@@ -12,7 +12,8 @@ from bench import build_field, make_action, time_kernel
 dev = torch.device("cuda")
 ops = native.get_ops()
 print(f"{'B':>4} {'N':>5} {'R':>4} | {'256 rays':>9} {'128 rays':>9} {'64 rays':>9} | {'256+lists':>9} | of the f32 MFMA peak (best dense) | same bits")
-for B, N, R in ((500, 50, 128), (500, 200, 128), (256, 200, 128), (500, 200, 100), (32, 1000, 128), (256, 1000, 128), (4, 5000, 128),
+SIZES = [tuple(int(x) for x in a.split(',')) for a in sys.argv[1:]]       # B,N,R … instead of the table's sizes
+for B, N, R in SIZES or ((500, 50, 128), (500, 200, 128), (256, 200, 128), (500, 200, 100), (32, 1000, 128), (256, 1000, 128), (4, 5000, 128),
                 (32, 5000, 128), (256, 5000, 128), (256, 1000, 64), (256, 5000, 64)):
     w = synthetic.Workload("s", N=N, B=B, R=R, sigma_scale=0.02, error_scale_mrad=40.0)
     helios, suns, errs, noise = synthetic.make_inputs(w, 0)
