@@ -6,6 +6,7 @@
 // (output allocation, pointer extraction, stream lookup, argument marshalling) costs ≈2 µs
 // instead of ≈7 µs.  No arithmetic happens here.  Optional: if it is not built, native.py's
 // ctypes path is used.
+#include <torch/csrc/autograd/anomaly_mode.h>
 #include <torch/extension.h>
 #include <hip/hip_runtime.h>
 #include <c10/hip/HIPFunctions.h>
@@ -773,9 +774,22 @@ class RenderFn : public torch::autograd::Function<RenderFn> {
         const auto sv = ctx->get_saved_variables();
         variable_list out(10);
         if (!g[0].defined() && !g[1].defined() && !g[2].defined()) return out;
-        out[0] = render_bwd(ctx->saved_data["plane"].toInt(), sv[4], sv[1], sv[0], sv[2], ctx->saved_data["stride"].toInt(),
-                            sv[3], sv[5], sv[6], opt_contig(g[0]), opt_contig(g[1]), opt_contig(g[2]),
-                            ctx->saved_data["bwd_variant"].toInt());
+        // a NaN / Inf in the image cotangent: the reference gives NaN for EVERY ray (0·NaN), the lists give 0 for the rays they
+        // drop.  Under torch.autograd.set_detect_anomaly(True) the cotangent is checked — one reduction and
+        // a wait, in the mode where the caller asked for such checks — and a non-finite one runs this backward dense
+        // (field.py's _Render.backward does the same for the ctypes binding)
+        const bool dense = g[0].defined() && g_use_scratch.load(std::memory_order_relaxed) && torch::autograd::AnomalyMode::is_enabled() &&
+                           !at::isfinite(g[0]).all().item<bool>();
+        if (dense) g_use_scratch.store(false);
+        try {
+            out[0] = render_bwd(ctx->saved_data["plane"].toInt(), sv[4], sv[1], sv[0], sv[2], ctx->saved_data["stride"].toInt(),
+                                sv[3], sv[5], sv[6], opt_contig(g[0]), opt_contig(g[1]), opt_contig(g[2]),
+                                ctx->saved_data["bwd_variant"].toInt());
+        } catch (...) {
+            if (dense) g_use_scratch.store(true);
+            throw;
+        }
+        if (dense) g_use_scratch.store(true);
         return out;
     }
 };

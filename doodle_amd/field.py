@@ -46,8 +46,20 @@ class _Render(torch.autograd.Function):
         helios, plane, xs, ys = ctx.consts
         c = lambda g: g.contiguous() if g is not None else None  # noqa: E731
         kw = {} if ctx.bwd_variant is None else {"variant": ctx.bwd_variant}
-        g = _get_ops().render_bwd(helios, sun, normals, trig, ctx.trig_stride, plane,
-                                  rays, xs, ys, c(g_image), c(g_actual), c(g_refl), **kw)
+        ops = _get_ops()
+        # A NaN / Inf in the image cotangent: the reference's autograd gives NaN for EVERY ray (0·NaN), the lists give 0
+        # for the rays they drop.  Under torch.autograd.set_detect_anomaly(True) — where the caller is
+        # looking for exactly that — the cotangent is checked (one reduction and a wait) and such a backward runs dense.
+        dense = (g_image is not None and getattr(ops, "cull", False) and torch.is_anomaly_enabled()
+                 and not bool(torch.isfinite(g_image).all()))
+        if dense:
+            ops.cull = False
+        try:
+            g = ops.render_bwd(helios, sun, normals, trig, ctx.trig_stride, plane,
+                               rays, xs, ys, c(g_image), c(g_actual), c(g_refl), **kw)
+        finally:
+            if dense:
+                ops.cull = True
         return g, None, None, None, None, None, None
 
 

@@ -544,3 +544,39 @@ def test_the_short_last_chunk_of_the_table_kernels_gives_the_full_chunk_s_bits(N
     # the two table kernels sum an image's rays in the same order, pair by pair, whatever their tile and chunk (256² tiles of
     # 64-ray chunks; 128² tiles of 32-ray chunks since round 4): one image, bit for bit
     assert same_bits(a, ops.splat_fwd(rays, f._xs, f._ys, variant=9 - variant, cull=False))
+
+
+def test_a_non_finite_cotangent_under_anomaly_mode_runs_the_backward_dense():
+    """with lists, a NaN in the image cotangent gives 0 (the reference: NaN) for the rays that were dropped —
+    the one documented divergence.  Under torch.autograd.set_detect_anomaly(True) render's backward checks its cotangent
+    and runs dense: the dense gradient's NaN pattern, bit for bit; a finite cotangent keeps the lists (and the bits)."""
+    from doodle_amd import native
+    ops = native.get_ops()
+    N, B, R = 600, 96, 256
+    f, suns, act, _ = field_and_rays(N, B, R, 0.01, 90.0, seed=11, span=40.0)
+    assert ops.lib.helio_bwd_scratch_bytes(B, N, R, 0) > 0
+    G = torch.randn(B, R, R, device=DEV, generator=torch.Generator(device=DEV).manual_seed(1))
+    Gn = G.clone()
+    Gn[3, 17, 40] = float("nan")
+
+    def grad(cot, anomaly, cull=True):
+        ops.cull = cull
+        try:
+            with torch.autograd.set_detect_anomaly(anomaly, check_nan=False):
+                a = act.reshape(B, -1).clone().requires_grad_(True)
+                img, _ = f.render(suns, a, None)
+                (g,) = torch.autograd.grad(img, a, grad_outputs=cot)
+        finally:
+            ops.cull = True
+        return g
+
+    dense = grad(Gn, False, cull=False)
+    nan_rows = torch.isnan(dense.view(B, N, 3)).any(dim=2)
+    assert nan_rows[3].all() and not nan_rows[[0, 1, 2, 4]].any()            # 0·NaN: every ray of image 3, nothing else
+    listed = grad(Gn, False)
+    assert not torch.isnan(listed.view(B, N, 3)[3]).any(dim=1).all()         # the documented divergence: dropped rays read 0
+    checked = grad(Gn, True)
+    assert torch.equal(torch.isnan(checked), torch.isnan(dense))
+    ok = ~torch.isnan(dense)
+    assert torch.equal(bits(checked)[ok], bits(dense)[ok])
+    assert same_bits(grad(G, True), grad(G, False)) and ops.cull             # finite: the lists, the same bits, flag restored
