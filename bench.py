@@ -752,6 +752,24 @@ def extras_leg(field, suns_d, action, w, dev):
         out["render_fwd_bwd_graph_us"] = round(wall(lambda: gr(), 300) * 1e6, 1)
     except Exception as e:  # noqa: BLE001
         out["render_fwd_bwd_graph_error"] = repr(e)
+    # the driver's own sample — 20 renders and a fence — as ONE HIP graph (captured once, untimed): what a caller who captures
+    # its loop gets on any host; the eager sample (`value` at --steps 20) is bound by the host's launch rate and the fence's
+    # wake-up, 4.3–5.7 M frames/s by box
+    try:
+        side, graph = torch.cuda.Stream(), torch.cuda.CUDAGraph()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.no_grad(), torch.cuda.stream(side):
+            for _ in range(3):
+                field.render(suns_d, action, None)
+        torch.cuda.current_stream().wait_stream(side)
+        with torch.no_grad(), torch.cuda.graph(graph):
+            kept = [field.render(suns_d, action, None)[0] for _ in range(20)]
+        t_g = wall(graph.replay, 50)
+        out["render_graph_of_20_frames_per_s"] = round(20 * w.B / t_g, 1)
+        out["render_graph_of_20_us_per_step"] = round(t_g / 20 * 1e6, 2)
+        del kept, graph
+    except Exception as e:  # noqa: BLE001
+        out["render_graph_of_20_error"] = repr(e)
     env = HelioEnv(field.heliostat_positions, torch.tensor(synthetic.TARGET_POSITION, device=dev), synthetic.TARGET_AREA,
                    torch.tensor(synthetic.TARGET_NORMAL, device=dev), sigma_scale=w.sigma_scale,
                    error_scale_mrad=w.error_scale_mrad, resolution=w.R, batch_size=w.B, device=dev)
@@ -773,7 +791,8 @@ def extras_leg(field, suns_d, action, w, dev):
                 "forward + backward kernels for the cotangents (G, 1) in one binding call; _autograd_us = render + "
                 "torch ops + torch.autograd.grad; _graph_us = that iteration replayed from a HIP graph.  env.step = "
                 "render + loss block (2 launches) + NaN/Inf check (one wait on a pinned host record); "
-                "env_step_fwd_bwd adds metrics['dist'].backward(); best of 3 wall-clock loops through the Python surface"})
+                "env_step_fwd_bwd adds metrics['dist'].backward(); best of 3 wall-clock loops through the Python surface.  "
+                "render_graph_of_20: 20 field.render calls captured once as a HIP graph, one replay + synchronize per sample"})
     return out
 
 
