@@ -282,17 +282,26 @@ splat_fwd_mfma_regs(int B, int Nall, int R, const float* __restrict__ rays, cons
             q0 = sRay[k + 4 + lh];
             q1 = sRay[k + 6 + lh];
             float fa0[MBI], fe0[MBJ], fa1[MBI], fe1[MBJ];
+            // the two k-pairs' factors as float PAIRS: the fused multiply-adds of a pair are one v_pk_fma_f32 (the same IEEE
+            // fma per component — bit-identical factors — in half the issue slots: the f32 MFMA and the VALU share a SIMD's
+            // issue, every vector instruction of this loop is MFMA time)
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            const f32x2 pz = {p0.z, p1.z}, px = {p0.x, p1.x}, py = {p0.y, p1.y}, pw = {p0.w, p1.w};
 #pragma unroll
             for (int m = 0; m < MBI; ++m) {
-                const float t0 = __builtin_fmaf(xv[m], p0.z, p0.x), t1 = __builtin_fmaf(xv[m], p1.z, p1.x);
-                fa0[m] = exp2_fast(-__builtin_fmaf(t0, t0, p0.w));
-                fa1[m] = exp2_fast(-__builtin_fmaf(t1, t1, p1.w));
+                const f32x2 c = {xv[m], xv[m]};
+                const f32x2 t = __builtin_elementwise_fma(c, pz, px);
+                const f32x2 a = __builtin_elementwise_fma(t, t, pw);
+                fa0[m] = exp2_fast(-a.x);
+                fa1[m] = exp2_fast(-a.y);
             }
 #pragma unroll
             for (int m = 0; m < MBJ; ++m) {
-                const float u0 = __builtin_fmaf(yv[m], p0.z, p0.y), u1 = __builtin_fmaf(yv[m], p1.z, p1.y);
-                fe0[m] = exp2_fast(-(u0 * u0));
-                fe1[m] = exp2_fast(-(u1 * u1));
+                const f32x2 c = {yv[m], yv[m]};
+                const f32x2 u = __builtin_elementwise_fma(c, pz, py);
+                const f32x2 uu = u * u;
+                fe0[m] = exp2_fast(-uu.x);
+                fe1[m] = exp2_fast(-uu.y);
             }
 #pragma unroll
             for (int mi = 0; mi < MBI; ++mi)
