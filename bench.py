@@ -1008,7 +1008,18 @@ def large_leg(dev, seed, iters=20):
                         "ms": round(tb[0] * 1e3, 3), "dense_ms": round(tb[1] * 1e3, 3),
                         "frames_per_s": round(w.B / tb[0], 1),
                         "gradient_bit_identical_with_dense": bool(torch.equal(g_c.view(torch.int32), g_d.view(torch.int32)))}
-        del G, ones, g_c, g_d
+        # the backward's footprint kernels alone (helio_splat_bwd: both contractions, one launch + the tail form's), dense and
+        # with the lists — the backward's own roofline entry: 4·B·N·R² flops (two fused multiply-adds per (ray, pixel))
+        trig_b, stride_b = field._select_trig(w.B)
+        rays_b = ops.geometry_fwd(field.heliostat_positions, suns_d, action.reshape(w.B, w.N, 3).contiguous(), trig_b, stride_b, field._plane)[2]
+        t_bd, t_bc = time_interleaved([lambda: ops.splat_bwd(rays_b, field._xs, field._ys, G, variant=0, cull=False),
+                                       lambda: ops.splat_bwd(rays_b, field._xs, field._ys, G, variant=0)], max(5, iters // 2))
+        bflops = 2.0 * r["algorithmic_flops"]
+        r["fwd_bwd"]["splat_bwd"] = {"bound": "mfma", "kernel": "splat_bwd_mfma_both (variant %d)" % ops.render_bwd_choice(w.B, w.N, w.R),
+                                     "dense_us": round(t_bd * 1e6, 1), "achieved": round(bflops / t_bd / 1e12, 2), "peak": F32_MFMA_PEAK_TF,
+                                     "unit": "TFLOP/s", "frac": round(bflops / t_bd / 1e12 / F32_MFMA_PEAK_TF, 4),
+                                     "algorithmic_flops": bflops, "with_lists_us": round(t_bc * 1e6, 1)}
+        del G, ones, g_c, g_d, rays_b
     except Exception as e:  # noqa: BLE001
         r["fwd_bwd"] = {"error": repr(e)}
     # the opt-in split-bf16 kernel (HELIO_SPLAT_VARIANT=7) on the same rays, beside the exact-f32 default:
