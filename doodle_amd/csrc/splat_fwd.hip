@@ -1699,7 +1699,11 @@ struct CullPlan { int te, S, P; bool order; };       // te = 0: this call runs d
 constexpr int CULL_WHOLE_IMAGE = 16384;              // a tile edge no image exceeds (R <= 16384)
 static CullPlan cull_fwd_plan(int variant, int B, int N, int R) {
     if (variant == 0 || variant == 2) variant = splat_fwd_choice(B, N, R);
-    if (!cull_enabled() || N < 192) return {0, 1, 0, false};
+    // lists from 192 rays — and from 64 where the call is long enough to carry the two launches in front (round 4,
+    // tools/bench_fwd_tiles.py at both error scales, profiles/r04_w_fwd_lists_small_fields.txt: thousands of suns over a field of
+    // 96–128 heliostats at err 90 mrad: B = 1024, N = 128, R = 256: 172 → 116 µs; B = 500, N = 96, R = 256: 73 → 56; with every
+    // ray live the lists cost 8–12 % there; below 64 rays what they save and what they cost are level, 10–16 % either way)
+    if (!cull_enabled() || N < 64 || (N < 192 && (long)B * N * R * R < (1l << 31))) return {0, 1, 0, false};
     const int S = split_parts(variant);
     // the work order (cull.h) matters once there are more lists than workgroups the chip starts at once; below
     // that its launch is only latency

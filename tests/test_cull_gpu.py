@@ -92,7 +92,7 @@ def splat_with_counts(rays, xs, ys, variant):
     return image, scratch[:4 * B * t * t].view(torch.int32).view(B, t * t).clone()
 
 
-@pytest.mark.parametrize("N,B,R", [(257, 3, 260), (333, 2, 200), (700, 2, 512), (192, 5, 129)])
+@pytest.mark.parametrize("N,B,R", [(257, 3, 260), (333, 2, 200), (700, 2, 512), (192, 5, 129), (96, 90, 512)])      # (96 rays: lists only for long calls)
 @pytest.mark.parametrize("sigma,err", [(0.01, 90.0), (0.01, 180.0), (0.01, 0.0), (0.1, 90.0), (0.002, 20.0)])
 def test_culled_forward_kernels_equal_the_dense_ones_bit_for_bit(N, B, R, sigma, err):
     from doodle_amd import native

@@ -16,9 +16,11 @@ cfg5 = dataclasses.replace(synthetic.CONFIGS["cfg5"], B=512)
 sizes = [("cfg4", cfg4), ("cfg5 shard", cfg5)]
 for B, N, R, span in ((256, 5000, 256, 30.0), (256, 1000, 256, 30.0), (32, 1000, 512, 30.0), (32, 5000, 512, 30.0), (256, 200, 256, 30.0), (256, 1000, 512, 30.0)):
     sizes.append((f"B={B} N={N} R={R} span={span:g}", synthetic.Workload("s", N=N, B=B, R=R, span=span)))
+SIGMA, ERR = float(os.environ.get("HELIO_SIGMA", 0.01)), float(os.environ.get("HELIO_ERR", 90.0))      # (of the sizes given on the command line)
 if len(sys.argv) > 1:        # B N R span quadruples instead
     a = sys.argv[1:]
-    sizes = [(f"B={a[i]} N={a[i + 1]} R={a[i + 2]} span={a[i + 3]}", synthetic.Workload("s", N=int(a[i + 1]), B=int(a[i]), R=int(a[i + 2]), span=float(a[i + 3])))
+    sizes = [(f"B={a[i]} N={a[i + 1]} R={a[i + 2]} span={a[i + 3]}", synthetic.Workload("s", N=int(a[i + 1]), B=int(a[i]), R=int(a[i + 2]), span=float(a[i + 3]),
+                                                                                sigma_scale=SIGMA, error_scale_mrad=ERR))
              for i in range(0, len(a) - 3, 4)]
 print(f"{'size':28s} | " + " | ".join(f"v{v} dense   lists  live" for v in (3, 4, 5)) + " | auto = v, us")
 for name, w in sizes:
