@@ -974,6 +974,12 @@ static bool tile64_lists_pay(int B, int N, int R) {
     const int ct = (R + (R <= 128 ? 127 : 255)) / (R <= 128 ? 128 : 256);
     return N > 256 && 2l * ct * ((N + 63) / 64) * B > 768 && (long)B * N * R * R >= (1l << 31);
 }
+// … and for fields of 65–256 heliostats (two to four 64-ray tiles; the 256-ray tiles have nothing to skip there): thousands
+// of suns over a small field at the reference's default error scale, where half the rays are dead per image
+static bool tile64_lists_small(int B, int N, int R) {
+    const int ct = (R + (R <= 128 ? 127 : 255)) / (R <= 128 ? 128 : 256);
+    return N > 64 && N <= 256 && 2l * ct * ((N + 63) / 64) * B > 768 && (long)B * N * R * R >= (1l << 31);
+}
 static bool bwd_tile64(int B, int N, int R) {
     if (N <= 32 || R <= 64) return false;
     const int ct = (R + (R <= 128 ? 127 : 255)) / (R <= 128 ? 128 : 256);
@@ -1743,7 +1749,9 @@ static int resolve_bwd(int variant, int B, int N, int R) {
 // → the kernel this call runs CAN walk a list (what a launch with enough scratch does) …
 static bool cull_bwd_possible(int variant, int B, int N, int R) {
     variant = resolve_bwd(variant, B, N, R);
-    if (!cull_enabled() || N <= 256) return false;
+    // (up to 256 rays the 256-ray tiles and the small tiles' 256-ray groups are one per image: nothing to skip; the 64-ray
+    // tiles are several from 65 rays)
+    if (!cull_enabled() || N <= (variant == 12 ? 64 : 256)) return false;
     return variant == 2 || variant == 9 || variant == 12;
 }
 // … and it PAYS (what the size query answers: a caller that sizes its scratch by the query hands none otherwise)
@@ -1753,7 +1761,7 @@ static bool cull_bwd_wanted(int variant, int B, int N, int R) {
     const long ray_tiles = (N + 255) / 256;
     if (variant == 2) return 2l * B * ((R + (R <= 128 ? 127 : 255)) / (R <= 128 ? 128 : 256)) * ray_tiles > 256;   // (both passes are one launch)
     // the 64-ray tiles: three workgroups per CU, and footprint work enough beside the three launches in front
-    if (variant == 12) return tile64_lists_pay(B, N, R);
+    if (variant == 12) return N > 256 ? tile64_lists_pay(B, N, R) : tile64_lists_small(B, N, R);
     // (both passes in one launch; two 4-wave workgroups fit a CU; and enough footprint work for the ≈15 µs of the
     // launches in front to be small beside it — grid A/B at err 90 / σs 0.01: B = 32, N = 5000, R = 64, 45 µs dense:
     // 54 µs with lists; B = 4, N = 5000, R = 256, 85 µs: 72 µs; B = 256, N = 5000, R = 64, 325 µs: 271 µs)

@@ -580,3 +580,29 @@ def test_a_non_finite_cotangent_under_anomaly_mode_runs_the_backward_dense():
     ok = ~torch.isnan(dense)
     assert torch.equal(bits(checked)[ok], bits(dense)[ok])
     assert same_bits(grad(G, True), grad(G, False)) and ops.cull             # finite: the lists, the same bits, flag restored
+
+
+@pytest.mark.parametrize("N,B,R", [(96, 5, 260), (160, 3, 512), (200, 4, 128), (256, 2, 300), (65, 3, 200)])
+@pytest.mark.parametrize("sigma,err", [(0.01, 90.0), (0.1, 90.0)])
+def test_64_ray_tiles_walk_lists_from_65_rays(N, B, R, sigma, err):
+    """Fields of 65–256 heliostats are ONE 256-ray tile (nothing to skip) but two to four 64-ray tiles: variant 12 walks lists
+    there too (round 4: thousands of suns over a small field at err 90 — B=2048, N=96, R=256: 638 → 474 µs).  Culled == dense
+    bit for bit, both list layouts; the size query asks for them only where the call is long."""
+    from doodle_amd import native
+    ops = native.get_ops()
+    f, suns, act, rays = field_and_rays(N, B, R, sigma, err, seed=N + R + 5, span=30.0)
+    G = torch.randn(B, R, R, device=DEV, generator=torch.Generator(device=DEV).manual_seed(5))
+    dense = ops.splat_bwd(rays, f._xs, f._ys, G, variant=12, cull=False)
+    culled, counts, need = splat_bwd_with_list(rays, f._xs, f._ys, G, 12)
+    assert same_bits(culled, dense) and int(counts.min()) >= 0 and int(counts.max()) <= N
+    assert same_bits(dense, ops.splat_bwd(rays, f._xs, f._ys, G, variant=2, cull=False))
+    if bwd_lists_per_image(R, 12) > 1:
+        fallback, counts1, _ = splat_bwd_with_list(rays, f._xs, f._ys, G, 12, per_image=True)
+        assert same_bits(fallback, dense) and counts1.numel() == B
+    if sigma == 0.01:
+        assert int(counts.sum()) < counts.numel() * N
+    else:
+        assert int(counts.sum()) == counts.numel() * N
+    assert ops.lib.helio_bwd_scratch_bytes(B, N, R, 12) == 0                       # a short call: dense
+    assert ops.lib.helio_bwd_scratch_bytes(2048, 96, 256, 0) > 0 and ops.lib.helio_render_bwd_choice(2048, 96, 256) == 12
+    assert ops.lib.helio_bwd_scratch_bytes(2048, 64, 256, 0) == 0 and ops.lib.helio_bwd_scratch_bytes(2048, 200, 256, 2) == 0

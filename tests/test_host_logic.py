@@ -435,7 +435,7 @@ def test_scratch_size_queries_are_consistent_over_random_sizes():
             seen_lists += 1
             seen_ctile += bwd == per_ctile and ct > 1
             seen_tile64 += tile == 64
-            assert N > 256
+            assert N > 256 or (tile == 64 and N > 64)          # (the 64-ray tiles are several per image from 65 rays)
         for v in (1, 4, 5, 6, 7, 8):
             assert lib.helio_bwd_scratch_bytes(B, N, R, v) == 0
         for v in (1, 6, 7, 8, 10, 11, 12, 13):

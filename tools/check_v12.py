@@ -16,8 +16,8 @@ print(f"# sigma_scale {SIGMA}, error_scale_mrad {ERR}")
 print(f"{'B':>4} {'N':>4} {'R':>4} | {'auto':>9} {'=v':>3} | {'v12':>9} {'v2':>9} {'v10':>9} {'v8':>9} | {'v12 dense':>9} {'v2 dense':>9} | v12 == v2 bits")
 OTHER = 9 if WIDE else 8
 for R in ((128, 256, 512) if WIDE else (100, 128, 256, 512)):
-    for N in ((260, 300, 320, 384, 448, 520, 576, 640) if WIDE else (40, 50, 64, 96, 128, 200) if R <= 128 else (33, 160, 192)):
-        for B in ((32, 128, 500) if WIDE else (60, 256, 500)):
+    for N in ((260, 300, 320, 384, 448, 520, 576, 640) if WIDE else (96, 128, 160, 200) if len(sys.argv) > 1 and sys.argv[1] == "small" else (40, 50, 64, 96, 128, 200) if R <= 128 else (33, 160, 192)):
+        for B in ((32, 128, 500) if WIDE else (500, 2048) if len(sys.argv) > 1 and sys.argv[1] == "small" else (60, 256, 500)):
             if B * N * R * R > 2e10:
                 continue
             w = synthetic.Workload("s", N=N, B=B, R=R, sigma_scale=SIGMA, error_scale_mrad=ERR, span=30.0 if N > 100 else 10.0)
