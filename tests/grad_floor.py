@@ -31,7 +31,7 @@ from conftest import ENV_FIXTURES, golden, render_fixture_names  # noqa: E402
 from oracle import torch_oracle as to  # noqa: E402
 
 DEV = "cuda"
-BWD_VARIANTS = (0, 1, 2, 3, 4, 5, 6, 7, 8)
+BWD_VARIANTS = (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12)
 RENDER_KEYS = ("grad_from_image", "grad_from_actual", "grad_from_refl", "grad_all")
 ENV_KEYS = ("mse", "dist", "bound", "alignment_loss")
 
